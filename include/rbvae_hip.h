@@ -1,0 +1,115 @@
+/* librbvae_hip -- C ABI of the MI355X (gfx950) RBVAE hot path.
+ *
+ * The reference (matt-suncy/symbols-from-video) has no FFI: its hot path is the
+ * torch ops issued by Seq2SeqBinaryVAE.forward/encode and by the trainer's loss
+ * functions.  Each entry point below replaces one of those op groups; the
+ * reference call site it stands in for is cited as file:line (relative to the
+ * reference root).  INTEGRATION.md shows the ctypes stub a maintainer adds.
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer valid for the duration of the call in
+ *    stream order; the library never allocates, frees or retains them;
+ *  - `stream` is a hipStream_t (NULL = default stream); calls are asynchronous
+ *    and never synchronise;
+ *  - return value 0 = ok, negative = RBVAE_E_*; rbvae_last_error() gives a
+ *    thread-local message; nothing throws or exits across the boundary;
+ *  - `dtype` selects the activation/weight storage type of the conv/linear
+ *    kernels: RBVAE_F32 (exact-fp32 parity mode, f32 MFMA) or RBVAE_BF16
+ *    (bf16 storage, f32 accumulation, bf16 MFMA).  LSTM, binarise and the loss
+ *    reductions are always f32;
+ *  - activations are NHWC ("pixel rows of C channels"), weights are the packed
+ *    layouts produced by rbvae_pack_conv_weight / rbvae_pack_linear_weight.
+ */
+#ifndef RBVAE_HIP_H
+#define RBVAE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RBVAE_OK 0
+#define RBVAE_E_INVALID (-1)     /* bad argument (shape, alignment, null pointer) */
+#define RBVAE_E_LAUNCH (-2)      /* HIP reported a launch error */
+#define RBVAE_E_UNSUPPORTED (-3) /* configuration outside what the kernels cover */
+
+#define RBVAE_F32 0
+#define RBVAE_BF16 1
+
+int rbvae_version(void);
+const char* rbvae_last_error(void);
+
+/* ---- binarise + KL -------------------------------------------------------
+ * binary_concrete_logits (models/percep_RBVAE/percep_RBVAE_model.py:17-44; triplet
+ * variant triplet_RBVAE_model.py:18-45 = noise_ratio 1; simple variant
+ * simple_RBVAE_model.py:17-44 = noise_eps 1e-10) fused with kl_binary_concrete
+ * applied to the SAMPLE z (models/percep_RBVAE/percep_RBVAE_train.py:52-76 as
+ * called at :528).  U is the uniform noise the reference draws with torch.rand
+ * on the host (:33); the caller supplies it so codes are reproducible.
+ *   y_soft = sigmoid((h + r*(log(U+e) - log(1-U+e))) / tau)
+ *   z      = hard ? (y_soft > 0.5) : y_soft
+ *   kl_mean[0] = mean_rows sum_L KL(clamp(sigmoid(z)) || Bernoulli(p))
+ * kl_mean may be NULL (encode path). */
+int rbvae_binarize_kl_fwd(const float* h, const float* U, float* y_soft, float* z, float* kl_mean,
+                          int rows, int L, float tau, float noise_ratio, float noise_eps, int hard,
+                          float kl_p, float kl_eps, int kl_clamp, void* stream);
+/* dh (+)= (g_z + kl_weight * gscale * dKL/dz) * y_soft*(1-y_soft)/tau (straight-through when hard).
+ * g_z may be NULL; gscale_dev (device scalar, may be NULL = 1) multiplies kl_weight. */
+int rbvae_binarize_kl_bwd(const float* g_z, const float* y_soft, const float* z, float* dh, int accumulate,
+                          int rows, int L, float tau, float kl_weight, const float* gscale_dev,
+                          float kl_p, float kl_eps, int kl_clamp, void* stream);
+
+/* kl_binary_concrete as a free function (percep_RBVAE_train.py:52-76; simple
+ * variant simple_RBVAE_train.py:45-68 = clamp 0, eps 1e-10). */
+int rbvae_kl_fwd(const float* q_logits, float* out_mean, int rows, int L, float p, float eps, int clamp,
+                 void* stream);
+int rbvae_kl_bwd(const float* q_logits, float* dq, int rows, int L, float p, float eps, int clamp,
+                 float scale, const float* gscale_dev, void* stream);
+
+/* ---- pairwise-distance losses -------------------------------------------
+ * contrast_loss 'euclidean' branch (percep_RBVAE_train.py:79-107):
+ *   d = ||x1 - x2 + eps||_2 over L;  label 0: mean(d^2);  label 1: mean(max(margin-d,0)^2)
+ * Rows are addressed as base + row*stride so h_seq[:, s] slices need no copy. */
+int rbvae_pairdist_fwd(const float* x1, const float* x2, long stride1, long stride2, int rows, int L,
+                       int label, float margin, float eps, float* out_mean, void* stream);
+int rbvae_pairdist_bwd(const float* x1, const float* x2, long stride1, long stride2, int rows, int L,
+                       int label, float margin, float eps, float scale, const float* gscale_dev,
+                       float* dx1, float* dx2, long dstride1, long dstride2, int accumulate, void* stream);
+/* The trainer's whole contrastive term in one launch (percep_RBVAE_train.py:534-543):
+ *   mean_{b,t} d(h0,h1)^2 + 1/(T-1) sum_s mean_b max(1 - d(h0[:,s],h0[:,s+1]),0)^2, eps 1e-6.
+ * h0,h1: [B,T,L] contiguous.  bwd WRITES dh0,dh1 (scale * d term/dh). */
+int rbvae_contrast_term_fwd(const float* h0, const float* h1, int B, int T, int L, float* out, void* stream);
+int rbvae_contrast_term_bwd(const float* h0, const float* h1, int B, int T, int L, float scale,
+                            const float* gscale_dev, float* dh0, float* dh1, void* stream);
+/* F.triplet_margin_loss(p=2, eps, swap) (triplet_RBVAE_train.py:82-96) on strided rows. */
+int rbvae_triplet_fwd(const float* a, const float* p, const float* n, long sa, long sp, long sn, int rows, int L,
+                      float margin, float eps, int swap, float* out_mean, void* stream);
+int rbvae_triplet_bwd(const float* a, const float* p, const float* n, long sa, long sp, long sn, int rows, int L,
+                      float margin, float eps, int swap, float scale, const float* gscale_dev,
+                      float* da, float* dp, float* dn, long dsa, long dsp, long dsn, int accumulate, void* stream);
+/* The triplet trainer's term (triplet_RBVAE_train.py:461-468): anchor h0[:,s], positive
+ * h1[:,s], negative h0[:,s+1], averaged over s < T-1; eps 1e-8, swap on. bwd WRITES. */
+int rbvae_triplet_term_fwd(const float* h0, const float* h1, int B, int T, int L, float margin, float* out,
+                           void* stream);
+int rbvae_triplet_term_bwd(const float* h0, const float* h1, int B, int T, int L, float margin, float scale,
+                           const float* gscale_dev, float* dh0, float* dh1, void* stream);
+
+/* recon_loss = F.mse_loss (percep_RBVAE_train.py:32-33).  ws: >= rbvae_mse_ws_floats(n) floats. */
+size_t rbvae_mse_ws_floats(long n);
+int rbvae_mse_fwd(const float* a, const float* b, long n, float* out_mean, float* ws, void* stream);
+int rbvae_mse_bwd(const float* a, const float* b, long n, float scale, const float* gscale_dev, float* da,
+                  void* stream);
+
+/* ---- hardware-map probes (diagnostics; tests/test_hw_maps.py) ------------------
+ * One-wave kernels that pin the gfx950 lane maps the GEMM kernels assume. */
+int rbvae_dbg_mfma_bf16(const void* A, const void* B, float* D, void* stream);   /* [16x32]x[32x16] bf16 */
+int rbvae_dbg_mfma_f32(const float* A, const float* B, float* D, void* stream);  /* [16x4]x[4x16] f32 */
+int rbvae_dbg_glds(const void* src, const int* lane_src_chunk, void* out, void* stream);
+int rbvae_dbg_tr16(const void* img, const int* rowsel, const int* colsel, void* out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RBVAE_HIP_H */

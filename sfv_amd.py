@@ -1,0 +1,11 @@
+"""Importable alias of the `symbols-from-video_amd` package (hyphenated directory)."""
+import importlib
+import os
+import sys
+
+_root = os.path.dirname(os.path.abspath(__file__))
+if _root not in sys.path:
+    sys.path.insert(0, _root)
+_pkg = importlib.import_module("symbols-from-video_amd")
+globals().update({k: v for k, v in vars(_pkg).items() if not k.startswith("__")})
+pkg = _pkg

@@ -1,0 +1,9 @@
+"""MI355X-native RBVAE hot path (gfx950): Python host side over librbvae_hip.so.
+
+The directory name carries a hyphen (it mirrors the reference repository's name),
+so import it with importlib -- `sfv_amd.py` at the repo root does that:
+
+    import sfv_amd as sfv
+    model = sfv.Seq2SeqBinaryVAE(in_channels=4, out_channels=4, latent_dim=32, variant="percep")
+"""
+from . import _lib  # noqa: F401

@@ -1,0 +1,80 @@
+// Shared host/device helpers for librbvae_hip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hip/hip_bf16.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+
+#include "../../include/rbvae_hip.h"
+
+namespace rbvae {
+
+// thread-local message behind rbvae_last_error()
+char* err_buf();
+int fail(int code, const char* fmt, ...);
+
+#define RBVAE_CHECK_ARG(cond, ...) \
+    do { if (!(cond)) return ::rbvae::fail(RBVAE_E_INVALID, __VA_ARGS__); } while (0)
+
+#define RBVAE_CHECK_LAUNCH(name) \
+    do { hipError_t e__ = hipGetLastError(); \
+         if (e__ != hipSuccess) return ::rbvae::fail(RBVAE_E_LAUNCH, "%s: %s", name, hipGetErrorString(e__)); \
+    } while (0)
+
+static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+// ---- device helpers -------------------------------------------------------
+typedef unsigned short bf16_t;   // raw bf16 bits
+
+__device__ __forceinline__ float bf16_to_f32(bf16_t v) {
+    return __uint_as_float(((unsigned)v) << 16);
+}
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) {
+    // plain cast: hipcc emits v_cvt_pk_bf16_f32 (round-to-nearest-even, NaN stays NaN)
+    __hip_bfloat16 b = __float2bfloat16(f);
+    return *reinterpret_cast<bf16_t*>(&b);
+}
+
+template <typename T> struct Elem;
+template <> struct Elem<float> {
+    static __device__ __forceinline__ float load(const float* p) { return *p; }
+    static __device__ __forceinline__ void store(float* p, float v) { *p = v; }
+};
+template <> struct Elem<bf16_t> {
+    static __device__ __forceinline__ float load(const bf16_t* p) { return bf16_to_f32(*p); }
+    static __device__ __forceinline__ void store(bf16_t* p, float v) { *p = f32_to_bf16(v); }
+};
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// Sum over the whole block in a FIXED order (bitwise reproducible).  `red` holds
+// one float per wave; every thread returns the total.
+__device__ __forceinline__ float block_sum(float v, float* red) {
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    __syncthreads();
+    if (lane == 0) red[wid] = v;
+    __syncthreads();
+    float t = 0.f;
+    for (int i = 0; i < nw; ++i) t += red[i];
+    return t;
+}
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+// Counter-based uniform bits for dropout: one 32-bit draw per element index.
+// (squares-style mixing of (seed, index); statistical quality is ample for a keep-mask)
+__device__ __forceinline__ unsigned hash_u32(unsigned long long seed, unsigned long long idx) {
+    unsigned long long x = (idx + 1) * 0x9E3779B97F4A7C15ull + seed;
+    x ^= x >> 32; x *= 0xD6E8FEB86659FD93ull;
+    x ^= x >> 32; x *= 0xD6E8FEB86659FD93ull;
+    x ^= x >> 32;
+    return (unsigned)x;
+}
+
+}  // namespace rbvae

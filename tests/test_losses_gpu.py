@@ -1,0 +1,152 @@
+"""HIP binarise/KL and loss reductions against the oracle and the reference fixtures."""
+import numpy as np
+import pytest
+import torch
+
+import rbvae_oracle as O
+from _golden import load
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def L():
+    import sfv_amd
+    return sfv_amd._lib
+
+
+def dev(a):
+    return torch.as_tensor(np.asarray(a)).contiguous().cuda()
+
+
+def test_binarize_codes_vs_reference_fixture(L):
+    g = load("functions")
+    flips = 0
+    for i in range(int(g["bin/count"])):
+        tau, r, hard, eps = (float(v) for v in g[f"bin/{i}/cfg"])
+        h, U = dev(g[f"bin/{i}/logits"]), dev(g[f"bin/{i}/U"])
+        y, z = torch.empty_like(h), torch.empty_like(h)
+        L.call("rbvae_binarize_kl_fwd", h, U, y, z, None, h.shape[0], h.shape[1], tau, r, eps, int(hard),
+               0.5, 1e-8, 1)
+        ref = g[f"bin/{i}/y"]
+        if hard:
+            # codes are bit-exact wherever the pre-activation is not within rounding of 0
+            noise = r * (np.log(g[f"bin/{i}/U"] + eps) - np.log(1 - g[f"bin/{i}/U"] + eps))
+            margin = np.abs(g[f"bin/{i}/logits"] + noise)
+            safe = margin > 1e-5
+            assert np.array_equal(z.cpu().numpy()[safe], ref[safe])
+            flips += int((z.cpu().numpy() != ref).sum())
+        else:
+            np.testing.assert_allclose(z.cpu().numpy(), ref, atol=2e-6)
+    assert flips == 0
+
+
+def test_kl_value_and_grad(L):
+    g = load("functions")
+    z = dev(g["kl/z"])
+    rows, Ld = z.shape[0] * z.shape[1], z.shape[2]
+    for p in (0.1, 0.5):
+        out = torch.empty(1, device="cuda")
+        L.call("rbvae_kl_fwd", z, out, rows, Ld, p, 1e-8, 1)
+        assert abs(out.item() - float(g[f"kl/p{p}/val"])) < 1e-5
+        dq = torch.empty_like(z)
+        L.call("rbvae_kl_bwd", z, dq, rows, Ld, p, 1e-8, 1, 1.0, None)
+        np.testing.assert_allclose(dq.cpu().numpy(), g[f"kl/p{p}/grad"], atol=1e-7)
+    lg = dev(g["kl_simple/logits"])
+    out = torch.empty(1, device="cuda")
+    L.call("rbvae_kl_fwd", lg, out, lg.shape[0], lg.shape[1], 0.1, 1e-10, 0)
+    assert abs(out.item() - float(g["kl_simple/val"])) < 1e-5
+    dq = torch.empty_like(lg)
+    L.call("rbvae_kl_bwd", lg, dq, lg.shape[0], lg.shape[1], 0.1, 1e-10, 0, 1.0, None)
+    np.testing.assert_allclose(dq.cpu().numpy(), g["kl_simple/grad"], atol=2e-7)
+
+
+def test_binarize_kl_fused_bwd(L):
+    gen = torch.Generator().manual_seed(3)
+    rows, Ld, tau, r = 24, 25, 0.7, 0.3
+    h = torch.randn(rows, Ld, generator=gen, requires_grad=True)
+    U = torch.rand(rows, Ld, generator=gen)
+    gz = torch.randn(rows, Ld, generator=gen)
+    for hard in (0, 1):
+        z = O.binarize(h, U, tau, bool(hard), r, 1e-8)
+        loss = (z * gz).sum() + 0.3 * O.kl_binary_concrete(z.reshape(4, 6, Ld), 0.1)
+        (gh,) = torch.autograd.grad(loss, h)
+        y, zd, kl = torch.empty(rows, Ld, device="cuda"), torch.empty(rows, Ld, device="cuda"), torch.empty(1, device="cuda")
+        L.call("rbvae_binarize_kl_fwd", h.detach().cuda(), U.cuda(), y, zd, kl, rows, Ld, tau, r, 1e-8, hard, 0.1, 1e-8, 1)
+        assert abs(kl.item() - O.kl_binary_concrete(z.detach(), 0.1).item()) < 1e-5
+        dh = torch.full((rows, Ld), 7.0, device="cuda")
+        L.call("rbvae_binarize_kl_bwd", gz.cuda(), y, zd, dh, 0, rows, Ld, tau, 0.3, None, 0.1, 1e-8, 1)
+        np.testing.assert_allclose(dh.cpu().numpy(), gh.numpy(), atol=2e-6, rtol=1e-5)
+
+
+def test_pairdist_and_contrast_term(L):
+    g = load("functions")
+    a, b = dev(g["contrast/a"]), dev(g["contrast/b"])
+    B, T, Ld = a.shape
+    for label in (0, 1):
+        out = torch.empty(1, device="cuda")
+        L.call("rbvae_pairdist_fwd", a, b, Ld, Ld, B * T, Ld, label, 1.0, 1e-6, out)
+        assert abs(out.item() - float(g[f"contrast/l{label}/val"])) < 1e-6
+        da, db = torch.empty_like(a), torch.empty_like(b)
+        L.call("rbvae_pairdist_bwd", a, b, Ld, Ld, B * T, Ld, label, 1.0, 1e-6, 1.0, None, da, db, Ld, Ld, 0)
+        np.testing.assert_allclose(da.cpu().numpy(), g[f"contrast/l{label}/ga"], atol=1e-7)
+        np.testing.assert_allclose(db.cpu().numpy(), g[f"contrast/l{label}/gb"], atol=1e-7)
+    # whole trainer term vs oracle (values + grads), odd sizes
+    gen = torch.Generator().manual_seed(4)
+    for (B, T, Ld) in ((3, 5, 25), (16, 8, 32), (2, 2, 100), (5, 17, 128)):
+        h0 = (torch.randn(B, T, Ld, generator=gen) * 0.2).requires_grad_()
+        h1 = (torch.randn(B, T, Ld, generator=gen) * 0.2).requires_grad_()
+        ref = O.contrast_term(h0, h1)
+        g0, g1 = torch.autograd.grad(ref * 0.5, (h0, h1))
+        out = torch.empty(1, device="cuda")
+        L.call("rbvae_contrast_term_fwd", h0.detach().cuda(), h1.detach().cuda(), B, T, Ld, out)
+        assert abs(out.item() - ref.item()) < 2e-6 * max(1.0, abs(ref.item()))
+        d0, d1 = torch.empty(B, T, Ld, device="cuda"), torch.empty(B, T, Ld, device="cuda")
+        L.call("rbvae_contrast_term_bwd", h0.detach().cuda(), h1.detach().cuda(), B, T, Ld, 0.5, None, d0, d1)
+        np.testing.assert_allclose(d0.cpu().numpy(), g0.numpy(), atol=1e-6)
+        np.testing.assert_allclose(d1.cpu().numpy(), g1.numpy(), atol=1e-6)
+    with pytest.raises(ValueError):
+        L.call("rbvae_contrast_term_fwd", a, b, 4, 1, 25, torch.empty(1, device="cuda"))
+
+
+def test_triplet(L):
+    g = load("functions")
+    a, p, n = dev(g["triplet/a"]), dev(g["triplet/p"]), dev(g["triplet/n"])
+    rows, Ld = a.shape
+    for m in (0.2, 1.0):
+        out = torch.empty(1, device="cuda")
+        L.call("rbvae_triplet_fwd", a, p, n, Ld, Ld, Ld, rows, Ld, m, 1e-8, 1, out)
+        assert abs(out.item() - float(g[f"triplet/m{m}/val"])) < 1e-6
+        da, dp, dn = (torch.empty_like(a) for _ in range(3))
+        L.call("rbvae_triplet_bwd", a, p, n, Ld, Ld, Ld, rows, Ld, m, 1e-8, 1, 1.0, None, da, dp, dn, Ld, Ld, Ld, 0)
+        for nm, d in zip("apn", (da, dp, dn)):
+            np.testing.assert_allclose(d.cpu().numpy(), g[f"triplet/m{m}/g{nm}"], atol=1e-7)
+    gen = torch.Generator().manual_seed(5)
+    for (B, T, Ld) in ((3, 5, 16), (8, 9, 50)):
+        h0 = (torch.randn(B, T, Ld, generator=gen) * 0.2).requires_grad_()
+        h1 = (torch.randn(B, T, Ld, generator=gen) * 0.2).requires_grad_()
+        ref = O.triplet_term(h0, h1, 0.2)
+        g0, g1 = torch.autograd.grad(ref * 2.0, (h0, h1))
+        out = torch.empty(1, device="cuda")
+        L.call("rbvae_triplet_term_fwd", h0.detach().cuda(), h1.detach().cuda(), B, T, Ld, 0.2, out)
+        assert abs(out.item() - ref.item()) < 2e-6
+        d0, d1 = torch.empty(B, T, Ld, device="cuda"), torch.empty(B, T, Ld, device="cuda")
+        L.call("rbvae_triplet_term_bwd", h0.detach().cuda(), h1.detach().cuda(), B, T, Ld, 0.2, 2.0, None, d0, d1)
+        np.testing.assert_allclose(d0.cpu().numpy(), g0.numpy(), atol=1e-6)
+        np.testing.assert_allclose(d1.cpu().numpy(), g1.numpy(), atol=1e-6)
+
+
+def test_mse(L):
+    g = load("functions")
+    a, b = dev(g["recon/xr"]), dev(g["recon/x"])
+    ws = torch.empty(L.query("rbvae_mse_ws_floats", a.numel()), device="cuda")
+    out = torch.empty(1, device="cuda")
+    L.call("rbvae_mse_fwd", a, b, a.numel(), out, ws)
+    assert abs(out.item() - float(g["recon/val"])) < 1e-7
+    gen = torch.Generator().manual_seed(6)
+    x, y = torch.rand(1_000_003, generator=gen), torch.rand(1_000_003, generator=gen)
+    L.call("rbvae_mse_fwd", x.cuda(), y.cuda(), x.numel(), out, ws)
+    assert abs(out.item() - ((x.double() - y.double()) ** 2).mean().item()) < 1e-6
+    da = torch.empty(x.numel(), device="cuda")
+    L.call("rbvae_mse_bwd", x.cuda(), y.cuda(), x.numel(), 0.5, None, da)
+    np.testing.assert_allclose(da.cpu().numpy(), (0.5 * 2 * (x - y) / x.numel()).numpy(), atol=1e-12, rtol=1e-5)
