@@ -102,6 +102,85 @@ int rbvae_mse_fwd(const float* a, const float* b, long n, float* out_mean, float
 int rbvae_mse_bwd(const float* a, const float* b, long n, float scale, const float* gscale_dev, float* da,
                   void* stream);
 
+/* ---- row-gather GEMM on the matrix cores ---------------------------------------
+ * Out[orow(m)][n] = epi( sum_{taps j} sum_{k<Kc} A[arow(m,j)][k] * W[n][widx_j][k] ), NHWC rows.
+ * Replaces nn.Conv2d(k,2,1) forward (percep_RBVAE_model.py:51-57), nn.ConvTranspose2d(k,2,1,op)
+ * forward (:76-82, as the conv's input gradient over 4 output-parity classes), the
+ * backward-data passes of both (autograd of percep_RBVAE_train.py:552) and, with one tap,
+ * the wide Linear products (:61,:74).
+ *   m -> (n, a, b) over Nimg x TH x TW;  A pixel (a*sa+dh_j, b*sa+dw_j) of an IH x IW grid (zero
+ *   outside);  Out pixel (a*so+oh0, b*so+ow0) of an OH x OW grid;  grid.z = parity class.
+ *   class_desc is a HOST int array: per class [ntaps, oh0, ow0, ntaps x (widx, dh, dw)].
+ *   epilogue: +bias, relu, *scale, dropout (drop_mode 1: counter hash of (seed, element index),
+ *   2: explicit u8 keep-mask [rows][Nout]), then zero where gate <= 0 (saved activation:
+ *   ReLU/dropout backward).  zero_page: >= 128 zero bytes.  Kc % (128/sizeof T) == 0, Nout % 8 == 0. */
+int rbvae_gather_gemm(int dtype, const void* A, const void* W, void* Out, const float* bias, const void* gate,
+                      const void* mask, const void* zero_page, int Nimg, int IH, int IW, int TH, int TW, int sa,
+                      int OH, int OW, int so, int Kc, int Nout, int lda, int ldo, int taps_total, int nclass,
+                      const int* class_desc, int relu, int drop_mode, float drop_p, float scale,
+                      unsigned long long seed, void* stream);
+
+/* ---- weight-gradient GEMM ---------------------------------------------------------
+ * dW[ks][co][t][ci] = sum over K-slice ks of Dy[p][co] * In[idx[t][p]][ci]  (f32 slabs, one per
+ * K-slice; sum them with rbvae_permute_reduce).  idx = rbvae_conv_gather_index table or NULL
+ * (identity, 1 tap: Linear).  Autograd of the Conv2d/ConvTranspose2d/Linear weights
+ * (percep_RBVAE_model.py:51-61,74-82). */
+int rbvae_conv_gather_index(int* idx, int Nimg, int IH, int IW, int OH, int OW, int KH, int KW, int stride,
+                            int pad, void* stream);
+int rbvae_wgrad_gemm(int dtype, const void* Dy, const void* In, float* dW_slabs, const int* idx,
+                     const void* zero_page, int P, int Co, int Ci, int ldy, int ldi, int taps, int ksplit,
+                     void* stream);
+
+/* ---- layout helpers --------------------------------------------------------------
+ * pack3:          out[i0*s0+i1*s1+i2*s2] = (T) in[i0][i1][i2]        (torch f32 weight -> packed T)
+ * permute_reduce: out[i0][i1][i2] (+)= scale * sum_k in[k*slab+i0*s0+i1*s1+i2*s2]  (slabs -> torch grad)
+ * cast_pad:       f32 [rows][L] -> T [rows][Lpad], zero padded
+ * colsum:         out[C] (+)= scale * sum_p X[p][c]  (bias gradients); ws >= colsum_ws_floats */
+int rbvae_pack3(int dtype, const float* in, void* out, int d0, int d1, int d2, long s0, long s1, long s2,
+                void* stream);
+int rbvae_permute_reduce(const float* in, int nslab, long slab_stride, float* out, int d0, int d1, int d2, long s0,
+                         long s1, long s2, float scale, int accumulate, void* stream);
+int rbvae_cast_pad(int dtype, const float* in, void* out, int rows, int L, int Lpad, void* stream);
+size_t rbvae_colsum_ws_floats(int P, int C);
+int rbvae_colsum(int dtype, const void* X, int P, int C, int ld, float* out, float* ws, float scale, int accumulate,
+                 void* stream);
+
+/* im2col of a strided f32 image (element strides sn,sc,sh,sw) into col[N*OH*OW][Kpad], column
+ * (kh*KW+kw)*C + c: the 3/4-channel first Conv2d (percep_RBVAE_model.py:51) and the last
+ * ConvTranspose2d's backward run as plain GEMMs on it. */
+int rbvae_im2col(int dtype, const float* src, long sn, long sc, long sh, long sw, int N, int C, int IH, int IW,
+                 int OH, int OW, int KH, int KW, int stride, int pad, int Kpad, void* col, void* stream);
+/* Last ConvTranspose2d + Sigmoid (percep_RBVAE_model.py:82-83) fused with recon_loss
+ * (percep_RBVAE_train.py:32-33): Y[(n,a,b)][t*Cout+co] = per-tap products; gathers them (col2im),
+ * adds bias, applies sigmoid, writes x_recon NCHW f32; with target: sse_mean[0] = mse and
+ * dpre[n][oh][ow][co] = gscale*gscale_dev*(xr-x)*xr*(1-xr).  ws >= col2im_ws_floats floats. */
+size_t rbvae_col2im_ws_floats(void);
+int rbvae_col2im_sigmoid(int dtype, const void* Y, int ldy, const float* bias, int N, int IH, int IW, int OH,
+                         int OW, int Cout, int KH, int KW, int pad, float* xr, const float* target,
+                         float* sse_mean, float* ws, float* dpre, float gscale, const float* gscale_dev,
+                         void* stream);
+int rbvae_sigmoid_bwd_nhwc(const float* g_nchw, const float* xr_nchw, float* dpre_nhwc, int N, int C, int H, int W,
+                           void* stream);
+/* Linear with few outputs (percep_RBVAE_model.py:61 forward; :74 backward-data):
+ * out[M][Nc] f32 = A[M][K] * B[Nc][K]^T + bias. */
+int rbvae_skinny_linear(int dtype, const void* A, const void* B, const float* bias, float* out, int M, int Nc,
+                        int K, int lda, int ldb, int ldo, void* stream);
+
+/* ---- stacked LSTM (percep_RBVAE_model.py:94-122) ------------------------------------
+ * wblk: per layer w_ih[4L][L], w_hh[4L][L], b_ih[4L], b_hh[4L] (the reference's registration
+ * order).  hs_all [layers+1][S][T][L]: slot 0 = input (caller fills), slot l+1 = layer l output.
+ * Training also saves hprev/cs [layers][S][T][L] and acts [layers][S][T][4L]. */
+int rbvae_lstm_fwd(const float* wblk, float* hs_all, float* hprev, float* acts, float* cs, int S, int T, int L,
+                   int layers, void* stream);
+int rbvae_lstm_bwd(const float* wblk, const float* acts, const float* cs, const float* g_top, float* dG, float* dx,
+                   int S, int T, int L, int layers, void* stream);
+int rbvae_lstm_wgrad(const float* dG, const float* hs_all, const float* hprev, float* gblk, int S, int T, int L,
+                     int layers, int accumulate, void* stream);
+
+/* torch.optim.Adam defaults (percep_RBVAE_train.py:753,553) on a flat f32 buffer; g is scaled by gscale first. */
+int rbvae_adam_step(float* w, const float* g, float* m, float* v, long n, double lr, double beta1, double beta2,
+                    double eps, int step, float gscale, void* stream);
+
 /* ---- hardware-map probes (diagnostics; tests/test_hw_maps.py) ------------------
  * One-wave kernels that pin the gfx950 lane maps the GEMM kernels assume. */
 int rbvae_dbg_mfma_bf16(const void* A, const void* B, float* D, void* stream);   /* [16x32]x[32x16] bf16 */

@@ -4,6 +4,10 @@ The directory name carries a hyphen (it mirrors the reference repository's name)
 so import it with importlib -- `sfv_amd.py` at the repo root does that:
 
     import sfv_amd as sfv
-    model = sfv.Seq2SeqBinaryVAE(in_channels=4, out_channels=4, latent_dim=32, variant="percep")
+    model = sfv.Seq2SeqBinaryVAE(in_channels=4, out_channels=4, latent_dim=32, variant="percep").cuda()
 """
 from . import _lib  # noqa: F401
+from .engine import VARIANTS, Engine, ParamLayout  # noqa: F401
+from .losses import (contrast_loss, contrast_term, kl_binary_concrete, kl_binary_concrete_simple,  # noqa: F401
+                     l1_loss, recon_loss, triplet_loss, triplet_term)
+from .model import Seq2SeqBinaryVAE, binary_concrete_logits  # noqa: F401

@@ -16,7 +16,7 @@ E_INVALID, E_LAUNCH, E_UNSUPPORTED = -1, -2, -3
 
 _CTYPES = {
     "int": ctypes.c_int, "long": ctypes.c_long, "float": ctypes.c_float, "size_t": ctypes.c_size_t,
-    "unsigned long long": ctypes.c_ulonglong, "unsigned": ctypes.c_uint,
+    "unsigned long long": ctypes.c_ulonglong, "unsigned": ctypes.c_uint, "double": ctypes.c_double,
 }
 
 

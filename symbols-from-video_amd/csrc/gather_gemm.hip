@@ -1,0 +1,360 @@
+// Row-gather GEMM on the gfx950 matrix cores: the conv / conv-transpose / linear
+// forward and input-gradient kernel of the RBVAE path.
+//
+//   Out[orow(m)][n] = epi( sum_{j < ntaps} sum_{k < Kc} A[arow(m, j)][k] * W[n][widx_j][k] )
+//
+// A is an NHWC activation (pixel rows of Kc channels), W is [Nout][taps][Kc] and
+// every tap contributes one gathered pixel row (or a zero row outside the image).
+// With the right tap table this one kernel is
+//   * Conv2d(k, s2, p1) forward                (percep_RBVAE_model.py:51-57)
+//   * ConvTranspose2d(k, s2, p1, op) forward = the conv's input gradient, split
+//     into the 4 output-parity classes (blockIdx.z)   (percep_RBVAE_model.py:76-82)
+//   * their backward-data counterparts, and the Linear layers as a 1-tap case.
+//
+// Tile: 128 output rows x (32*NT) output channels per 256-thread workgroup, K in
+// 128-byte slices (64 bf16 / 32 f32).  Both operand tiles are staged by LDS-DMA
+// (global_load_lds, 16 B per lane, double buffered) into 128-B-row images whose
+// 16-B chunk index is XOR-swizzled with (row>>1)&7 -- applied on the per-lane
+// SOURCE address and again on the ds_read_b128 fragment read -- so fragment
+// reads are bank-conflict free.  bf16 uses v_mfma_f32_16x16x32_bf16, f32 uses
+// v_mfma_f32_16x16x4_f32 (exact f32 fma chain) on the same LDS image.
+// The accumulator is produced transposed (weights as the MFMA row operand) so a
+// lane owns 4 consecutive output channels of one pixel; the tile goes through
+// LDS once more and leaves as whole 16-B chunks of NHWC rows.
+#include "common.h"
+
+namespace rbvae {
+
+typedef __attribute__((ext_vector_type(8))) short bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
+
+struct TapClass {
+    int ntaps;
+    int oh0, ow0;              // output-grid offset of this parity class
+    signed char widx[16];      // tap index into W's tap axis
+    signed char dh[16], dw[16];
+};
+
+struct GgArgs {
+    const unsigned char* A;    // [*, lda] T
+    const unsigned char* W;    // [Nout][taps_total][Kc] T
+    unsigned char* Out;        // [*, ldo] T
+    const float* bias;         // [Nout] or null
+    const unsigned char* gate; // [*, ldo] T or null: zero the output where gate <= 0
+    const unsigned char* mask; // [*, Nout] u8 keep-mask or null
+    const unsigned char* zero; // >= 128 zero bytes
+    int Nimg, IH, IW;          // pixel grid of A
+    int TH, TW;                // per-class row grid: m -> (n, a, b)
+    int sa;                    // A pixel = (a*sa + dh, b*sa + dw)
+    int OH, OW, so;            // Out pixel = (a*so + oh0, b*so + ow0)
+    int Kc, Nout, lda, ldo, taps_total;
+    int relu, drop_mode;       // drop_mode: 0 none, 1 counter hash, 2 explicit mask
+    float scale;               // applied after bias/relu (dropout 1/(1-p) or gate scale)
+    unsigned drop_thresh;      // keep iff hash >= thresh
+    unsigned long long seed;
+    int nclass;
+    TapClass cls[4];
+};
+
+__device__ __forceinline__ void glds16(const void* g, void* lds) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                     (__attribute__((address_space(3))) void*)lds, 16, 0, 0);
+}
+
+template <typename T> struct Mma;
+template <> struct Mma<bf16_t> {
+    // one 128-B LDS row slice = 64 k: two 32-k MFMAs, lane group g reads chunk 4*kk+g
+    static __device__ __forceinline__ void run(f32x4_t& acc, const u32x4_t& rowop, const u32x4_t& colop) {
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8_t*)&rowop, *(const bf16x8_t*)&colop, acc,
+                                                      0, 0, 0);
+    }
+};
+template <> struct Mma<float> {
+    // 32 k per row slice; lane group g holds k = 16*kk + 4*g + c for MFMA c (same on both operands)
+    static __device__ __forceinline__ void run(f32x4_t& acc, const u32x4_t& rowop, const u32x4_t& colop) {
+        const f32x4_t r = *(const f32x4_t*)&rowop, c = *(const f32x4_t*)&colop;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(r[q], c[q], acc, 0, 0, 0);
+    }
+};
+
+template <typename T> __device__ __forceinline__ bool elem_pos(const unsigned char* p, int e);
+template <> __device__ __forceinline__ bool elem_pos<float>(const unsigned char* p, int e) {
+    return ((const float*)p)[e] > 0.f;
+}
+template <> __device__ __forceinline__ bool elem_pos<bf16_t>(const unsigned char* p, int e) {
+    const bf16_t v = ((const bf16_t*)p)[e];
+    return (v & 0x8000u) == 0 && (v & 0x7fffu) != 0 && (v & 0x7fffu) <= 0x7f80u;   // > 0 (NaN excluded)
+}
+
+constexpr int GG_BM = 128;
+
+template <typename T, int NT>
+__global__ __launch_bounds__(256, 2) void gather_gemm_k(const GgArgs p) {
+    constexpr int BN = NT * 32;
+    constexpr int ES = sizeof(T);
+    constexpr int KE = 128 / ES;                 // k elements per staged row slice
+    constexpr int EC = 16 / ES;                  // elements per 16-B chunk
+    constexpr int A_BYTES = GG_BM * 128, B_BYTES = BN * 128;
+    constexpr int PITCH = BN * ES + 16;          // epilogue tile row pitch
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* sA = smem;                    // 2 x A_BYTES
+    unsigned char* sB = smem + 2 * A_BYTES;      // 2 x B_BYTES
+    int* s_orow = (int*)(smem + (2 * A_BYTES + 2 * B_BYTES > GG_BM * PITCH ? 2 * A_BYTES + 2 * B_BYTES
+                                                                            : GG_BM * PITCH));
+
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const TapClass& tc = p.cls[blockIdx.z];
+    const int Mc = p.Nimg * p.TH * p.TW;
+    const int m0 = blockIdx.x * GG_BM, n0 = blockIdx.y * BN;
+
+    // output row of every tile row (for the store phase)
+    if (tid < GG_BM) {
+        const int m = m0 + tid;
+        int o = -1;
+        if (m < Mc) {
+            const int n = m / (p.TH * p.TW), rem = m - n * (p.TH * p.TW);
+            const int a = rem / p.TW, b = rem - a * p.TW;
+            const int oh = a * p.so + tc.oh0, ow = b * p.so + tc.ow0;
+            if (oh < p.OH && ow < p.OW) o = (n * p.OH + oh) * p.OW + ow;
+        }
+        s_orow[tid] = o;
+    }
+
+    // staging roles: one LDS-DMA instruction moves 8 rows x 128 B; wave w issues rows
+    // (w*4+i)*8 .. +7 of A (i<4) and (w*NT+i)*8 .. +7 of B (i<NT)
+    const int srow = lane >> 3, schunk = lane & 7;
+    int an[4], aa[4], ab[4];
+    unsigned a_sw[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = (w * 4 + i) * 8 + srow;
+        const int m = m0 + r;
+        a_sw[i] = (unsigned)((schunk ^ ((r >> 1) & 7)) * 16);
+        if (m < Mc) {
+            const int n = m / (p.TH * p.TW), rem = m - n * (p.TH * p.TW);
+            an[i] = n; aa[i] = rem / p.TW; ab[i] = rem - aa[i] * p.TW;
+        } else {
+            an[i] = -1; aa[i] = 0; ab[i] = 0;
+        }
+    }
+    const unsigned char* bptr[NT];
+    bool bval[NT];
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+        const int r = (w * NT + i) * 8 + srow;
+        const int n = n0 + r;
+        bval[i] = n < p.Nout;
+        bptr[i] = p.W + ((size_t)(bval[i] ? n : 0) * p.taps_total * p.Kc) * ES + (schunk ^ ((r >> 1) & 7)) * 16;
+    }
+    const unsigned char* zsrc = p.zero + schunk * 16;
+
+    const int kchunks = p.Kc / KE;
+    const int nsteps = tc.ntaps * kchunks;
+
+    const unsigned char* aptr[4];
+    auto tap_setup = [&](int j) {
+        const int dh = tc.dh[j], dw = tc.dw[j];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int ih = aa[i] * p.sa + dh, iw = ab[i] * p.sa + dw;
+            const bool v = an[i] >= 0 && ih >= 0 && ih < p.IH && iw >= 0 && iw < p.IW;
+            aptr[i] = v ? p.A + ((size_t)((an[i] * p.IH + ih) * p.IW + iw) * p.lda) * ES + a_sw[i] : nullptr;
+        }
+    };
+    auto stage = [&](int j, int kc, int buf) {
+        unsigned char* la = sA + buf * A_BYTES + (w * 4) * 1024;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            glds16(aptr[i] ? aptr[i] + (size_t)kc * 128 : zsrc, la + i * 1024);
+        unsigned char* lb = sB + buf * B_BYTES + (w * NT) * 1024;
+        const size_t woff = ((size_t)tc.widx[j] * p.Kc) * ES + (size_t)kc * 128;
+#pragma unroll
+        for (int i = 0; i < NT; ++i)
+            glds16(bval[i] ? bptr[i] + woff : zsrc, lb + i * 1024);
+    };
+
+    // fragment read offsets (swizzle depends on the lane only: tile rows are multiples of 16)
+    const int fi = lane & 15, fg = lane >> 4;
+    const int fsw = (fi >> 1) & 7;
+    const int wr = w >> 1, wc = w & 1;
+    int offA[2], offB[2];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+        const int ch = ((4 * kk + fg) ^ fsw) * 16;
+        offA[kk] = (wr * 64 + fi) * 128 + ch;
+        offB[kk] = (wc * NT * 16 + fi) * 128 + ch;
+    }
+
+    f32x4_t acc[4][NT];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    int j = 0, kc = 0;
+    tap_setup(0);
+    stage(0, 0, 0);
+    for (int s = 0; s < nsteps; ++s) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        // advance (j, kc) to step s+1 and prefetch it into the other buffer
+        int kn = kc + 1, jn = j;
+        if (kn == kchunks) { kn = 0; jn = j + 1; }
+        if (s + 1 < nsteps) {
+            if (jn != j) tap_setup(jn);
+            stage(jn, kn, (s + 1) & 1);
+        }
+        j = jn; kc = kn;
+        const unsigned char* la = sA + (s & 1) * A_BYTES;
+        const unsigned char* lb = sB + (s & 1) * B_BYTES;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            u32x4_t fa[4], fb[NT];
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) fa[mt] = *(const u32x4_t*)(la + offA[kk] + mt * 2048);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) fb[nt] = *(const u32x4_t*)(lb + offB[kk] + nt * 2048);
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) Mma<T>::run(acc[mt][nt], fb[nt], fa[mt]);
+        }
+    }
+    __syncthreads();
+
+    // ---- epilogue, register phase: bias, relu, scale; lane owns pixel fi, channels 4*fg..+3
+    unsigned char* tile = smem;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int cb = wc * NT * 16 + nt * 16 + 4 * fg;      // tile-local channel
+        float bz[4] = {0.f, 0.f, 0.f, 0.f};
+        if (p.bias && n0 + cb < p.Nout) {
+            const float4 b4 = *(const float4*)(p.bias + n0 + cb);
+            bz[0] = b4.x; bz[1] = b4.y; bz[2] = b4.z; bz[3] = b4.w;
+        }
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            const int row = wr * 64 + mt * 16 + fi;
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float x = acc[mt][nt][r] + bz[r];
+                if (p.relu) x = fmaxf(x, 0.f);
+                v[r] = x * p.scale;
+            }
+            unsigned char* dst = tile + row * PITCH + cb * ES;
+            if constexpr (ES == 4) {
+                *(float4*)dst = make_float4(v[0], v[1], v[2], v[3]);
+            } else {
+                uint2 pk;
+                pk.x = (unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16);
+                pk.y = (unsigned)f32_to_bf16(v[2]) | ((unsigned)f32_to_bf16(v[3]) << 16);
+                *(uint2*)dst = pk;
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- store phase: whole 16-B chunks of NHWC rows; dropout / gate zeroing happens here
+    constexpr int CPR = BN / EC;
+    for (int idx = tid; idx < GG_BM * CPR; idx += 256) {
+        const int row = idx / CPR, ch = idx - row * CPR;
+        const int orow = s_orow[row];
+        const int col = n0 + ch * EC;
+        if (orow < 0 || col >= p.Nout) continue;
+        u32x4_t val = *(const u32x4_t*)(tile + row * PITCH + ch * 16);
+        T* ev = (T*)&val;
+        if (p.drop_mode == 1) {
+            const unsigned long long base = (unsigned long long)orow * p.Nout + col;
+#pragma unroll
+            for (int e = 0; e < EC; ++e)
+                if (hash_u32(p.seed, base + e) < p.drop_thresh) ev[e] = 0;
+        } else if (p.drop_mode == 2) {
+            const unsigned char* mk = p.mask + (size_t)orow * p.Nout + col;
+#pragma unroll
+            for (int e = 0; e < EC; ++e)
+                if (!mk[e]) ev[e] = 0;
+        }
+        if (p.gate) {
+            const unsigned char* gp = p.gate + ((size_t)orow * p.ldo + col) * ES;
+            const u32x4_t gv = *(const u32x4_t*)gp;
+#pragma unroll
+            for (int e = 0; e < EC; ++e)
+                if (!elem_pos<T>((const unsigned char*)&gv, e)) ev[e] = 0;
+        }
+        *(u32x4_t*)(p.Out + ((size_t)orow * p.ldo + col) * ES) = val;
+    }
+}
+
+template <typename T, int NT>
+static int launch_gg(const GgArgs& a, hipStream_t st) {
+    constexpr int BN = NT * 32;
+    constexpr int ES = sizeof(T);
+    const int Mc = a.Nimg * a.TH * a.TW;
+    const size_t stage_bytes = 2 * GG_BM * 128 + 2 * BN * 128;
+    const size_t tile_bytes = (size_t)GG_BM * (BN * ES + 16);
+    const size_t lds = (stage_bytes > tile_bytes ? stage_bytes : tile_bytes) + GG_BM * sizeof(int);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute((const void*)gather_gemm_k<T, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    dim3 grid(cdiv(Mc, GG_BM), cdiv(a.Nout, BN), a.nclass);
+    hipLaunchKernelGGL((gather_gemm_k<T, NT>), grid, dim3(256), lds, st, a);
+    RBVAE_CHECK_LAUNCH("gather_gemm");
+    return RBVAE_OK;
+}
+
+}  // namespace rbvae
+
+using namespace rbvae;
+
+extern "C" int rbvae_gather_gemm(int dtype, const void* A, const void* W, void* Out, const float* bias,
+                                 const void* gate, const void* mask, const void* zero_page, int Nimg, int IH,
+                                 int IW, int TH, int TW, int sa, int OH, int OW, int so, int Kc, int Nout, int lda,
+                                 int ldo, int taps_total, int nclass, const int* class_desc, int relu,
+                                 int drop_mode, float drop_p, float scale, unsigned long long seed, void* stream) {
+    RBVAE_CHECK_ARG(A && W && Out && zero_page && class_desc, "gather_gemm: null pointer");
+    RBVAE_CHECK_ARG(dtype == RBVAE_F32 || dtype == RBVAE_BF16, "gather_gemm: dtype %d", dtype);
+    const int ES = dtype == RBVAE_F32 ? 4 : 2;
+    const int KE = 128 / ES;
+    RBVAE_CHECK_ARG(Kc > 0 && Kc % KE == 0, "gather_gemm: Kc=%d must be a multiple of %d", Kc, KE);
+    RBVAE_CHECK_ARG(Nout > 0 && Nout % 8 == 0, "gather_gemm: Nout=%d must be a multiple of 8", Nout);
+    RBVAE_CHECK_ARG(lda >= Kc && (lda * ES) % 16 == 0 && ldo >= Nout && (ldo * ES) % 16 == 0,
+                    "gather_gemm: leading dimensions lda=%d ldo=%d", lda, ldo);
+    RBVAE_CHECK_ARG(nclass >= 1 && nclass <= 4, "gather_gemm: nclass=%d", nclass);
+    RBVAE_CHECK_ARG(Nimg > 0 && IH > 0 && IW > 0 && TH > 0 && TW > 0 && OH > 0 && OW > 0, "gather_gemm: bad grid");
+    RBVAE_CHECK_ARG((long)Nimg * TH * TW < (1l << 30) && (long)Nimg * OH * OW < (1l << 30) &&
+                        (long)Nimg * IH * IW < (1l << 30), "gather_gemm: more than 2^30 pixel rows");
+    RBVAE_CHECK_ARG(((uintptr_t)A | (uintptr_t)W | (uintptr_t)Out | (uintptr_t)zero_page | (uintptr_t)gate) % 16 == 0,
+                    "gather_gemm: pointers must be 16-byte aligned");
+    RBVAE_CHECK_ARG(drop_mode >= 0 && drop_mode <= 2 && (drop_mode != 2 || mask), "gather_gemm: drop_mode/mask");
+    GgArgs a;
+    a.A = (const unsigned char*)A; a.W = (const unsigned char*)W; a.Out = (unsigned char*)Out; a.bias = bias;
+    a.gate = (const unsigned char*)gate; a.mask = (const unsigned char*)mask;
+    a.zero = (const unsigned char*)zero_page;
+    a.Nimg = Nimg; a.IH = IH; a.IW = IW; a.TH = TH; a.TW = TW; a.sa = sa; a.OH = OH; a.OW = OW; a.so = so;
+    a.Kc = Kc; a.Nout = Nout; a.lda = lda; a.ldo = ldo; a.taps_total = taps_total;
+    a.relu = relu; a.drop_mode = drop_mode; a.scale = scale; a.seed = seed;
+    a.drop_thresh = (unsigned)((double)drop_p * 4294967296.0);
+    a.nclass = nclass;
+    // class_desc (host ints): per class [ntaps, oh0, ow0, then ntaps x (widx, dh, dw)], classes back to back
+    const int* d = class_desc;
+    for (int c = 0; c < nclass; ++c) {
+        TapClass& t = a.cls[c];
+        t.ntaps = d[0]; t.oh0 = d[1]; t.ow0 = d[2];
+        RBVAE_CHECK_ARG(t.ntaps >= 1 && t.ntaps <= 16, "gather_gemm: class %d has %d taps", c, t.ntaps);
+        d += 3;
+        for (int j = 0; j < t.ntaps; ++j) {
+            RBVAE_CHECK_ARG(d[0] >= 0 && d[0] < taps_total, "gather_gemm: tap index %d outside [0,%d)", d[0], taps_total);
+            t.widx[j] = (signed char)d[0]; t.dh[j] = (signed char)d[1]; t.dw[j] = (signed char)d[2];
+            d += 3;
+        }
+    }
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == RBVAE_F32)
+        return Nout > 64 ? launch_gg<float, 4>(a, st) : launch_gg<float, 2>(a, st);
+    return Nout > 64 ? launch_gg<bf16_t, 4>(a, st) : launch_gg<bf16_t, 2>(a, st);
+}

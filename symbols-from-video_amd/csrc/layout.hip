@@ -1,0 +1,398 @@
+// Layout and small dense helpers around the two GEMM kernels: weight packing,
+// slab reduction back to torch layouts, im2col for the few-channel ends of the
+// network, the col2im + sigmoid + MSE epilogue of the last ConvTranspose2d, column
+// sums (bias gradients), f32 -> T casts, the skinny Linear (N <= 128) and Adam.
+#include "common.h"
+
+namespace rbvae {
+
+typedef __attribute__((ext_vector_type(8))) short bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
+
+// out[i0*s0 + i1*s1 + i2*s2] = in[i0][i1][i2]   (in: contiguous f32)
+template <typename T>
+__global__ void pack3_k(const float* __restrict__ in, T* __restrict__ out, int d0, int d1, int d2, long s0,
+                        long s1, long s2) {
+    const long n = (long)d0 * d1 * d2;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const int i2 = (int)(i % d2);
+        const long r = i / d2;
+        const int i1 = (int)(r % d1), i0 = (int)(r / d1);
+        Elem<T>::store(out + i0 * s0 + i1 * s1 + i2 * s2, in[i]);
+    }
+}
+
+// out[i0][i1][i2] (+)= scale * sum_k in[k*slab + i0*s0 + i1*s1 + i2*s2]   (fixed k order)
+__global__ void permute_reduce_k(const float* __restrict__ in, int nslab, long slab, float* __restrict__ out,
+                                 int d0, int d1, int d2, long s0, long s1, long s2, float scale, int accumulate) {
+    const long n = (long)d0 * d1 * d2;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const int i2 = (int)(i % d2);
+        const long r = i / d2;
+        const int i1 = (int)(r % d1), i0 = (int)(r / d1);
+        const float* p = in + i0 * s0 + i1 * s1 + i2 * s2;
+        float acc = 0.f;
+        for (int k = 0; k < nslab; ++k) acc += p[k * slab];
+        acc *= scale;
+        out[i] = accumulate ? out[i] + acc : acc;
+    }
+}
+
+template <typename T>
+__global__ void cast_pad_k(const float* __restrict__ in, T* __restrict__ out, int rows, int L, int Lpad) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * Lpad) return;
+    const int r = i / Lpad, c = i - r * Lpad;
+    Elem<T>::store(out + i, c < L ? in[(long)r * L + c] : 0.f);
+}
+
+// ---- column sums: X [P][ld] -> partial [nblk][C] -> out[C] -------------------
+constexpr int CS_ROWS = 256;   // rows per block
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_partial_k(const T* __restrict__ X, int P, int C, int ld,
+                                                        float* __restrict__ ws) {
+    // thread -> (column c = tid % cw, row lane = tid / cw); cw = min(C, 256) columns per pass
+    __shared__ float red[256];
+    const int cw = C < 256 ? C : 256;
+    const int rl = 256 / cw;
+    const int tc = threadIdx.x % cw, tr = threadIdx.x / cw;
+    const int r0 = blockIdx.x * CS_ROWS;
+    const int r1 = min(P, r0 + CS_ROWS);
+    for (int c0 = 0; c0 < C; c0 += cw) {
+        const int c = c0 + tc;
+        float acc = 0.f;
+        if (tr < rl && c < C)
+            for (int r = r0 + tr; r < r1; r += rl) acc += Elem<T>::load(X + (long)r * ld + c);
+        red[threadIdx.x] = acc;
+        __syncthreads();
+        if (tr == 0 && c < C) {
+            float t = 0.f;
+            for (int k = 0; k < rl; ++k) t += red[k * cw + tc];
+            ws[(long)blockIdx.x * C + c] = t;
+        }
+        __syncthreads();
+    }
+}
+__global__ void colsum_final_k(const float* __restrict__ ws, int nblk, int C, float* __restrict__ out, float scale,
+                               int accumulate) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float t = 0.f;
+    for (int b = 0; b < nblk; ++b) t += ws[(long)b * C + c];
+    t *= scale;
+    out[c] = accumulate ? out[c] + t : t;
+}
+
+// ---- im2col: strided f32 source -> col[P][Kpad] (column (kh*KW+kw)*C + c) ----
+template <typename T>
+__global__ void im2col_k(const float* __restrict__ src, long sn, long sc, long sh, long sw, int N, int C, int IH,
+                         int IW, int OH, int OW, int KH, int KW, int stride, int pad, int Kpad,
+                         T* __restrict__ col) {
+    const long tot = (long)N * OH * OW * Kpad;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < tot; i += (long)gridDim.x * blockDim.x) {
+        const int kx = (int)(i % Kpad);
+        const long pp = i / Kpad;
+        float v = 0.f;
+        if (kx < KH * KW * C) {
+            const int t = kx / C, c = kx - t * C;
+            const int kh = t / KW, kw = t - kh * KW;
+            const int ow = (int)(pp % OW);
+            const long r = pp / OW;
+            const int oh = (int)(r % OH), n = (int)(r / OH);
+            const int ih = oh * stride - pad + kh, iw = ow * stride - pad + kw;
+            if (ih >= 0 && ih < IH && iw >= 0 && iw < IW) v = src[n * sn + c * sc + ih * sh + iw * sw];
+        }
+        Elem<T>::store(col + i, v);
+    }
+}
+
+// ---- last ConvTranspose2d: col2im gather + bias + sigmoid (+ MSE, + d(loss)/d(pre)) ----
+// Y[(n,a,b)][t*Cout + co] holds each input pixel's contribution to every tap.
+template <typename T>
+__global__ __launch_bounds__(256) void col2im_sigmoid_k(
+    const T* __restrict__ Y, int ldy, const float* __restrict__ bias, int N, int IH, int IW, int OH, int OW,
+    int Cout, int KH, int KW, int pad, float* __restrict__ xr, const float* __restrict__ target,
+    float* __restrict__ sse_ws, float* __restrict__ dpre, float gscale, const float* __restrict__ gs_dev) {
+    __shared__ float red[4];
+    const long tot = (long)N * OH * OW * Cout;
+    float sse = 0.f;
+    float gsc = gscale;
+    if (gs_dev) gsc *= gs_dev[0];
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < tot; i += (long)gridDim.x * blockDim.x) {
+        // i enumerates the NCHW output: (n, co, oh, ow), ow fastest -> coalesced xr/target accesses
+        const int ow = (int)(i % OW);
+        long r = i / OW;
+        const int oh = (int)(r % OH);
+        r /= OH;
+        const int co = (int)(r % Cout), n = (int)(r / Cout);
+        float v = bias ? bias[co] : 0.f;
+        for (int kh = (oh + pad) & 1; kh < KH; kh += 2) {
+            const int a = (oh + pad - kh) >> 1;
+            if (a < 0 || a >= IH) continue;
+            for (int kw = (ow + pad) & 1; kw < KW; kw += 2) {
+                const int b = (ow + pad - kw) >> 1;
+                if (b < 0 || b >= IW) continue;
+                v += Elem<T>::load(Y + ((long)(n * IH + a) * IW + b) * ldy + (kh * KW + kw) * Cout + co);
+            }
+        }
+        const float s = sigmoidf_(v);
+        xr[i] = s;
+        if (target) {
+            const float d = s - target[i];
+            sse += d * d;
+            if (dpre) dpre[((long)(n * OH + oh) * OW + ow) * Cout + co] = gsc * d * s * (1.f - s);
+        }
+    }
+    if (sse_ws) {
+        const float tot_b = block_sum(sse, red);
+        if (threadIdx.x == 0) sse_ws[blockIdx.x] = tot_b;
+    }
+}
+__global__ __launch_bounds__(1024) void sum_partials_k(const float* __restrict__ ws, int n, float scale,
+                                                       float* out, int accumulate) {
+    __shared__ float red[16];
+    float a = 0.f;
+    for (int i = threadIdx.x; i < n; i += 1024) a += ws[i];
+    const float t = block_sum(a, red) * scale;
+    if (threadIdx.x == 0) out[0] = accumulate ? out[0] + t : t;
+}
+// dpre[n][h][w][c] = g[n][c][h][w] * xr * (1 - xr)
+__global__ void sigmoid_bwd_nhwc_k(const float* __restrict__ g, const float* __restrict__ xr,
+                                   float* __restrict__ dpre, int N, int C, int H, int W) {
+    const long tot = (long)N * C * H * W;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < tot; i += (long)gridDim.x * blockDim.x) {
+        const int w = (int)(i % W);
+        long r = i / W;
+        const int h = (int)(r % H);
+        r /= H;
+        const int c = (int)(r % C), n = (int)(r / C);
+        const float s = xr[i];
+        dpre[((long)(n * H + h) * W + w) * C + c] = g[i] * s * (1.f - s);
+    }
+}
+
+// ---- skinny Linear: out[M][Nc] = A[M][K] * B[Nc][K]^T + bias, Nc <= 128 -------------
+// One 16x16 output tile per 512-thread workgroup; the 8 waves split K, operands go
+// straight from global to the MFMA (each is read once), partials meet in LDS.
+template <typename T>
+__global__ __launch_bounds__(512) void skinny_linear_k(const T* __restrict__ A, const T* __restrict__ B,
+                                                       const float* __restrict__ bias, float* __restrict__ out,
+                                                       int M, int Nc, int K, int lda, int ldb, int ldo) {
+    constexpr int ES = sizeof(T);
+    constexpr int KS = (ES == 2) ? 32 : 16;      // k per step (16 B per lane per operand)
+    constexpr int EC = 16 / ES;
+    __shared__ float part[8][256];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int i = lane & 15, g = lane >> 4;
+    const int m = blockIdx.x * 16 + i, n = blockIdx.y * 16 + i;
+    const bool mv = m < M, nv = n < Nc;
+    const T* ap = A + (long)(mv ? m : 0) * lda + g * EC;
+    const T* bp = B + (long)(nv ? n : 0) * ldb + g * EC;
+    f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+    const u32x4_t z = {0u, 0u, 0u, 0u};
+    for (int k = w * KS; k < K; k += 8 * KS) {
+        const u32x4_t a = mv ? *(const u32x4_t*)(ap + k) : z;
+        const u32x4_t b = nv ? *(const u32x4_t*)(bp + k) : z;
+        if constexpr (ES == 2) {
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8_t*)&a, *(const bf16x8_t*)&b, acc, 0, 0, 0);
+        } else {
+            const f32x4_t af = *(const f32x4_t*)&a, bf = *(const f32x4_t*)&b;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[q], bf[q], acc, 0, 0, 0);
+        }
+    }
+    // D[row = m-local 4g+r][col = n-local i]
+#pragma unroll
+    for (int r = 0; r < 4; ++r) part[w][(4 * g + r) * 16 + i] = acc[r];
+    __syncthreads();
+    if (threadIdx.x < 256) {
+        const int rm = threadIdx.x >> 4, cn = threadIdx.x & 15;
+        const int mm = blockIdx.x * 16 + rm, nn = blockIdx.y * 16 + cn;
+        if (mm < M && nn < Nc) {
+            float t = 0.f;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) t += part[k][threadIdx.x];
+            out[(long)mm * ldo + nn] = t + (bias ? bias[nn] : 0.f);
+        }
+    }
+}
+
+// ---- Adam (torch.optim.Adam defaults: no weight decay, no amsgrad) ------------------
+// Same operation order as torch's single-tensor path: m.lerp_(g, 1-b1); v = v*b2 + ((1-b2)*g)*g;
+// denom = sqrt(v)/sqrt(bc2) + eps; w += -(lr/bc1) * (m/denom).
+__global__ void adam_k(float* __restrict__ w, const float* __restrict__ g, float* __restrict__ m,
+                       float* __restrict__ v, long n, float step_size, float one_m_b1, float b2, float one_m_b2,
+                       float eps, float bc2_sqrt, float gscale) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const float gi = g[i] * gscale;
+        const float m0 = m[i];
+        const float mi = m0 + one_m_b1 * (gi - m0);
+        const float vi = v[i] * b2 + (one_m_b2 * gi) * gi;
+        m[i] = mi;
+        v[i] = vi;
+        const float denom = sqrtf(vi) / bc2_sqrt + eps;
+        w[i] = w[i] - step_size * (mi / denom);
+    }
+}
+
+static inline int grid_for(long n, int block = 256, int cap = 4096) {
+    long b = (n + block - 1) / block;
+    return (int)(b < 1 ? 1 : (b > cap ? cap : b));
+}
+
+}  // namespace rbvae
+
+using namespace rbvae;
+
+extern "C" {
+
+int rbvae_pack3(int dtype, const float* in, void* out, int d0, int d1, int d2, long s0, long s1, long s2,
+                void* stream) {
+    RBVAE_CHECK_ARG(in && out && d0 > 0 && d1 > 0 && d2 > 0, "pack3: bad arguments");
+    const long n = (long)d0 * d1 * d2;
+    if (dtype == RBVAE_F32)
+        hipLaunchKernelGGL(pack3_k<float>, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, in, (float*)out, d0,
+                           d1, d2, s0, s1, s2);
+    else if (dtype == RBVAE_BF16)
+        hipLaunchKernelGGL(pack3_k<bf16_t>, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, in, (bf16_t*)out,
+                           d0, d1, d2, s0, s1, s2);
+    else
+        return fail(RBVAE_E_INVALID, "pack3: dtype %d", dtype);
+    RBVAE_CHECK_LAUNCH("pack3");
+    return RBVAE_OK;
+}
+
+int rbvae_permute_reduce(const float* in, int nslab, long slab_stride, float* out, int d0, int d1, int d2, long s0,
+                         long s1, long s2, float scale, int accumulate, void* stream) {
+    RBVAE_CHECK_ARG(in && out && nslab > 0 && d0 > 0 && d1 > 0 && d2 > 0, "permute_reduce: bad arguments");
+    const long n = (long)d0 * d1 * d2;
+    hipLaunchKernelGGL(permute_reduce_k, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, in, nslab,
+                       slab_stride, out, d0, d1, d2, s0, s1, s2, scale, accumulate);
+    RBVAE_CHECK_LAUNCH("permute_reduce");
+    return RBVAE_OK;
+}
+
+int rbvae_cast_pad(int dtype, const float* in, void* out, int rows, int L, int Lpad, void* stream) {
+    RBVAE_CHECK_ARG(in && out && rows > 0 && L > 0 && Lpad >= L, "cast_pad: bad arguments");
+    const int n = rows * Lpad;
+    if (dtype == RBVAE_F32)
+        hipLaunchKernelGGL(cast_pad_k<float>, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, in, (float*)out,
+                           rows, L, Lpad);
+    else if (dtype == RBVAE_BF16)
+        hipLaunchKernelGGL(cast_pad_k<bf16_t>, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, in,
+                           (bf16_t*)out, rows, L, Lpad);
+    else
+        return fail(RBVAE_E_INVALID, "cast_pad: dtype %d", dtype);
+    RBVAE_CHECK_LAUNCH("cast_pad");
+    return RBVAE_OK;
+}
+
+size_t rbvae_colsum_ws_floats(int P, int C) { return (size_t)cdiv(P, CS_ROWS) * C; }
+
+int rbvae_colsum(int dtype, const void* X, int P, int C, int ld, float* out, float* ws, float scale, int accumulate,
+                 void* stream) {
+    RBVAE_CHECK_ARG(X && out && ws && P > 0 && C > 0 && ld >= C, "colsum: bad arguments");
+    const int nblk = cdiv(P, CS_ROWS);
+    if (dtype == RBVAE_F32)
+        hipLaunchKernelGGL(colsum_partial_k<float>, dim3(nblk), dim3(256), 0, (hipStream_t)stream, (const float*)X,
+                           P, C, ld, ws);
+    else if (dtype == RBVAE_BF16)
+        hipLaunchKernelGGL(colsum_partial_k<bf16_t>, dim3(nblk), dim3(256), 0, (hipStream_t)stream,
+                           (const bf16_t*)X, P, C, ld, ws);
+    else
+        return fail(RBVAE_E_INVALID, "colsum: dtype %d", dtype);
+    hipLaunchKernelGGL(colsum_final_k, dim3(cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, ws, nblk, C, out, scale,
+                       accumulate);
+    RBVAE_CHECK_LAUNCH("colsum");
+    return RBVAE_OK;
+}
+
+int rbvae_im2col(int dtype, const float* src, long sn, long sc, long sh, long sw, int N, int C, int IH, int IW,
+                 int OH, int OW, int KH, int KW, int stride, int pad, int Kpad, void* col, void* stream) {
+    RBVAE_CHECK_ARG(src && col && N > 0 && C > 0 && Kpad >= KH * KW * C, "im2col: bad arguments");
+    const long tot = (long)N * OH * OW * Kpad;
+    if (dtype == RBVAE_F32)
+        hipLaunchKernelGGL(im2col_k<float>, dim3(grid_for(tot, 256, 8192)), dim3(256), 0, (hipStream_t)stream, src,
+                           sn, sc, sh, sw, N, C, IH, IW, OH, OW, KH, KW, stride, pad, Kpad, (float*)col);
+    else if (dtype == RBVAE_BF16)
+        hipLaunchKernelGGL(im2col_k<bf16_t>, dim3(grid_for(tot, 256, 8192)), dim3(256), 0, (hipStream_t)stream, src,
+                           sn, sc, sh, sw, N, C, IH, IW, OH, OW, KH, KW, stride, pad, Kpad, (bf16_t*)col);
+    else
+        return fail(RBVAE_E_INVALID, "im2col: dtype %d", dtype);
+    RBVAE_CHECK_LAUNCH("im2col");
+    return RBVAE_OK;
+}
+
+size_t rbvae_col2im_ws_floats(void) { return 1024; }
+
+int rbvae_col2im_sigmoid(int dtype, const void* Y, int ldy, const float* bias, int N, int IH, int IW, int OH,
+                         int OW, int Cout, int KH, int KW, int pad, float* xr, const float* target,
+                         float* sse_mean, float* ws, float* dpre, float gscale, const float* gscale_dev,
+                         void* stream) {
+    RBVAE_CHECK_ARG(Y && xr && N > 0 && Cout > 0 && ldy >= KH * KW * Cout, "col2im_sigmoid: bad arguments");
+    RBVAE_CHECK_ARG(!sse_mean || (target && ws), "col2im_sigmoid: sse_mean needs target and ws");
+    RBVAE_CHECK_ARG(!dpre || target, "col2im_sigmoid: dpre needs target");
+    const long tot = (long)N * OH * OW * Cout;
+    const int nb = grid_for(tot, 256, 1024);
+    float* sws = sse_mean ? ws : nullptr;
+    if (dtype == RBVAE_F32)
+        hipLaunchKernelGGL(col2im_sigmoid_k<float>, dim3(nb), dim3(256), 0, (hipStream_t)stream, (const float*)Y, ldy,
+                           bias, N, IH, IW, OH, OW, Cout, KH, KW, pad, xr, target, sws, dpre, gscale, gscale_dev);
+    else if (dtype == RBVAE_BF16)
+        hipLaunchKernelGGL(col2im_sigmoid_k<bf16_t>, dim3(nb), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)Y,
+                           ldy, bias, N, IH, IW, OH, OW, Cout, KH, KW, pad, xr, target, sws, dpre, gscale,
+                           gscale_dev);
+    else
+        return fail(RBVAE_E_INVALID, "col2im_sigmoid: dtype %d", dtype);
+    if (sse_mean)
+        hipLaunchKernelGGL(sum_partials_k, dim3(1), dim3(1024), 0, (hipStream_t)stream, ws, nb, 1.0f / (float)tot,
+                           sse_mean, 0);
+    RBVAE_CHECK_LAUNCH("col2im_sigmoid");
+    return RBVAE_OK;
+}
+
+int rbvae_sigmoid_bwd_nhwc(const float* g_nchw, const float* xr_nchw, float* dpre_nhwc, int N, int C, int H, int W,
+                           void* stream) {
+    RBVAE_CHECK_ARG(g_nchw && xr_nchw && dpre_nhwc && N > 0 && C > 0 && H > 0 && W > 0, "sigmoid_bwd_nhwc: bad arguments");
+    const long tot = (long)N * C * H * W;
+    hipLaunchKernelGGL(sigmoid_bwd_nhwc_k, dim3(grid_for(tot)), dim3(256), 0, (hipStream_t)stream, g_nchw, xr_nchw,
+                       dpre_nhwc, N, C, H, W);
+    RBVAE_CHECK_LAUNCH("sigmoid_bwd_nhwc");
+    return RBVAE_OK;
+}
+
+int rbvae_skinny_linear(int dtype, const void* A, const void* B, const float* bias, float* out, int M, int Nc,
+                        int K, int lda, int ldb, int ldo, void* stream) {
+    RBVAE_CHECK_ARG(A && B && out && M > 0 && Nc > 0 && K > 0, "skinny_linear: bad arguments");
+    RBVAE_CHECK_ARG(dtype == RBVAE_F32 || dtype == RBVAE_BF16, "skinny_linear: dtype %d", dtype);
+    const int ES = dtype == RBVAE_F32 ? 4 : 2;
+    const int KS = dtype == RBVAE_F32 ? 16 : 32;
+    RBVAE_CHECK_ARG(K % KS == 0, "skinny_linear: K=%d must be a multiple of %d", K, KS);
+    RBVAE_CHECK_ARG((lda * ES) % 16 == 0 && (ldb * ES) % 16 == 0 && lda >= K && ldb >= K && ldo >= Nc,
+                    "skinny_linear: leading dimensions");
+    RBVAE_CHECK_ARG(((uintptr_t)A | (uintptr_t)B) % 16 == 0, "skinny_linear: operands must be 16-byte aligned");
+    dim3 grid(cdiv(M, 16), cdiv(Nc, 16));
+    if (dtype == RBVAE_F32)
+        hipLaunchKernelGGL(skinny_linear_k<float>, grid, dim3(512), 0, (hipStream_t)stream, (const float*)A,
+                           (const float*)B, bias, out, M, Nc, K, lda, ldb, ldo);
+    else
+        hipLaunchKernelGGL(skinny_linear_k<bf16_t>, grid, dim3(512), 0, (hipStream_t)stream, (const bf16_t*)A,
+                           (const bf16_t*)B, bias, out, M, Nc, K, lda, ldb, ldo);
+    RBVAE_CHECK_LAUNCH("skinny_linear");
+    return RBVAE_OK;
+}
+
+int rbvae_adam_step(float* w, const float* g, float* m, float* v, long n, double lr, double beta1, double beta2,
+                    double eps, int step, float gscale, void* stream) {
+    RBVAE_CHECK_ARG(w && g && m && v && n > 0 && step >= 1, "adam_step: bad arguments");
+    const double bc1 = 1.0 - pow(beta1, (double)step);
+    const double bc2 = 1.0 - pow(beta2, (double)step);
+    hipLaunchKernelGGL(adam_k, dim3(grid_for(n, 256, 2048)), dim3(256), 0, (hipStream_t)stream, w, g, m, v, n,
+                       (float)(lr / bc1), (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps,
+                       (float)sqrt(bc2), gscale);
+    RBVAE_CHECK_LAUNCH("adam_step");
+    return RBVAE_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,281 @@
+// Weight-gradient GEMM on the gfx950 matrix cores:
+//
+//   dW[ks][co][t][ci] = sum_{p in K-slice ks} Dy[p][co] * In[idx[t][p]][ci]
+//
+// for Conv2d / ConvTranspose2d / Linear weight gradients of the RBVAE path (autograd of
+// percep_RBVAE_model.py:51-57,61,74,76-82 as run by percep_RBVAE_train.py:552).
+// Both operands are pixel-major ("k-major") NHWC rows, so the reduction index is
+// the LDS image's ROW: fragments are read with the transposing LDS read
+// (ds_read_b64_tr_b16) for bf16 and with plain dword reads for f32.
+//
+// Tile: (32*MT) x (32*NT) (co x ci) per 256-thread workgroup, 32 pixels per K step,
+// double-buffered LDS-DMA staging.  grid = (co tiles, ci tiles, taps * ksplit); each
+// K-slice writes its own f32 slab (summed later in a fixed order by
+// rbvae_permute_reduce, so gradients are bitwise reproducible -- no float atomics).
+#include "common.h"
+
+namespace rbvae {
+
+typedef __attribute__((ext_vector_type(8))) short bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+
+struct WgArgs {
+    const unsigned char* Dy;   // [P][ldy] T
+    const unsigned char* In;   // [*][ldi] T
+    float* dW;                 // [ksplit][Co][taps][Ci] f32
+    const int* idx;            // [taps][P] row of In per (tap, pixel), -1 = zero row; null = identity
+    const unsigned char* zero; // >= 16 zero bytes
+    int P, Co, Ci, ldy, ldi, taps, ksplit, Pper;
+};
+
+__device__ __forceinline__ void glds16w(const void* g, void* lds) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                     (__attribute__((address_space(3))) void*)lds, 16, 0, 0);
+}
+
+// XOR applied to the 16-B chunk index of an LDS image row so that the transposed
+// reads of a 32-lane half (rows {q, 8+q} or {4+q, 12+q}) hit distinct banks.
+template <int RB> __device__ __forceinline__ int tr_swz(int row) {
+    if constexpr (RB >= 256) return ((row & 3) | (((row >> 3) & 1) << 2)) << 1;   // 8 chunk pairs
+    else return (((row >> 1) & 1) | (((row >> 3) & 1) << 1)) << 1;                // 128-B rows: 4 pairs
+}
+
+constexpr int WG_BK = 32;   // pixels per K step
+
+template <typename T, int MT, int NT>   // wave tile = (16*MT) x (16*NT); block = 2x2 waves
+__global__ __launch_bounds__(256, 2) void wgrad_gemm_k(const WgArgs p) {
+    constexpr int ES = sizeof(T);
+    constexpr int BM = 32 * MT, BN = 32 * NT;
+    constexpr int RBA = BM * ES, RBB = BN * ES;           // image row bytes
+    constexpr int A_BYTES = WG_BK * RBA, B_BYTES = WG_BK * RBB;
+    constexpr int A_INSTR = A_BYTES / 1024 / 4, B_INSTR = B_BYTES / 1024 / 4;   // LDS-DMA per wave per step
+    static_assert(A_INSTR >= 1 && B_INSTR >= 1, "tile too small for 4 staging waves");
+    constexpr bool SWZ = (ES == 2);
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * A_BYTES + 2 * B_BYTES];
+    unsigned char* sA = smem;
+    unsigned char* sB = smem + 2 * A_BYTES;
+
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int co0 = blockIdx.x * BM, ci0 = blockIdx.y * BN;
+    const int tap = blockIdx.z / p.ksplit, ks = blockIdx.z - tap * p.ksplit;
+    const int pbeg = ks * p.Pper;
+    const int pend = min(p.P, pbeg + p.Pper);
+    const int nsteps = (pend - pbeg + WG_BK - 1) / WG_BK;
+    const int* idx = p.idx ? p.idx + (size_t)tap * p.P : nullptr;
+
+    // staging roles.  One instruction = 1 KiB = (1024/RB) image rows; wave w issues
+    // instructions w*INSTR .. of each image.
+    constexpr int A_LPR = RBA / 16, B_LPR = RBB / 16;     // lanes (chunks) per row
+    constexpr int A_RPI = 64 / A_LPR, B_RPI = 64 / B_LPR; // rows per instruction
+    int a_row[A_INSTR], a_coff[A_INSTR];
+    bool a_cval[A_INSTR];
+#pragma unroll
+    for (int i = 0; i < A_INSTR; ++i) {
+        const int r = (w * A_INSTR + i) * A_RPI + lane / A_LPR;
+        const int c = (lane % A_LPR) ^ (SWZ ? tr_swz<RBA>(r) : 0);
+        a_row[i] = r;
+        a_coff[i] = c * 16;
+        a_cval[i] = co0 + c * (16 / ES) < p.Co;
+    }
+    int b_row[B_INSTR], b_coff[B_INSTR];
+    bool b_cval[B_INSTR];
+#pragma unroll
+    for (int i = 0; i < B_INSTR; ++i) {
+        const int r = (w * B_INSTR + i) * B_RPI + lane / B_LPR;
+        const int c = (lane % B_LPR) ^ (SWZ ? tr_swz<RBB>(r) : 0);
+        b_row[i] = r;
+        b_coff[i] = c * 16;
+        b_cval[i] = ci0 + c * (16 / ES) < p.Ci;
+    }
+
+    int b_src[B_INSTR];          // gathered In row of the NEXT step to stage
+    auto load_idx = [&](int step) {
+#pragma unroll
+        for (int i = 0; i < B_INSTR; ++i) {
+            const int pp = pbeg + step * WG_BK + b_row[i];
+            b_src[i] = (pp < pend) ? (idx ? idx[pp] : pp) : -1;
+        }
+    };
+    auto stage = [&](int step, int buf) {
+        unsigned char* la = sA + buf * A_BYTES + (w * A_INSTR) * 1024;
+#pragma unroll
+        for (int i = 0; i < A_INSTR; ++i) {
+            const int pp = pbeg + step * WG_BK + a_row[i];
+            const bool v = a_cval[i] && pp < pend;
+            glds16w(v ? p.Dy + ((size_t)pp * p.ldy + co0) * ES + a_coff[i] : p.zero, la + i * 1024);
+        }
+        unsigned char* lb = sB + buf * B_BYTES + (w * B_INSTR) * 1024;
+#pragma unroll
+        for (int i = 0; i < B_INSTR; ++i) {
+            const bool v = b_cval[i] && b_src[i] >= 0;
+            glds16w(v ? p.In + ((size_t)b_src[i] * p.ldi + ci0) * ES + b_coff[i] : p.zero, lb + i * 1024);
+        }
+    };
+
+    const int wr = w >> 1, wc = w & 1;
+    const int fi = lane & 15, fg = lane >> 4;
+    f32x4_t acc[MT][NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    // fragment read offsets
+    int offA[MT], offB[NT];
+    if constexpr (ES == 2) {
+        // transposed read: lane (g, q, pp) addresses row 8g+4h+q, elements cb+4pp..+3 of a 16-channel block
+        const int q = fi >> 2, pp = fi & 3;
+        const int row = 8 * fg + q;                       // + 4h
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int chunk = ((wr * MT + mt) * 2 + (pp >> 1)) ^ tr_swz<RBA>(row);
+            offA[mt] = row * RBA + chunk * 16 + (pp & 1) * 8;
+        }
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int chunk = ((wc * NT + nt) * 2 + (pp >> 1)) ^ tr_swz<RBB>(row);
+            offB[nt] = row * RBB + chunk * 16 + (pp & 1) * 8;
+        }
+    } else {
+        // f32: lane (i, g) reads element (row 4s+g, channel cb+i)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) offA[mt] = fg * RBA + ((wr * MT + mt) * 16 + fi) * 4;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) offB[nt] = fg * RBB + ((wc * NT + nt) * 16 + fi) * 4;
+    }
+
+    if (nsteps > 0) {
+        load_idx(0);
+        stage(0, 0);
+        if (nsteps > 1) load_idx(1);
+    }
+    for (int s = 0; s < nsteps; ++s) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (s + 1 < nsteps) {
+            stage(s + 1, (s + 1) & 1);
+            if (s + 2 < nsteps) load_idx(s + 2);
+        }
+        const unsigned char* la = sA + (s & 1) * A_BYTES;
+        const unsigned char* lb = sB + (s & 1) * B_BYTES;
+        if constexpr (ES == 2) {
+            bf16x8_t fa[MT], fb[NT];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                    (__attribute__((address_space(3))) s16x4_t*)(la + offA[mt]));
+                const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                    (__attribute__((address_space(3))) s16x4_t*)(la + offA[mt] + 4 * RBA));
+                fa[mt] = bf16x8_t{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            }
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                    (__attribute__((address_space(3))) s16x4_t*)(lb + offB[nt]));
+                const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                    (__attribute__((address_space(3))) s16x4_t*)(lb + offB[nt] + 4 * RBB));
+                fb[nt] = bf16x8_t{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            }
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[nt], fa[mt], acc[mt][nt], 0, 0, 0);
+        } else {
+#pragma unroll
+            for (int sub = 0; sub < WG_BK / 4; ++sub) {
+                float fa[MT], fb[NT];
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) fa[mt] = *(const float*)(la + offA[mt] + sub * 4 * RBA);
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) fb[nt] = *(const float*)(lb + offB[nt] + sub * 4 * RBB);
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(fb[nt], fa[mt], acc[mt][nt], 0, 0, 0);
+            }
+        }
+    }
+
+    // D[row = ci 4g+r][col = co i]: lane owns 4 consecutive ci of one co -> one 16-B store
+    float* slab = p.dW + (size_t)ks * p.Co * p.taps * p.Ci;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const int co = co0 + (wr * MT + mt) * 16 + fi;
+        if (co >= p.Co) continue;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int ci = ci0 + (wc * NT + nt) * 16 + 4 * fg;
+            if (ci >= p.Ci) continue;
+            *(f32x4_t*)(slab + ((size_t)co * p.taps + tap) * p.Ci + ci) = acc[mt][nt];
+        }
+    }
+}
+
+// idx[t][p] for a strided convolution: the In pixel row tap t reads at output pixel p.
+__global__ void conv_gather_index_k(int* __restrict__ idx, int Nimg, int IH, int IW, int OH, int OW, int KH,
+                                    int KW, int stride, int pad) {
+    const int P = Nimg * OH * OW;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P * KH * KW) return;
+    const int t = i / P, pp = i - t * P;
+    const int kh = t / KW, kw = t - kh * KW;
+    const int n = pp / (OH * OW), rem = pp - n * (OH * OW);
+    const int oh = rem / OW, ow = rem - oh * OW;
+    const int ih = oh * stride - pad + kh, iw = ow * stride - pad + kw;
+    idx[i] = (ih >= 0 && ih < IH && iw >= 0 && iw < IW) ? (n * IH + ih) * IW + iw : -1;
+}
+
+template <typename T, int MT, int NT>
+static int launch_wg(const WgArgs& a, hipStream_t st) {
+    dim3 grid(cdiv(a.Co, 32 * MT), cdiv(a.Ci, 32 * NT), a.taps * a.ksplit);
+    hipLaunchKernelGGL((wgrad_gemm_k<T, MT, NT>), grid, dim3(256), 0, st, a);
+    RBVAE_CHECK_LAUNCH("wgrad_gemm");
+    return RBVAE_OK;
+}
+
+}  // namespace rbvae
+
+using namespace rbvae;
+
+extern "C" {
+
+int rbvae_conv_gather_index(int* idx, int Nimg, int IH, int IW, int OH, int OW, int KH, int KW, int stride,
+                            int pad, void* stream) {
+    RBVAE_CHECK_ARG(idx && Nimg > 0 && IH > 0 && IW > 0 && OH > 0 && OW > 0 && KH > 0 && KW > 0 && stride > 0,
+                    "conv_gather_index: bad arguments");
+    const long tot = (long)Nimg * OH * OW * KH * KW;
+    RBVAE_CHECK_ARG(tot < (1l << 31) && (long)Nimg * IH * IW < (1l << 31), "conv_gather_index: too many rows");
+    hipLaunchKernelGGL(conv_gather_index_k, dim3(cdiv(tot, 256)), dim3(256), 0, (hipStream_t)stream, idx, Nimg, IH,
+                       IW, OH, OW, KH, KW, stride, pad);
+    RBVAE_CHECK_LAUNCH("conv_gather_index");
+    return RBVAE_OK;
+}
+
+int rbvae_wgrad_gemm(int dtype, const void* Dy, const void* In, float* dW_slabs, const int* idx,
+                     const void* zero_page, int P, int Co, int Ci, int ldy, int ldi, int taps, int ksplit,
+                     void* stream) {
+    RBVAE_CHECK_ARG(Dy && In && dW_slabs && zero_page, "wgrad_gemm: null pointer");
+    RBVAE_CHECK_ARG(dtype == RBVAE_F32 || dtype == RBVAE_BF16, "wgrad_gemm: dtype %d", dtype);
+    const int ES = dtype == RBVAE_F32 ? 4 : 2;
+    RBVAE_CHECK_ARG(P > 0 && Co > 0 && Ci > 0 && taps > 0 && ksplit > 0, "wgrad_gemm: bad sizes");
+    RBVAE_CHECK_ARG(Co % 8 == 0 && Ci % 8 == 0, "wgrad_gemm: Co=%d Ci=%d must be multiples of 8", Co, Ci);
+    RBVAE_CHECK_ARG((ldy * ES) % 16 == 0 && (ldi * ES) % 16 == 0 && ldy >= Co && ldi >= Ci,
+                    "wgrad_gemm: leading dimensions ldy=%d ldi=%d", ldy, ldi);
+    RBVAE_CHECK_ARG(((uintptr_t)Dy | (uintptr_t)In | (uintptr_t)dW_slabs | (uintptr_t)zero_page) % 16 == 0,
+                    "wgrad_gemm: pointers must be 16-byte aligned");
+    RBVAE_CHECK_ARG(taps * ksplit <= 65535, "wgrad_gemm: taps*ksplit=%d exceeds the grid limit", taps * ksplit);
+    WgArgs a;
+    a.Dy = (const unsigned char*)Dy; a.In = (const unsigned char*)In; a.dW = dW_slabs; a.idx = idx;
+    a.zero = (const unsigned char*)zero_page;
+    a.P = P; a.Co = Co; a.Ci = Ci; a.ldy = ldy; a.ldi = ldi; a.taps = taps; a.ksplit = ksplit;
+    a.Pper = ((cdiv(P, ksplit) + WG_BK - 1) / WG_BK) * WG_BK;
+    hipStream_t st = (hipStream_t)stream;
+    const bool big = Co > 64 && Ci > 64;
+    if (dtype == RBVAE_F32) return big ? launch_wg<float, 4, 4>(a, st) : launch_wg<float, 2, 2>(a, st);
+    return big ? launch_wg<bf16_t, 4, 4>(a, st) : launch_wg<bf16_t, 2, 2>(a, st);
+}
+
+}  // extern "C"

@@ -1,0 +1,515 @@
+"""Hand-scheduled forward/backward of the RBVAE path over librbvae_hip.
+
+The engine owns no parameters: it is given the model's flat f32 parameter buffer
+(the reference's registration order, see `ParamLayout`) and writes gradients into a
+flat buffer of the same layout.  Activations are NHWC in the engine's storage dtype
+("f32" parity mode / "bf16" performance mode); LSTM, binarise and the losses are f32.
+
+Reference path restated by the kernels this file sequences:
+  Seq2SeqBinaryVAE.forward / encode   models/percep_RBVAE/percep_RBVAE_model.py:143-191
+  (contrastive / triplet / simple variants: the matching *_model.py files)
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib as L
+
+F32, BF16 = 0, 1
+
+
+@dataclass(frozen=True)
+class Variant:
+    name: str
+    channels: Tuple[int, int, int]
+    kernel: int
+    lstm_layers: int
+    dropout: float
+    noise_ratio_arg: bool
+    eps: float
+    simple_order: bool          # conv -> binarise -> rnn -> rnn -> deconv, ReLU after conv3
+    default_hw: Tuple[int, int]
+
+
+VARIANTS = {
+    # models/percep_RBVAE/percep_RBVAE_model.py:46-141
+    "percep": Variant("percep", (256, 256, 256), 3, 4, 0.2, True, 1e-8, False, (88, 160)),
+    # models/contrastive_RBVAE/contrastive_RBVAE_model.py:45-140
+    "contrastive": Variant("contrastive", (64, 64, 64), 3, 2, 0.2, True, 1e-8, False, (256, 256)),
+    # models/triplet_RBVAE/triplet_RBVAE_model.py:18-45,144-171 (noise is never scaled)
+    "triplet": Variant("triplet", (64, 64, 64), 3, 2, 0.2, False, 1e-8, False, (256, 256)),
+    # models/simple_RBVAE/simple_RBVAE_model.py:77-193
+    "simple": Variant("simple", (64, 128, 256), 4, 1, 0.0, False, 1e-10, True, (64, 64)),
+}
+
+
+def conv_out(n: int, k: int) -> int:
+    return (n + 2 - k) // 2 + 1
+
+
+def _ru(x: int, m: int) -> int:
+    return (x + m - 1) // m * m
+
+
+class ParamLayout:
+    """Names, shapes and flat offsets of the parameters in the reference's
+    registration order (state_dict order of Seq2SeqBinaryVAE)."""
+
+    def __init__(self, v: Variant, in_ch: int, out_ch: int, latent: int, hw: Tuple[int, int]):
+        c1, c2, c3 = v.channels
+        k = v.kernel
+        h, w = hw
+        for _ in range(3):
+            h, w = conv_out(h, k), conv_out(w, k)
+        self.bott = (h, w)
+        flat = c3 * h * w
+        idx = (0, 2, 4) if v.name == "simple" else (0, 3, 6)
+        shapes: List[Tuple[str, Tuple[int, ...]]] = []
+        for i, (ci, co) in zip(idx, [(in_ch, c1), (c1, c2), (c2, c3)]):
+            shapes += [(f"encoder_cnn.conv.{i}.weight", (co, ci, k, k)), (f"encoder_cnn.conv.{i}.bias", (co,))]
+        shapes += [("encoder_cnn.fc.weight", (latent, flat)), ("encoder_cnn.fc.bias", (latent,)),
+                   ("decoder_cnn.fc.weight", (flat, latent)), ("decoder_cnn.fc.bias", (flat,))]
+        for i, (ci, co) in zip(idx, [(c3, c2), (c2, c1), (c1, out_ch)]):
+            shapes += [(f"decoder_cnn.deconv.{i}.weight", (ci, co, k, k)), (f"decoder_cnn.deconv.{i}.bias", (co,))]
+        for stack in ("encoder_rnn", "decoder_rnn"):
+            for l in range(v.lstm_layers):
+                shapes += [(f"{stack}.lstm.weight_ih_l{l}", (4 * latent, latent)),
+                           (f"{stack}.lstm.weight_hh_l{l}", (4 * latent, latent)),
+                           (f"{stack}.lstm.bias_ih_l{l}", (4 * latent,)),
+                           (f"{stack}.lstm.bias_hh_l{l}", (4 * latent,))]
+        self.names = [n for n, _ in shapes]
+        self.shapes = dict(shapes)
+        self.offsets: Dict[str, int] = {}
+        off = 0
+        for n, s in shapes:
+            # keep every tensor 16-byte aligned inside the flat buffer
+            off = _ru(off, 4)
+            self.offsets[n] = off
+            off += math.prod(s)
+        self.total = _ru(off, 4)
+        self.conv_idx = idx
+        # the LSTM blocks must be gap-free (the kernel walks w_ih, w_hh, b_ih, b_hh per layer)
+        for stack in ("encoder_rnn", "decoder_rnn"):
+            base = self.offsets[f"{stack}.lstm.weight_ih_l0"]
+            per = 8 * latent * latent + 8 * latent
+            for l in range(v.lstm_layers):
+                assert self.offsets[f"{stack}.lstm.weight_ih_l{l}"] == base + l * per, "lstm block not contiguous"
+
+    def view(self, flat: torch.Tensor, name: str) -> torch.Tensor:
+        o = self.offsets[name]
+        s = self.shapes[name]
+        return flat[o:o + math.prod(s)].view(s)
+
+
+def conv_classes(k: int) -> List[int]:
+    """gather_gemm descriptor of Conv2d(k, stride 2, pad 1): one class, k*k taps."""
+    d = [k * k, 0, 0]
+    for kh in range(k):
+        for kw in range(k):
+            d += [kh * k + kw, kh - 1, kw - 1]
+    return d
+
+
+def dgrad_classes(k: int) -> Tuple[List[int], int]:
+    """Descriptor of the conv's input gradient (= ConvTranspose2d(k,2,1) forward): four
+    output-parity classes, heaviest first so the long workgroups start early."""
+    per = []
+    for ch in (0, 1):
+        for cw in (0, 1):
+            taps = []
+            for kh in range(k):
+                if (ch + 1 - kh) % 2:
+                    continue
+                for kw in range(k):
+                    if (cw + 1 - kw) % 2:
+                        continue
+                    taps += [kh * k + kw, (ch + 1 - kh) // 2, (cw + 1 - kw) // 2]
+            per.append((len(taps) // 3, ch, cw, taps))
+    per.sort(key=lambda t: -t[0])
+    d: List[int] = []
+    for n, ch, cw, taps in per:
+        d += [n, ch, cw] + taps
+    return d, len(per)
+
+
+ONE_TAP = [1, 0, 0, 0, 0, 0]
+
+
+class Saved:
+    """Activations one forward call keeps for its backward."""
+    __slots__ = ("N", "S", "T", "hw", "train", "tau", "hard", "col1", "a1", "a2", "a3", "e", "hs_enc", "hp_enc",
+                 "acts_enc", "cs_enc", "y", "z", "hs_dec", "hp_dec", "acts_dec", "cs_dec", "ds_pad", "f", "d1", "d2",
+                 "xr", "gate_scale", "dpre3")
+
+
+class Engine:
+    def __init__(self, variant: str, in_ch: int, out_ch: int, latent: int, hw: Tuple[int, int],
+                 dtype: str = "f32", device: Optional[torch.device] = None):
+        if variant not in VARIANTS:
+            raise ValueError(f"unknown variant {variant!r}")
+        if dtype not in ("f32", "bf16"):
+            raise ValueError("dtype must be 'f32' or 'bf16'")
+        self.v = VARIANTS[variant]
+        self.in_ch, self.out_ch, self.latent = in_ch, out_ch, latent
+        self.hw = tuple(hw)
+        if self.hw[0] % 8 or self.hw[1] % 8:
+            raise ValueError(f"frame size {self.hw} must be divisible by 8 (three stride-2 stages)")
+        if latent > 128:
+            raise ValueError("latent_dim > 128 is not supported by the LSTM kernel")
+        self.dt = F32 if dtype == "f32" else BF16
+        self.tdt = torch.float32 if dtype == "f32" else torch.bfloat16
+        self.es = 4 if dtype == "f32" else 2
+        self.ke = 128 // self.es
+        self.layout = ParamLayout(self.v, in_ch, out_ch, latent, self.hw)
+        self.device = device or torch.device("cuda", torch.cuda.current_device())
+        k = self.v.kernel
+        self.k = k
+        H, W = self.hw
+        self.g1 = (conv_out(H, k), conv_out(W, k))
+        self.g2 = (conv_out(self.g1[0], k), conv_out(self.g1[1], k))
+        self.g3 = (conv_out(self.g2[0], k), conv_out(self.g2[1], k))
+        c1, c2, c3 = self.v.channels
+        self.F3 = c3 * self.g3[0] * self.g3[1]
+        self.K1 = _ru(k * k * in_ch, self.ke)          # im2col width of the first conv
+        self.K3 = _ru(k * k * out_ch, self.ke)         # im2col width of d(loss)/d(pre) for the last deconv
+        self.NY = _ru(k * k * out_ch, 8)               # per-tap product width of the last deconv
+        self.Lp = _ru(latent, self.ke)
+        self.zero = torch.zeros(256, dtype=torch.uint8, device=self.device)
+        self._cls_conv = conv_classes(k)
+        self._cls_dgrad, self._ncls_dgrad = dgrad_classes(k)
+        self._desc_cache: Dict[Tuple, object] = {}
+        self._idx_cache: Dict[Tuple, torch.Tensor] = {}
+        self._alloc_packed()
+
+    # ---- packed weights -------------------------------------------------------
+    def _alloc_packed(self):
+        c1, c2, c3 = self.v.channels
+        kk = self.k * self.k
+        z = lambda *s: torch.zeros(*s, dtype=self.tdt, device=self.device)
+        self.W1p = z(c1, self.K1)                      # conv1 as a 1-tap GEMM over im2col columns
+        self.W2f, self.W2d = z(c2, kk, c1), z(c1, kk, c2)
+        self.W3f, self.W3d = z(c3, kk, c2), z(c2, kk, c3)
+        self.Wfc = z(self.latent, self.F3)             # [L][NHWC-flat]
+        self.WfcT = z(self.F3, self.Lp)                # [NHWC-flat][Lp]
+        self.Wdfc = z(self.F3, self.Lp)                # [NHWC-flat][Lp]
+        self.WdfcT = z(self.latent, self.F3)
+        self.bdfc = torch.zeros(self.F3, dtype=torch.float32, device=self.device)   # NHWC order
+        self.V1f, self.V1d = z(c3, kk, c2), z(c2, kk, c3)   # deconv0: c3 -> c2
+        self.V2f, self.V2d = z(c2, kk, c1), z(c1, kk, c2)   # deconv1: c2 -> c1
+        self.V3p = z(self.NY, c1)                      # [(t,co)][c1]: per-tap products of the last deconv
+        self.V3f = z(c1, self.K3)                      # [c1][(t,co) padded]
+
+    def pack(self, flat: torch.Tensor):
+        """f32 parameters (reference layouts) -> the packed T copies the GEMMs read."""
+        lay, dt = self.layout, self.dt
+        c1, c2, c3 = self.v.channels
+        kk = self.k * self.k
+        g3 = self.g3[0] * self.g3[1]
+        i0, i1, i2 = lay.conv_idx
+        P = lambda name: lay.view(flat, name)
+        # conv1 [c1][cin][kk] -> [c1][t*cin + ci]
+        L.call("rbvae_pack3", dt, P(f"encoder_cnn.conv.{i0}.weight"), self.W1p, c1, self.in_ch, kk, self.K1, 1, self.in_ch)
+        for name, wf, wd, co, ci in ((f"encoder_cnn.conv.{i1}.weight", self.W2f, self.W2d, c2, c1),
+                                     (f"encoder_cnn.conv.{i2}.weight", self.W3f, self.W3d, c3, c2),
+                                     (f"decoder_cnn.deconv.{i0}.weight", self.V1f, self.V1d, c3, c2),
+                                     (f"decoder_cnn.deconv.{i1}.weight", self.V2f, self.V2d, c2, c1)):
+            w = P(name)                                                  # [co][ci][kk]
+            L.call("rbvae_pack3", dt, w, wf, co, ci, kk, kk * ci, 1, ci)  # [co][t][ci]
+            L.call("rbvae_pack3", dt, w, wd, co, ci, kk, 1, kk * co, co)  # [ci][t][co]
+        v3 = P(f"decoder_cnn.deconv.{i2}.weight")                        # [c1][out][kk]
+        L.call("rbvae_pack3", dt, v3, self.V3p, c1, self.out_ch, kk, 1, c1, self.out_ch * c1)      # [(t*out+co)][c1]
+        L.call("rbvae_pack3", dt, v3, self.V3f, c1, self.out_ch, kk, self.K3, 1, self.out_ch)      # [c1][t*out+co]
+        wfc = P("encoder_cnn.fc.weight")                                 # [L][c3][g3]
+        L.call("rbvae_pack3", dt, wfc, self.Wfc, self.latent, c3, g3, self.F3, 1, c3)
+        L.call("rbvae_pack3", dt, wfc, self.WfcT, self.latent, c3, g3, 1, self.Lp, c3 * self.Lp)
+        wd = P("decoder_cnn.fc.weight")                                  # [c3][g3][L]
+        L.call("rbvae_pack3", dt, wd, self.Wdfc, c3, g3, self.latent, self.Lp, c3 * self.Lp, 1)
+        L.call("rbvae_pack3", dt, wd, self.WdfcT, c3, g3, self.latent, 1, c3, self.F3)
+        L.call("rbvae_pack3", F32, P("decoder_cnn.fc.bias"), self.bdfc, c3, g3, 1, 1, c3, 0)
+
+    # ---- helpers ---------------------------------------------------------------
+    def _desc(self, key, ints):
+        d = self._desc_cache.get(key)
+        if d is None:
+            import ctypes
+            d = (ctypes.c_int * len(ints))(*ints)
+            self._desc_cache[key] = d
+        return d
+
+    def _gemm(self, A, W, out, bias, gate, mask, nimg, ih, iw, th, tw, sa, oh, ow, so, kc, nout, lda, ldo, taps,
+              cls_key, relu=0, drop_mode=0, drop_p=0.0, scale=1.0, seed=0):
+        if cls_key == "one":
+            desc, ncls = self._desc("one", ONE_TAP), 1
+        elif cls_key == "conv":
+            desc, ncls = self._desc("conv", self._cls_conv), 1
+        else:
+            desc, ncls = self._desc("dgrad", self._cls_dgrad), self._ncls_dgrad
+        import ctypes
+        L.call("rbvae_gather_gemm", self.dt, A, W, out, bias, gate, mask, self.zero, nimg, ih, iw, th, tw, sa, oh, ow,
+               so, kc, nout, lda, ldo, taps, ncls, ctypes.addressof(desc), relu, drop_mode, float(drop_p),
+               float(scale), int(seed))
+
+    def _conv_idx(self, nimg, ih, iw, oh, ow):
+        key = (nimg, ih, iw, oh, ow)
+        t = self._idx_cache.get(key)
+        if t is None:
+            t = torch.empty(self.k * self.k * nimg * oh * ow, dtype=torch.int32, device=self.device)
+            L.call("rbvae_conv_gather_index", t, nimg, ih, iw, oh, ow, self.k, self.k, 2, 1)
+            self._idx_cache[key] = t
+        return t
+
+    def _wgrad(self, Dy, In, idx, P, Co, Ci, ldy, ldi, taps, out, dims, strides, accumulate=False):
+        """wgrad GEMM into K-slice slabs, then the fixed-order reduction into the torch layout."""
+        bm = 128 if (Co > 64 and Ci > 64) else 64
+        blocks = -(-Co // bm) * -(-Ci // bm) * taps
+        ks = max(1, min(32, 512 // max(blocks, 1), P // 256 if P >= 256 else 1))
+        slabs = torch.empty(ks * Co * taps * Ci, dtype=torch.float32, device=self.device)
+        L.call("rbvae_wgrad_gemm", self.dt, Dy, In, slabs, idx, self.zero, P, Co, Ci, ldy, ldi, taps, ks)
+        L.call("rbvae_permute_reduce", slabs, ks, Co * taps * Ci, out, dims[0], dims[1], dims[2],
+               strides[0], strides[1], strides[2], 1.0, int(accumulate))
+
+    def _colsum(self, dt, X, P, C, ld, out, accumulate=False):
+        ws = torch.empty(L.query("rbvae_colsum_ws_floats", P, C), dtype=torch.float32, device=self.device)
+        L.call("rbvae_colsum", dt, X, P, C, ld, out, ws, 1.0, int(accumulate))
+
+    def _E(self, *shape, dtype=None):
+        return torch.empty(*shape, dtype=dtype or self.tdt, device=self.device)
+
+    # ---- forward ---------------------------------------------------------------
+    def forward(self, flat: torch.Tensor, x: torch.Tensor, U: torch.Tensor, tau: float, hard: bool,
+                noise_ratio: float, train: bool, masks: Optional[Sequence[torch.Tensor]] = None,
+                seed: int = 0, need_grad: bool = True, encode_only: bool = False,
+                target: Optional[torch.Tensor] = None, recon_gscale: float = 0.0, kl_p: Optional[float] = None):
+        """x: [S,T,C,H,W] f32 NCHW frames; U: [S*T, L] uniform noise.
+        masks: explicit dropout keep-masks (u8, NHWC rows) for the 4 dropout sites, else a counter hash.
+        target/recon_gscale: fuse recon_loss and its gradient into the last kernel (trainer path).
+        Returns dict(xr, hs, z, e, kl, mse, saved)."""
+        v = self.v
+        S, T, C, H, W = x.shape
+        if (H, W) != self.hw or C != self.in_ch:
+            raise RuntimeError(f"input frames {tuple(x.shape[2:])} do not match the model's "
+                               f"({self.in_ch}, {self.hw[0]}, {self.hw[1]})")
+        N = S * T
+        k, kk = self.k, self.k * self.k
+        c1, c2, c3 = v.channels
+        (h1, w1), (h2, w2), (h3, w3) = self.g1, self.g2, self.g3
+        Ld, lay = self.latent, self.layout
+        i0, i1, i2 = lay.conv_idx
+        P = lambda name: lay.view(flat, name)
+        x = x.contiguous()
+        drop = v.dropout if train else 0.0
+        dscale = 1.0 / (1.0 - drop) if drop > 0 else 1.0
+
+        def dm(j):      # (drop_mode, mask) of dropout site j
+            if drop == 0:
+                return 0, None
+            return (2, masks[j]) if masks is not None else (1, None)
+
+        sv = Saved()
+        sv.N, sv.S, sv.T, sv.hw, sv.train, sv.tau, sv.hard = N, S, T, (H, W), train, tau, hard
+        sv.gate_scale = dscale
+        # encoder CNN
+        sv.col1 = self._E(N * h1 * w1, self.K1)
+        L.call("rbvae_im2col", self.dt, x, C * H * W, H * W, W, 1, N, C, H, W, h1, w1, k, k, 2, 1, self.K1, sv.col1)
+        sv.a1 = self._E(N * h1 * w1, c1)
+        m, mk = dm(0)
+        self._gemm(sv.col1, self.W1p, sv.a1, P(f"encoder_cnn.conv.{i0}.bias"), None, mk, N * h1 * w1, 1, 1, 1, 1, 1,
+                   1, 1, 1, self.K1, c1, self.K1, c1, 1, "one", relu=1, drop_mode=m, drop_p=drop, scale=dscale,
+                   seed=seed * 8 + 1)
+        sv.a2 = self._E(N * h2 * w2, c2)
+        m, mk = dm(1)
+        self._gemm(sv.a1, self.W2f, sv.a2, P(f"encoder_cnn.conv.{i1}.bias"), None, mk, N, h1, w1, h2, w2, 2, h2, w2,
+                   1, c1, c2, c1, c2, kk, "conv", relu=1, drop_mode=m, drop_p=drop, scale=dscale, seed=seed * 8 + 2)
+        sv.a3 = self._E(N * h3 * w3, c3)
+        self._gemm(sv.a2, self.W3f, sv.a3, P(f"encoder_cnn.conv.{i2}.bias"), None, None, N, h2, w2, h3, w3, 2, h3,
+                   w3, 1, c2, c3, c2, c3, kk, "conv", relu=1 if v.simple_order else 0)
+        # fc -> logits e [N][L]
+        nl = v.lstm_layers
+        sv.hs_enc = self._E(nl + 1, S, T, Ld, dtype=torch.float32)
+        sv.hs_dec = self._E(nl + 1, S, T, Ld, dtype=torch.float32)
+        sv.e = self._E(N, Ld, dtype=torch.float32) if v.simple_order else sv.hs_enc[0].view(N, Ld)
+        L.call("rbvae_skinny_linear", self.dt, sv.a3, self.Wfc, P("encoder_cnn.fc.bias"), sv.e, N, Ld, self.F3,
+               self.F3, self.F3, Ld)
+        keep = need_grad
+        if keep:
+            sv.hp_enc = self._E(nl, S, T, Ld, dtype=torch.float32)
+            sv.cs_enc = self._E(nl, S, T, Ld, dtype=torch.float32)
+            sv.acts_enc = self._E(nl, S, T, 4 * Ld, dtype=torch.float32)
+            sv.hp_dec, sv.cs_dec, sv.acts_dec = (torch.empty_like(sv.hp_enc), torch.empty_like(sv.cs_enc),
+                                                 torch.empty_like(sv.acts_enc))
+        else:
+            sv.hp_enc = sv.cs_enc = sv.acts_enc = sv.hp_dec = sv.cs_dec = sv.acts_dec = None
+        sv.y = self._E(N, Ld, dtype=torch.float32)
+        r = noise_ratio if v.noise_ratio_arg else 1.0
+        kl = self._E(1, dtype=torch.float32) if kl_p is not None else None
+        wenc, wdec = P("encoder_rnn.lstm.weight_ih_l0"), P("decoder_rnn.lstm.weight_ih_l0")
+        if not v.simple_order:
+            L.call("rbvae_lstm_fwd", wenc, sv.hs_enc, sv.hp_enc, sv.acts_enc, sv.cs_enc, S, T, Ld, nl)
+            hs = sv.hs_enc[nl]
+            sv.z = sv.hs_dec[0].view(N, Ld)
+            L.call("rbvae_binarize_kl_fwd", hs, U, sv.y, sv.z, kl, N, Ld, float(tau), float(r), v.eps, int(hard),
+                   float(kl_p if kl_p is not None else 0.5), 1e-8, 1)
+            if encode_only:
+                return {"z": sv.z.view(S, T, Ld), "hs": hs, "saved": sv}
+            L.call("rbvae_lstm_fwd", wdec, sv.hs_dec, sv.hp_dec, sv.acts_dec, sv.cs_dec, S, T, Ld, nl)
+        else:
+            sv.z = sv.hs_enc[0].view(N, Ld)
+            L.call("rbvae_binarize_kl_fwd", sv.e, U, sv.y, sv.z, None, N, Ld, float(tau), float(r), v.eps, int(hard),
+                   0.5, 1e-10, 0)
+            L.call("rbvae_lstm_fwd", wenc, sv.hs_enc, sv.hp_enc, sv.acts_enc, sv.cs_enc, S, T, Ld, nl)
+            hs = sv.hs_enc[nl]
+            sv.hs_dec[0].copy_(hs)
+            L.call("rbvae_lstm_fwd", wdec, sv.hs_dec, sv.hp_dec, sv.acts_dec, sv.cs_dec, S, T, Ld, nl)
+        ds = sv.hs_dec[nl]
+        # decoder CNN
+        sv.ds_pad = self._E(N, self.Lp)
+        L.call("rbvae_cast_pad", self.dt, ds, sv.ds_pad, N, Ld, self.Lp)
+        sv.f = self._E(N * h3 * w3, c3)
+        self._gemm(sv.ds_pad, self.Wdfc, sv.f, self.bdfc, None, None, N, 1, 1, 1, 1, 1, 1, 1, 1, self.Lp, self.F3,
+                   self.Lp, self.F3, 1, "one")
+        sv.d1 = self._E(N * h2 * w2, c2)
+        m, mk = dm(2)
+        self._gemm(sv.f, self.V1d, sv.d1, P(f"decoder_cnn.deconv.{i0}.bias"), None, mk, N, h3, w3, h3, w3, 1, h2, w2,
+                   2, c3, c2, c3, c2, kk, "dgrad", relu=1, drop_mode=m, drop_p=drop, scale=dscale, seed=seed * 8 + 3)
+        sv.d2 = self._E(N * h1 * w1, c1)
+        m, mk = dm(3)
+        self._gemm(sv.d1, self.V2d, sv.d2, P(f"decoder_cnn.deconv.{i1}.bias"), None, mk, N, h2, w2, h2, w2, 1, h1, w1,
+                   2, c2, c1, c2, c1, kk, "dgrad", relu=1, drop_mode=m, drop_p=drop, scale=dscale, seed=seed * 8 + 4)
+        Y = self._E(N * h1 * w1, self.NY)
+        self._gemm(sv.d2, self.V3p, Y, None, None, None, N * h1 * w1, 1, 1, 1, 1, 1, 1, 1, 1, c1, self.NY, c1,
+                   self.NY, 1, "one")
+        sv.xr = self._E(S, T, self.out_ch, H, W, dtype=torch.float32)
+        mse = None
+        sv.dpre3 = None
+        if target is not None:
+            mse = self._E(1, dtype=torch.float32)
+            ws = self._E(L.query("rbvae_col2im_ws_floats"), dtype=torch.float32)
+            if need_grad:
+                sv.dpre3 = self._E(N, H, W, self.out_ch, dtype=torch.float32)
+            L.call("rbvae_col2im_sigmoid", self.dt, Y, self.NY, P(f"decoder_cnn.deconv.{i2}.bias"), N, h1, w1, H, W,
+                   self.out_ch, k, k, 1, sv.xr, target.contiguous(), mse, ws, sv.dpre3, float(recon_gscale), None)
+        else:
+            L.call("rbvae_col2im_sigmoid", self.dt, Y, self.NY, P(f"decoder_cnn.deconv.{i2}.bias"), N, h1, w1, H, W,
+                   self.out_ch, k, k, 1, sv.xr, None, None, None, None, 0.0, None)
+        return {"xr": sv.xr, "hs": hs, "z": sv.z.view(S, T, Ld), "e": sv.e, "kl": kl, "mse": mse, "saved": sv}
+
+    # ---- backward --------------------------------------------------------------
+    def backward(self, flat: torch.Tensor, gflat: torch.Tensor, sv: Saved, g_xr: Optional[torch.Tensor],
+                 g_hs: Optional[torch.Tensor], g_z: Optional[torch.Tensor], g_e: Optional[torch.Tensor] = None,
+                 kl_weight: float = 0.0, kl_p: float = 0.5):
+        """Writes every parameter gradient into gflat (same layout as flat).
+        g_xr: [S,T,C,H,W] upstream gradient of x_recon (None: use the fused dpre3 of forward()).
+        g_hs / g_z: [S,T,L] upstream gradients of h_seq / z_seq (None = 0).
+        g_e: upstream gradient of the conv logits (simple variant's second output).
+        kl_weight: d(loss)/d(kl_mean) when the KL term was fused into forward()."""
+        v = self.v
+        N, S, T = sv.N, sv.S, sv.T
+        H, W = sv.hw
+        k, kk = self.k, self.k * self.k
+        c1, c2, c3 = v.channels
+        (h1, w1), (h2, w2), (h3, w3) = self.g1, self.g2, self.g3
+        Ld, lay, nl = self.latent, self.layout, v.lstm_layers
+        i0, i1, i2 = lay.conv_idx
+        P = lambda name: lay.view(flat, name)
+        G = lambda name: lay.view(gflat, name)
+        gs = sv.gate_scale
+        P1, P2, P3 = N * h1 * w1, N * h2 * w2, N * h3 * w3
+        g3 = h3 * w3
+        # --- last deconv
+        if g_xr is not None:
+            dpre3 = self._E(N, H, W, self.out_ch, dtype=torch.float32)
+            L.call("rbvae_sigmoid_bwd_nhwc", g_xr.contiguous(), sv.xr, dpre3, N, self.out_ch, H, W)
+        else:
+            dpre3 = sv.dpre3
+            if dpre3 is None:
+                raise RuntimeError("backward without g_xr needs forward(target=..., need_grad=True)")
+        self._colsum(F32, dpre3, N * H * W, self.out_ch, self.out_ch, G(f"decoder_cnn.deconv.{i2}.bias"))
+        col3 = self._E(P1, self.K3)
+        oc = self.out_ch
+        L.call("rbvae_im2col", self.dt, dpre3, H * W * oc, 1, W * oc, oc, N, oc, H, W, h1, w1, k, k, 2, 1, self.K3, col3)
+        self._wgrad(sv.d2, col3, None, P1, c1, self.K3, c1, self.K3, 1, G(f"decoder_cnn.deconv.{i2}.weight"),
+                    (c1, oc, kk), (self.K3, 1, oc))
+        dd2 = self._E(P1, c1)
+        self._gemm(col3, self.V3f, dd2, None, sv.d2, None, P1, 1, 1, 1, 1, 1, 1, 1, 1, self.K3, c1, self.K3, c1, 1,
+                   "one", scale=gs)
+        # --- deconv1 (c2 -> c1): input grad = conv forward of dd2 with the same weights
+        self._colsum(self.dt, dd2, P1, c1, c1, G(f"decoder_cnn.deconv.{i1}.bias"))
+        self._wgrad(sv.d1, dd2, self._conv_idx(N, h1, w1, h2, w2), P2, c2, c1, c2, c1, kk,
+                    G(f"decoder_cnn.deconv.{i1}.weight"), (c2, c1, kk), (kk * c1, 1, c1))
+        dd1 = self._E(P2, c2)
+        self._gemm(dd2, self.V2f, dd1, None, sv.d1, None, N, h1, w1, h2, w2, 2, h2, w2, 1, c1, c2, c1, c2, kk, "conv",
+                   scale=gs)
+        # --- deconv0 (c3 -> c2)
+        self._colsum(self.dt, dd1, P2, c2, c2, G(f"decoder_cnn.deconv.{i0}.bias"))
+        self._wgrad(sv.f, dd1, self._conv_idx(N, h2, w2, h3, w3), P3, c3, c2, c3, c2, kk,
+                    G(f"decoder_cnn.deconv.{i0}.weight"), (c3, c2, kk), (kk * c2, 1, c2))
+        df = self._E(P3, c3)
+        self._gemm(dd1, self.V1f, df, None, None, None, N, h2, w2, h3, w3, 2, h3, w3, 1, c2, c3, c2, c3, kk, "conv")
+        # --- decoder fc
+        tmp = self._E(self.F3, dtype=torch.float32)
+        self._colsum(self.dt, df, N, self.F3, self.F3, tmp)
+        L.call("rbvae_permute_reduce", tmp, 1, 0, G("decoder_cnn.fc.bias"), c3, g3, 1, 1, c3, 0, 1.0, 0)
+        self._wgrad(df, sv.ds_pad, None, N, self.F3, self.Lp, self.F3, self.Lp, 1, G("decoder_cnn.fc.weight"),
+                    (c3, g3, Ld), (self.Lp, c3 * self.Lp, 1))
+        dds = self._E(N, Ld, dtype=torch.float32)
+        L.call("rbvae_skinny_linear", self.dt, df, self.WdfcT, None, dds, N, Ld, self.F3, self.F3, self.F3, Ld)
+        # --- decoder LSTM
+        wenc, wdec = P("encoder_rnn.lstm.weight_ih_l0"), P("decoder_rnn.lstm.weight_ih_l0")
+        dG = self._E(nl, S, T, 4 * Ld, dtype=torch.float32)
+        d_in_dec = self._E(N, Ld, dtype=torch.float32)
+        L.call("rbvae_lstm_bwd", wdec, sv.acts_dec, sv.cs_dec, dds, dG, d_in_dec, S, T, Ld, nl)
+        L.call("rbvae_lstm_wgrad", dG, sv.hs_dec, sv.hp_dec, G("decoder_rnn.lstm.weight_ih_l0"), S, T, Ld, nl, 0)
+        de = self._E(N, Ld, dtype=torch.float32)
+        if not v.simple_order:
+            # z -> binarise backward (+ fused KL) -> gradient of h_seq
+            gz = d_in_dec
+            if g_z is not None:
+                gz = gz + g_z.reshape(N, Ld)
+            dh = self._E(N, Ld, dtype=torch.float32)
+            L.call("rbvae_binarize_kl_bwd", gz, sv.y, sv.z, dh, 0, N, Ld, float(sv.tau), float(kl_weight), None,
+                   float(kl_p), 1e-8, 1)
+            if g_hs is not None:
+                dh = dh + g_hs.reshape(N, Ld)
+            L.call("rbvae_lstm_bwd", wenc, sv.acts_enc, sv.cs_enc, dh, dG, de, S, T, Ld, nl)
+            L.call("rbvae_lstm_wgrad", dG, sv.hs_enc, sv.hp_enc, G("encoder_rnn.lstm.weight_ih_l0"), S, T, Ld, nl, 0)
+        else:
+            # decoder stack input = encoder stack output
+            dz = self._E(N, Ld, dtype=torch.float32)
+            L.call("rbvae_lstm_bwd", wenc, sv.acts_enc, sv.cs_enc, d_in_dec, dG, dz, S, T, Ld, nl)
+            L.call("rbvae_lstm_wgrad", dG, sv.hs_enc, sv.hp_enc, G("encoder_rnn.lstm.weight_ih_l0"), S, T, Ld, nl, 0)
+            L.call("rbvae_binarize_kl_bwd", dz, sv.y, sv.z, de, 0, N, Ld, float(sv.tau), 0.0, None, 0.5, 1e-10, 0)
+            if g_e is not None:
+                de = de + g_e.reshape(N, Ld)
+        # --- encoder fc
+        self._colsum(F32, de, N, Ld, Ld, G("encoder_cnn.fc.bias"))
+        de_pad = self._E(N, self.Lp)
+        L.call("rbvae_cast_pad", self.dt, de, de_pad, N, Ld, self.Lp)
+        gw = self._E(self.Lp, self.F3, dtype=torch.float32)
+        bm = 64
+        L.call("rbvae_wgrad_gemm", self.dt, de_pad, sv.a3, gw, None, self.zero, N, self.Lp, self.F3, self.Lp, self.F3, 1, 1)
+        L.call("rbvae_permute_reduce", gw, 1, 0, G("encoder_cnn.fc.weight"), Ld, c3, g3, self.F3, 1, c3, 1.0, 0)
+        da3 = self._E(P3, c3)
+        self._gemm(de_pad, self.WfcT, da3, None, sv.a3 if v.simple_order else None, None, N, 1, 1, 1, 1, 1, 1, 1, 1,
+                   self.Lp, self.F3, self.Lp, self.F3, 1, "one")
+        # --- conv3
+        self._colsum(self.dt, da3, P3, c3, c3, G(f"encoder_cnn.conv.{i2}.bias"))
+        self._wgrad(da3, sv.a2, self._conv_idx(N, h2, w2, h3, w3), P3, c3, c2, c3, c2, kk,
+                    G(f"encoder_cnn.conv.{i2}.weight"), (c3, c2, kk), (kk * c2, 1, c2))
+        da2 = self._E(P2, c2)
+        self._gemm(da3, self.W3d, da2, None, sv.a2, None, N, h3, w3, h3, w3, 1, h2, w2, 2, c3, c2, c3, c2, kk, "dgrad",
+                   scale=gs)
+        # --- conv2
+        self._colsum(self.dt, da2, P2, c2, c2, G(f"encoder_cnn.conv.{i1}.bias"))
+        self._wgrad(da2, sv.a1, self._conv_idx(N, h1, w1, h2, w2), P2, c2, c1, c2, c1, kk,
+                    G(f"encoder_cnn.conv.{i1}.weight"), (c2, c1, kk), (kk * c1, 1, c1))
+        da1 = self._E(P1, c1)
+        self._gemm(da2, self.W2d, da1, None, sv.a1, None, N, h2, w2, h2, w2, 1, h1, w1, 2, c2, c1, c2, c1, kk, "dgrad",
+                   scale=gs)
+        # --- conv1 (1-tap GEMM over the saved im2col columns)
+        self._colsum(self.dt, da1, P1, c1, c1, G(f"encoder_cnn.conv.{i0}.bias"))
+        self._wgrad(da1, sv.col1, None, P1, c1, self.K1, c1, self.K1, 1, G(f"encoder_cnn.conv.{i0}.weight"),
+                    (c1, self.in_ch, kk), (self.K1, 1, self.in_ch))

@@ -1,0 +1,221 @@
+"""Unit parity of the GEMM / LSTM / layout kernels against plain torch fp32 on the CPU."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import rbvae_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def sfv():
+    import sfv_amd
+    return sfv_amd
+
+
+def rel(a, b):
+    a, b = a.double(), b.double()
+    return float((a - b).norm() / max(b.norm(), 1e-12))
+
+
+DT = {"f32": (0, torch.float32, 1e-5), "bf16": (1, torch.bfloat16, 1.2e-2)}
+
+
+def nhwc(t, tdt):       # [N,C,H,W] -> rows [N*H*W, C] on the GPU
+    return t.permute(0, 2, 3, 1).contiguous().reshape(-1, t.shape[1]).to(tdt).cuda()
+
+
+def from_rows(r, N, H, W):
+    return r.float().cpu().reshape(N, H, W, -1).permute(0, 3, 1, 2)
+
+
+def gemm(sfv, dt, A, Wp, out, bias, gate, mask, geom, kc, nout, taps, desc, ncls, relu=0, drop_mode=0, drop_p=0.0,
+         scale=1.0, seed=0):
+    zero = torch.zeros(256, dtype=torch.uint8, device="cuda")
+    d = (ctypes.c_int * len(desc))(*desc)
+    sfv._lib.call("rbvae_gather_gemm", dt, A, Wp, out, bias, gate, mask, zero, *geom, kc, nout, A.shape[1],
+                  out.shape[1], taps, ncls, ctypes.addressof(d), relu, drop_mode, drop_p, scale, seed)
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("k,C,Co,N,H,W", [(3, 64, 64, 3, 16, 24), (3, 256, 256, 2, 8, 8), (4, 64, 128, 2, 16, 16),
+                                           (3, 128, 72, 5, 10, 6)])
+def test_conv_forward_and_dgrad(sfv, dtype, k, C, Co, N, H, W):
+    from importlib import import_module
+    E = import_module("symbols-from-video_amd.engine")
+    dt, tdt, tol = DT[dtype]
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(N, C, H, W, generator=g).to(tdt).float()
+    w = (torch.randn(Co, C, k, k, generator=g) / (C * k * k) ** 0.5).to(tdt).float()
+    b = torch.randn(Co, generator=g)
+    Ho, Wo = E.conv_out(H, k), E.conv_out(W, k)
+    # forward: conv + bias + relu, scaled
+    wf = w.permute(0, 2, 3, 1).contiguous().to(tdt).cuda()             # [co][kh][kw][ci]
+    out = torch.empty(N * Ho * Wo, Co, dtype=tdt, device="cuda")
+    gemm(sfv, dt, nhwc(x, tdt), wf, out, b.cuda(), None, None, (N, H, W, Ho, Wo, 2, Ho, Wo, 1), C, Co, k * k,
+         E.conv_classes(k), 1, relu=1, scale=1.25)
+    ref = F.relu(F.conv2d(x, w, b, stride=2, padding=1)) * 1.25
+    assert rel(from_rows(out, N, Ho, Wo), ref) < tol
+    # input gradient (= conv-transpose forward) with a gate
+    dy = torch.randn(N, Co, Ho, Wo, generator=g).to(tdt).float()
+    gate = torch.randn(N, C, 2 * Ho, 2 * Wo, generator=g)
+    wd = w.permute(1, 2, 3, 0).contiguous().to(tdt).cuda()             # [ci][kh][kw][co]
+    desc, ncls = E.dgrad_classes(k)
+    dx = torch.full((N * 2 * Ho * 2 * Wo, C), 7.0, dtype=tdt, device="cuda")
+    gemm(sfv, dt, nhwc(dy, tdt), wd, dx, None, nhwc(gate, tdt), None, (N, Ho, Wo, Ho, Wo, 1, 2 * Ho, 2 * Wo, 2), Co, C,
+         k * k, desc, ncls, scale=0.5)
+    op = 1 if k == 3 else 0
+    ref = F.conv_transpose2d(dy, w, None, stride=2, padding=1, output_padding=op) * 0.5
+    ref = ref * (gate.to(tdt).float() > 0)
+    assert rel(from_rows(dx, N, 2 * Ho, 2 * Wo), ref) < tol
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_dropout_modes(sfv, dtype):
+    dt, tdt, tol = DT[dtype]
+    g = torch.Generator().manual_seed(2)
+    M, K, Nout = 300, 128, 136
+    A = torch.randn(M, K, generator=g).to(tdt)
+    Wt = (torch.randn(Nout, K, generator=g) / K ** 0.5).to(tdt)
+    ref = A.float() @ Wt.float().t()
+    keep = (torch.rand(M, Nout, generator=g) > 0.2)
+    out = torch.empty(M, Nout, dtype=tdt, device="cuda")
+    gemm(sfv, dt, A.cuda(), Wt.cuda(), out, None, None, keep.to(torch.uint8).cuda(), (M, 1, 1, 1, 1, 1, 1, 1, 1), K,
+         Nout, 1, [1, 0, 0, 0, 0, 0], 1, drop_mode=2, drop_p=0.2, scale=1.25)
+    assert rel(out.float().cpu(), ref * keep * 1.25) < tol
+    gemm(sfv, dt, A.cuda(), Wt.cuda(), out, None, None, None, (M, 1, 1, 1, 1, 1, 1, 1, 1), K, Nout, 1,
+         [1, 0, 0, 0, 0, 0], 1, drop_mode=1, drop_p=0.2, scale=1.25, seed=11)
+    o = out.float().cpu()
+    dropped = (o == 0)
+    assert 0.17 < dropped.float().mean().item() < 0.23
+    assert rel(o[~dropped], (ref * 1.25)[~dropped]) < tol
+    out2 = torch.empty_like(out)
+    gemm(sfv, dt, A.cuda(), Wt.cuda(), out2, None, None, None, (M, 1, 1, 1, 1, 1, 1, 1, 1), K, Nout, 1,
+         [1, 0, 0, 0, 0, 0], 1, drop_mode=1, drop_p=0.2, scale=1.25, seed=11)
+    assert torch.equal(out, out2)                                       # same seed -> same mask, bitwise
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("k,C,Co,N,H,W,ks", [(3, 64, 64, 3, 16, 24, 1), (3, 256, 256, 2, 8, 8, 2), (4, 64, 128, 2, 16, 16, 3),
+                                              (3, 128, 72, 5, 10, 6, 1)])
+def test_conv_wgrad(sfv, dtype, k, C, Co, N, H, W, ks):
+    from importlib import import_module
+    E = import_module("symbols-from-video_amd.engine")
+    dt, tdt, tol = DT[dtype]
+    g = torch.Generator().manual_seed(3)
+    Ho, Wo = E.conv_out(H, k), E.conv_out(W, k)
+    x = torch.randn(N, C, H, W, generator=g).to(tdt).float().requires_grad_(False)
+    dy = torch.randn(N, Co, Ho, Wo, generator=g).to(tdt).float()
+    w = torch.zeros(Co, C, k, k, requires_grad=True)
+    F.conv2d(x, w, None, stride=2, padding=1).backward(dy)
+    P = N * Ho * Wo
+    idx = torch.empty(k * k * P, dtype=torch.int32, device="cuda")
+    sfv._lib.call("rbvae_conv_gather_index", idx, N, H, W, Ho, Wo, k, k, 2, 1)
+    slabs = torch.full((ks, Co, k * k, C), 9.0, device="cuda")
+    zero = torch.zeros(256, dtype=torch.uint8, device="cuda")
+    sfv._lib.call("rbvae_wgrad_gemm", dt, nhwc(dy, tdt), nhwc(x, tdt), slabs, idx, zero, P, Co, C, Co, C, k * k, ks)
+    out = torch.empty(Co, C, k * k, device="cuda")
+    sfv._lib.call("rbvae_permute_reduce", slabs, ks, Co * k * k * C, out, Co, C, k * k, k * k * C, 1, C, 1.0, 0)
+    assert rel(out.cpu().reshape(Co, C, k, k), w.grad) < tol
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_skinny_linear_and_colsum(sfv, dtype):
+    dt, tdt, tol = DT[dtype]
+    g = torch.Generator().manual_seed(4)
+    for (M, Nc, K) in ((37, 25, 4096), (256, 32, 1024), (6, 100, 64)):
+        A = torch.randn(M, K, generator=g).to(tdt)
+        B = (torch.randn(Nc, K, generator=g) / K ** 0.5).to(tdt)
+        b = torch.randn(Nc, generator=g)
+        out = torch.empty(M, Nc, device="cuda")
+        sfv._lib.call("rbvae_skinny_linear", dt, A.cuda(), B.cuda(), b.cuda(), out, M, Nc, K, K, K, Nc)
+        assert rel(out.cpu(), A.float() @ B.float().t() + b) < tol
+    for (P, C) in ((1000, 256), (77, 3), (513, 4096), (300, 25)):
+        X = torch.randn(P, C, generator=g).to(tdt)
+        out = torch.empty(C, device="cuda")
+        ws = torch.empty(sfv._lib.query("rbvae_colsum_ws_floats", P, C), device="cuda")
+        sfv._lib.call("rbvae_colsum", dt, X.cuda(), P, C, C, out, ws, 1.0, 0)
+        assert rel(out.cpu(), X.float().sum(0)) < 1e-5
+
+
+@pytest.mark.parametrize("L,layers,S,T", [(32, 4, 5, 8), (25, 2, 3, 5), (64, 2, 2, 3), (100, 1, 2, 4)])
+def test_lstm_forward_backward(sfv, L, layers, S, T):
+    g = torch.Generator().manual_seed(5)
+    names = []
+    p = {}
+    for l in range(layers):
+        for nm, shp in (("weight_ih", (4 * L, L)), ("weight_hh", (4 * L, L)), ("bias_ih", (4 * L,)), ("bias_hh", (4 * L,))):
+            t = ((torch.rand(shp, generator=g) * 2 - 1) / L ** 0.5).requires_grad_()
+            p[f"r.lstm.{nm}_l{l}"] = t
+            names.append(f"r.lstm.{nm}_l{l}")
+    x = torch.randn(S, T, L, generator=g, requires_grad=True)
+    gt = torch.randn(S, T, L, generator=g)
+    y = O.lstm_stack(x, p, "r", layers)
+    y.backward(gt)
+    wblk = torch.cat([p[n].detach().reshape(-1) for n in names]).cuda()
+    hs = torch.empty(layers + 1, S, T, L, device="cuda")
+    hs[0] = x.detach().cuda()
+    hp, cs, acts = torch.empty(layers, S, T, L, device="cuda"), torch.empty(layers, S, T, L, device="cuda"), \
+        torch.empty(layers, S, T, 4 * L, device="cuda")
+    sfv._lib.call("rbvae_lstm_fwd", wblk, hs, hp, acts, cs, S, T, L, layers)
+    np.testing.assert_allclose(hs[layers].cpu().numpy(), y.detach().numpy(), atol=2e-6)
+    dG, dx = torch.empty(layers, S, T, 4 * L, device="cuda"), torch.empty(S, T, L, device="cuda")
+    sfv._lib.call("rbvae_lstm_bwd", wblk, acts, cs, gt.cuda(), dG, dx, S, T, L, layers)
+    np.testing.assert_allclose(dx.cpu().numpy(), x.grad.numpy(), atol=2e-6, rtol=1e-4)
+    gb = torch.empty_like(wblk)
+    sfv._lib.call("rbvae_lstm_wgrad", dG, hs, hp, gb, S, T, L, layers, 0)
+    ref = torch.cat([p[n].grad.reshape(-1) for n in names])
+    assert rel(gb.cpu(), ref) < 1e-5
+
+
+def test_im2col_col2im(sfv):
+    g = torch.Generator().manual_seed(6)
+    N, C, H, W, k = 2, 4, 8, 12, 3
+    x = torch.randn(N, C, H, W, generator=g)
+    Ho, Wo, Kp = 4, 6, 64
+    col = torch.empty(N * Ho * Wo, Kp, device="cuda")
+    sfv._lib.call("rbvae_im2col", 0, x.cuda(), C * H * W, H * W, W, 1, N, C, H, W, Ho, Wo, k, k, 2, 1, Kp, col)
+    ref = F.unfold(x, k, padding=1, stride=2)                         # [N, C*k*k, Ho*Wo], (c, kh, kw) order
+    ref = ref.reshape(N, C, k * k, Ho * Wo).permute(0, 3, 2, 1).reshape(N * Ho * Wo, k * k * C)
+    np.testing.assert_array_equal(col.cpu()[:, :k * k * C].numpy(), ref.numpy())
+    assert float(col[:, k * k * C:].abs().max()) == 0.0
+    # col2im + bias + sigmoid + mse + dpre against conv_transpose2d
+    Cin, Co = 16, 3
+    a = torch.randn(N, Cin, Ho, Wo, generator=g)
+    V = torch.randn(Cin, Co, k, k, generator=g) * 0.2
+    b = torch.randn(Co, generator=g)
+    tgt = torch.rand(N, Co, 2 * Ho, 2 * Wo, generator=g)
+    Y = torch.einsum("nchw,cotk->nhwtok", a, V.reshape(Cin, Co, k * k, 1)).reshape(N * Ho * Wo, k * k * Co)
+    NY = 32
+    Yp = torch.zeros(N * Ho * Wo, NY)
+    Yp[:, :k * k * Co] = Y
+    xr = torch.empty(N, Co, 2 * Ho, 2 * Wo, device="cuda")
+    mse = torch.empty(1, device="cuda")
+    ws = torch.empty(sfv._lib.query("rbvae_col2im_ws_floats"), device="cuda")
+    dpre = torch.empty(N, 2 * Ho, 2 * Wo, Co, device="cuda")
+    sfv._lib.call("rbvae_col2im_sigmoid", 0, Yp.cuda(), NY, b.cuda(), N, Ho, Wo, 2 * Ho, 2 * Wo, Co, k, k, 1, xr,
+                  tgt.cuda(), mse, ws, dpre, 0.5, None)
+    ref = torch.sigmoid(F.conv_transpose2d(a, V, b, stride=2, padding=1, output_padding=1))
+    np.testing.assert_allclose(xr.cpu().numpy(), ref.numpy(), atol=2e-6)
+    assert abs(mse.item() - ((ref - tgt) ** 2).mean().item()) < 1e-6
+    dref = 0.5 * (ref - tgt) * ref * (1 - ref)
+    np.testing.assert_allclose(dpre.cpu().permute(0, 3, 1, 2).numpy(), dref.numpy(), atol=1e-6)
+
+
+def test_adam_matches_torch(sfv):
+    g = torch.Generator().manual_seed(7)
+    n = 10007
+    w = torch.randn(n, generator=g)
+    p = torch.nn.Parameter(w.clone())
+    opt = torch.optim.Adam([p], lr=1e-3)
+    wd, m, v = w.clone().cuda(), torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
+    for step in range(1, 4):
+        gr = torch.randn(n, generator=g) * 10 ** float(torch.randint(-6, 1, (1,), generator=g))
+        p.grad = gr.clone()
+        opt.step()
+        sfv._lib.call("rbvae_adam_step", wd, gr.cuda(), m, v, n, 1e-3, 0.9, 0.999, 1e-8, step, 1.0)
+        np.testing.assert_allclose(wd.cpu().numpy(), p.detach().numpy(), atol=2e-7, rtol=0)

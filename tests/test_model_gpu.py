@@ -1,0 +1,167 @@
+"""End-to-end parity of the HIP module with the reference's own outputs (golden fixtures
+made by tools/make_golden.py) and with the CPU oracle."""
+import numpy as np
+import pytest
+import torch
+
+import rbvae_oracle as O
+from _golden import MODEL_CASES, case_masks, load, sample_idx
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def sfv():
+    import sfv_amd
+    return sfv_amd
+
+
+def build(sfv, g, dtype="f32"):
+    variant = str(g["meta/variant"])
+    in_ch, Ld = int(g["meta/in_ch"]), int(g["meta/L"])
+    hw = tuple(int(v) for v in g["meta/hw"])
+    torch.manual_seed(int(g["meta/seed"]))
+    m = sfv.Seq2SeqBinaryVAE(in_ch, in_ch, Ld, Ld, variant=variant, input_hw=hw, compute_dtype=dtype)
+    sd = m.state_dict()
+    for k, v in sd.items():                      # same initial weights as the reference run
+        cs = g[f"paramsum/{k}"]
+        assert float(v.double().sum()) == cs[0] and float(v.double().abs().sum()) == cs[1], k
+    return variant, m.cuda()
+
+
+def step(sfv, variant, m, g, item, U, masks):
+    tau, r = float(g["meta/tau"]), float(g["meta/noise_ratio"])
+    hard = bool(g["meta/hard"])
+    outs, recons, kls = [], [], []
+    for vw in range(2):
+        kw = dict(temperature=tau, hard=hard, u=U[vw], dropout_masks=None if masks is None else masks[vw])
+        if variant != "triplet":
+            kw["noise_ratio"] = r
+        xr, h, z = m(item[:, vw], **kw)
+        outs.append((xr, h, z))
+        recons.append(sfv.recon_loss(xr, item[:, vw]))
+        kls.append(sfv.kl_binary_concrete(z, p=float(g["meta/bern_p"])))
+    recon, kl = (recons[0] + recons[1]) / 2, (kls[0] + kls[1]) / 2
+    h0, h1 = outs[0][1], outs[1][1]
+    T = h0.shape[1]
+    if variant == "triplet":
+        pair = sum(sfv.triplet_loss(h0[:, s], h1[:, s], h0[:, s + 1], margin=float(g["meta/margin"]), p=2.0, swap=True)
+                   for s in range(T - 1)) / float(T - 1)
+    else:
+        pair = sfv.contrast_loss(h0, h1, label=0) + sum(
+            sfv.contrast_loss(h0[:, s], h0[:, s + 1], label=1) for s in range(T - 1)) / float(T - 1)
+    total = recon + float(g["meta/beta"]) * kl + float(g["meta/alpha"]) * pair
+    return outs, {"total": total, "recon": recon, "kl": kl, "pair": pair}
+
+
+@pytest.mark.parametrize("name", MODEL_CASES)
+def test_reference_fixture_f32(sfv, name):
+    g = load(name)
+    variant, m = build(sfv, g)
+    train = bool(g["meta/train_mode"])
+    m.train(train)
+    item = torch.from_numpy(g["item"]).cuda()
+    U = [torch.from_numpy(g["U0"]).cuda(), torch.from_numpy(g["U1"]).cuda()]
+    masks = [case_masks(g, 0), case_masks(g, 1)] if train else None
+    outs, res = step(sfv, variant, m, g, item, U, masks)
+    for vw, (xr, h, z) in enumerate(outs):
+        np.testing.assert_allclose(h.detach().cpu().numpy(), g[f"h{vw}"], atol=2e-5)
+        if bool(g["meta/hard"]):
+            # binary codes: bit-exact wherever the pre-activation is not within rounding of zero
+            r, tau = float(g["meta/noise_ratio"]), float(g["meta/tau"])
+            U_ = g[f"U{vw}"]
+            margin = np.abs(g[f"h{vw}"].reshape(U_.shape) + r * (np.log(U_ + 1e-8) - np.log(1 - U_ + 1e-8)))
+            safe = (margin > 1e-4).reshape(g[f"z{vw}"].shape)
+            zz = z.detach().cpu().numpy()
+            assert set(np.unique(zz)) <= {0.0, 1.0}
+            assert np.array_equal(zz[safe], g[f"z{vw}"][safe])
+            assert safe.mean() > 0.99
+        else:
+            np.testing.assert_allclose(z.detach().cpu().numpy(), g[f"z{vw}"], atol=2e-5)
+        if f"xr{vw}" in g.files:
+            np.testing.assert_allclose(xr.detach().cpu().numpy(), g[f"xr{vw}"], atol=2e-5)
+        else:
+            flat = xr.detach().cpu().reshape(-1)
+            np.testing.assert_allclose(flat[sample_idx(flat.numel(), 389)].numpy(), g[f"xr{vw}_samp"], atol=2e-5)
+    for k in ("total", "recon", "kl", "pair"):                 # north_star: losses within 1e-4
+        assert abs(res[k].item() - float(g[f"loss/{k}"])) < 1e-4, (k, res[k].item(), float(g[f"loss/{k}"]))
+    res["total"].backward()
+    sd_names = list(m.state_dict().keys())
+    for k, p in zip(sd_names, m.parameters()):
+        gr = p.grad.detach().cpu().reshape(-1)
+        n_ref = float(g[f"gradnorm/{k}"])
+        if f"gradfull/{k}" in g.files:
+            ref = g[f"gradfull/{k}"]
+            err = np.linalg.norm(gr.numpy() - ref) / max(np.linalg.norm(ref), 1e-12)
+        else:
+            ref = g[f"gradsamp/{k}"]
+            err = np.linalg.norm(gr[sample_idx(gr.numel())].numpy() - ref) / max(np.linalg.norm(ref), 1e-12)
+        assert err < 1e-4, (k, err)
+        assert abs(float(gr.double().norm()) - n_ref) <= 1e-4 * max(n_ref, 1e-6), k
+
+
+def test_simple_cfg1(sfv):
+    g = load("simple_cfg1")
+    Ld = int(g["meta/L"])
+    torch.manual_seed(int(g["meta/seed"]))
+    m = sfv.Seq2SeqBinaryVAE(3, 3, Ld, Ld, variant="simple").cuda()
+    x = torch.from_numpy(g["x"]).cuda()
+    xr, logits = m(x, temperature=0.5, hard=False, u=torch.from_numpy(g["U"]).cuda())
+    np.testing.assert_allclose(logits.detach().cpu().numpy(), g["logits"], atol=2e-5)
+    recon = sfv.recon_loss(xr, x)
+    kl = sfv.kl_binary_concrete_simple(logits, p=0.1)
+    total = recon + 0.1 * kl
+    for k, v in (("total", total), ("recon", recon), ("kl", kl)):
+        assert abs(v.item() - float(g[f"loss/{k}"])) < 1e-4
+    total.backward()
+    for k, p in zip(m.state_dict().keys(), m.parameters()):
+        n_ref = float(g[f"gradnorm/{k}"])
+        assert abs(float(p.grad.double().norm()) - n_ref) <= 2e-4 * max(n_ref, 1e-6), k
+        ref = g[f"gradsamp/{k}"]
+        got = p.grad.detach().cpu().reshape(-1)[sample_idx(p.grad.numel())].numpy()
+        assert np.linalg.norm(got - ref) <= 2e-4 * max(np.linalg.norm(ref), 1e-9), k
+
+
+@pytest.mark.parametrize("name", ["percep_small_eval", "contrastive_small_train"])
+def test_bf16_mode_tracks_f32(sfv, name):
+    """bf16 storage / f32 accumulation: reported, loosely gated (1e-2 relative)."""
+    g = load(name)
+    variant, m = build(sfv, g, dtype="bf16")
+    train = bool(g["meta/train_mode"])
+    m.train(train)
+    item = torch.from_numpy(g["item"]).cuda()
+    U = [torch.from_numpy(g["U0"]).cuda(), torch.from_numpy(g["U1"]).cuda()]
+    masks = [case_masks(g, 0), case_masks(g, 1)] if train else None
+    outs, res = step(sfv, variant, m, g, item, U, masks)
+    for k in ("total", "recon", "kl", "pair"):
+        ref = float(g[f"loss/{k}"])
+        assert abs(res[k].item() - ref) < 2e-2 * max(abs(ref), 1.0), (k, res[k].item(), ref)
+    res["total"].backward()
+    worst = 0.0
+    for k, p in zip(m.state_dict().keys(), m.parameters()):
+        n_ref = float(g[f"gradnorm/{k}"])
+        worst = max(worst, abs(float(p.grad.double().norm()) - n_ref) / max(n_ref, 1e-9))
+    assert worst < 0.1, worst
+
+
+def test_encode_codes_and_api(sfv):
+    g = load("contrastive_small_hard")
+    variant, m = build(sfv, g)
+    m.eval()
+    item = torch.from_numpy(g["item"]).cuda()
+    z = m.encode(item[:, 0], temperature=float(g["meta/tau"]), hard=True, noise_ratio=float(g["meta/noise_ratio"]),
+                 u=torch.from_numpy(g["U0"]).cuda())
+    assert z.shape == g["z0"].shape and set(np.unique(z.cpu().numpy())) <= {0.0, 1.0}
+    assert (z.cpu().numpy() != g["z0"]).mean() < 0.01
+    z1 = m.encode(item[:1, 0, :1], temperature=0.2, hard=True)          # B = T = 1 like the eval scripts
+    assert z1.shape == (1, 1, m.latent_dim)
+    with pytest.raises(RuntimeError):
+        m(item[:, 0].cpu())
+    with pytest.raises(RuntimeError):
+        m(torch.zeros(1, 2, 3, 40, 40, device="cuda"))
+    sd = m.state_dict()
+    m2 = sfv.Seq2SeqBinaryVAE(3, 3, m.latent_dim, variant=variant, input_hw=m.input_hw).cuda()
+    m2.load_state_dict(sd)
+    z2 = m2.eval().encode(item[:, 0], temperature=float(g["meta/tau"]), hard=True,
+                          noise_ratio=float(g["meta/noise_ratio"]), u=torch.from_numpy(g["U0"]).cuda())
+    assert torch.equal(z, z2)
