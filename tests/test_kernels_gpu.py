@@ -43,7 +43,7 @@ def gemm(sfv, dt, A, Wp, out, bias, gate, mask, geom, kc, nout, taps, desc, ncls
 
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
 @pytest.mark.parametrize("k,C,Co,N,H,W", [(3, 64, 64, 3, 16, 24), (3, 256, 256, 2, 8, 8), (4, 64, 128, 2, 16, 16),
-                                           (3, 128, 72, 5, 10, 6)])
+                                           (3, 192, 128, 5, 10, 6)])
 def test_conv_forward_and_dgrad(sfv, dtype, k, C, Co, N, H, W):
     from importlib import import_module
     E = import_module("symbols-from-video_amd.engine")
