@@ -1,0 +1,200 @@
+#!/usr/bin/env python3
+"""RBVAE hot-path benchmark: frames/s of the fused training step (encode + binarise + decode,
+forward + backward + losses + Adam) on synthetic LDM-latent frames.
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: launched by torch.distributed.run, one rank per GPU, RCCL all-reduce of the flat gradients)
+
+Workload (BASELINE.json configs[1]): percep_RBVAE, item [16,2,8,4,32,32] ~ N(0,1)
+(256 frames per step per GPU = the latents of 256x256 frames), latent 32, 4-layer LSTMs, bf16
+storage / f32 accumulation, tau 0.7, noise ratio 0.1, p 0.1, alpha = beta = 1, dropout on.
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import contextlib
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch
+
+B_ITEMS, T_STATES, C_IN, HW, LATENT = 16, 8, 4, (32, 32), 32
+TAU, NOISE_R, BERN_P, ALPHA, BETA = 0.7, 0.1, 0.1, 1.0, 1.0
+MFMA_BF16_PEAK_TFLOPS = 2500.0     # MI355X_MICROARCH.md: dense bf16 MFMA peak
+
+
+class KernelTimer:
+    """HIP events around every launch of one kernel family, on the stream it is launched on."""
+
+    def __init__(self):
+        self.pairs = []
+        self.flops = 0.0
+
+    @contextlib.contextmanager
+    def __call__(self, flops):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(torch.cuda.current_stream())
+        yield
+        b.record(torch.cuda.current_stream())
+        self.pairs.append((a, b))
+        self.flops += flops
+
+    def result(self):
+        torch.cuda.synchronize()
+        ms = sum(a.elapsed_time(b) for a, b in self.pairs)
+        return ms, len(self.pairs), self.flops
+
+
+def roofline_leg(trainer, item, steps):
+    """Re-run `steps` steps eagerly with events bracketing every launch of the dominant kernel
+    (the bf16 128x128 row-gather GEMM: conv / deconv forward and input gradients)."""
+    eng = trainer.eng
+    timer = KernelTimer()
+    orig = eng._gemm
+
+    def timed(A, W, out, bias, gate, mask, nimg, ih, iw, th, tw, sa, oh, ow, so, kc, nout, lda, ldo, taps, cls_key, **kw):
+        if nout <= 64:                       # other template instance (64-wide tile): not the dominant kernel
+            return orig(A, W, out, bias, gate, mask, nimg, ih, iw, th, tw, sa, oh, ow, so, kc, nout, lda, ldo, taps,
+                        cls_key, **kw)
+        if cls_key == "dgrad":               # 4 parity classes share the k*k taps: k*k/4 taps per output pixel
+            rows, t_eff = nimg * th * tw * 4, taps / 4.0
+        else:
+            rows, t_eff = nimg * th * tw, float(taps)
+        flops = 2.0 * rows * nout * kc * t_eff
+        with timer(flops):
+            return orig(A, W, out, bias, gate, mask, nimg, ih, iw, th, tw, sa, oh, ow, so, kc, nout, lda, ldo, taps,
+                        cls_key, **kw)
+
+    eng._gemm = timed
+    trainer.instrument = True
+    try:
+        for _ in range(steps):
+            trainer.step(item, TAU)
+        ms, launches, flops = timer.result()
+    finally:
+        eng._gemm = orig
+        trainer.instrument = None
+    return ms, launches, flops
+
+
+def cpu_baseline(seconds_budget=20.0):
+    """The oracle (plain-torch restatement pinned to the reference by tests/golden) on this host's cores."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import rbvae_oracle as O
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    p = O.init_params("percep", C_IN, C_IN, LATENT, HW, seed=1234)
+    for v in p.values():
+        v.requires_grad_()
+    g = torch.Generator().manual_seed(1234)
+    Bc = 4                                           # bounded sample: 4 items = 64 frames per step
+    item = torch.randn(Bc, 2, T_STATES, C_IN, *HW, generator=g)
+    times = []
+    t_start = time.perf_counter()
+    state = {}
+    step = 0
+    while True:
+        U = [torch.rand(Bc * T_STATES, LATENT), torch.rand(Bc * T_STATES, LATENT)]
+        t0 = time.perf_counter()
+        res = O.step_losses("percep", p, item, U, TAU, NOISE_R, BERN_P, ALPHA, BETA, train=True)
+        for v in p.values():
+            v.grad = None
+        res["total"].backward()
+        step += 1
+        with torch.no_grad():
+            O.adam_step({k: v for k, v in p.items()}, {k: v.grad for k, v in p.items()}, state, 1e-3, step)
+        times.append(time.perf_counter() - t0)
+        if len(times) >= 4 and time.perf_counter() - t_start > seconds_budget or len(times) >= 40:
+            break
+    times = times[1:]                                # first step warms the allocator / oneDNN primitives
+    frames = Bc * 2 * T_STATES
+    return {"value": round(frames / (sum(times) / len(times)), 2), "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": f"{len(times)} steps of {frames} frames (item [{Bc},2,{T_STATES},{C_IN},{HW[0]},{HW[1]}]), "
+                      f"fwd+bwd+Adam, torch {torch.__version__} CPU, {cores} threads"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    args = ap.parse_args()
+
+    import sfv_amd as sfv
+    from importlib import import_module
+    ddp = import_module("symbols-from-video_amd.ddp")
+    trainer_mod = import_module("symbols-from-video_amd.trainer")
+    rank, world, local = ddp.init_from_env("nccl")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    torch.manual_seed(1234)                          # identical initial weights on every rank
+    model = sfv.Seq2SeqBinaryVAE(C_IN, C_IN, LATENT, LATENT, variant="percep", input_hw=HW,
+                                 compute_dtype=args.dtype).to(dev).train()
+    ddp.broadcast_(model._flat)
+    g = torch.Generator(device="cpu").manual_seed(1234 + rank)          # per-rank shard of the global batch
+    item = torch.randn(B_ITEMS, 2, T_STATES, C_IN, *HW, generator=g).to(dev)
+    tr = trainer_mod.FusedTrainer(model, lr=1e-3, alpha=ALPHA, beta_kl=BETA, bernoulli_p=BERN_P, noise_ratio=NOISE_R,
+                                  device_noise=True, use_graph=not args.no_graph)
+    frames_per_step = B_ITEMS * 2 * T_STATES
+
+    for _ in range(args.warmup):
+        tr.step(item, TAU)
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        tr.step(item, TAU)
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    dt = time.perf_counter() - t0
+    t = torch.tensor([dt], device=dev)
+    if world > 1:
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+    dt = float(t.item())
+    losses = [float(v) for v in tr.losses.tolist()]
+
+    roof = None
+    cpu = None
+    if rank == 0:
+        ms, launches, flops = roofline_leg(tr, item, min(args.steps, 20))
+        achieved = flops / (ms * 1e-3) / 1e12
+        roof = {"bound": "mfma", "kernel": "gather_gemm_k<bf16,4>" if args.dtype == "bf16" else "gather_gemm_k<f32,4>",
+                "achieved": round(achieved, 2), "peak": MFMA_BF16_PEAK_TFLOPS if args.dtype == "bf16" else 157.3,
+                "unit": "TFLOP/s", "frac": round(achieved / (MFMA_BF16_PEAK_TFLOPS if args.dtype == "bf16" else 157.3), 4),
+                "traffic": None, "launches": launches, "avg_us": round(ms * 1e3 / max(launches, 1), 2)}
+        if world == 1 and not args.no_cpu:
+            cpu = cpu_baseline()
+    if world > 1:
+        torch.distributed.barrier()
+    if rank == 0:
+        value = frames_per_step * world * args.steps / dt
+        line = {"metric": "frames/sec (enc+binarise+dec fwd+bwd), batch 256x256, 1/2/4/8 MI355X",
+                "value": round(value, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
+                "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True,
+                "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+                "config": {"workload": "percep_RBVAE fused train step (fwd+bwd+losses+Adam), item [16,2,8,4,32,32] "
+                                       "per GPU = 256 frames/step/GPU (latents of 256x256 frames), latent 32, "
+                                       "4-layer LSTMs, dropout on",
+                           "frames_per_step_per_gpu": frames_per_step, "global_frames_per_step": frames_per_step * world,
+                           "parallelism": f"dp{world}", "graph": not args.no_graph,
+                           "last_losses": {"total": losses[0], "recon": losses[1], "kl": losses[2], "pair": losses[3]}},
+                "roofline": roof, "cpu_baseline": cpu}
+        print(json.dumps(line))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -39,6 +39,8 @@ extern "C" {
 #define RBVAE_BF16 1
 
 int rbvae_version(void);
+/* counter[0] += inc: the device step counter the dropout / noise hashes mix in (graph replay safe). */
+int rbvae_counter_add(unsigned long long* counter, unsigned long long inc, void* stream);
 const char* rbvae_last_error(void);
 
 /* ---- binarise + KL -------------------------------------------------------
@@ -51,10 +53,12 @@ const char* rbvae_last_error(void);
  *   y_soft = sigmoid((h + r*(log(U+e) - log(1-U+e))) / tau)
  *   z      = hard ? (y_soft > 0.5) : y_soft
  *   kl_mean[0] = mean_rows sum_L KL(clamp(sigmoid(z)) || Bernoulli(p))
- * kl_mean may be NULL (encode path). */
+ * kl_mean may be NULL (encode path).  U may be NULL: the kernel then draws 24-bit uniforms from a
+ * counter hash of (seed + *seed_dev, element index) -- device-side noise for the fused trainer. */
 int rbvae_binarize_kl_fwd(const float* h, const float* U, float* y_soft, float* z, float* kl_mean,
                           int rows, int L, float tau, float noise_ratio, float noise_eps, int hard,
-                          float kl_p, float kl_eps, int kl_clamp, void* stream);
+                          float kl_p, float kl_eps, int kl_clamp, unsigned long long seed,
+                          const unsigned long long* seed_dev, void* stream);
 /* dh (+)= (g_z + kl_weight * gscale * dKL/dz) * y_soft*(1-y_soft)/tau (straight-through when hard).
  * g_z may be NULL; gscale_dev (device scalar, may be NULL = 1) multiplies kl_weight. */
 int rbvae_binarize_kl_bwd(const float* g_z, const float* y_soft, const float* z, float* dh, int accumulate,
@@ -118,7 +122,7 @@ int rbvae_gather_gemm(int dtype, const void* A, const void* W, void* Out, const 
                       const void* mask, const void* zero_page, int Nimg, int IH, int IW, int TH, int TW, int sa,
                       int OH, int OW, int so, int Kc, int Nout, int lda, int ldo, int taps_total, int nclass,
                       const int* class_desc, int relu, int drop_mode, float drop_p, float scale,
-                      unsigned long long seed, void* stream);
+                      unsigned long long seed, const unsigned long long* seed_dev, void* stream);
 
 /* ---- weight-gradient GEMM ---------------------------------------------------------
  * dW[ks][co][t][ci] = sum over K-slice ks of Dy[p][co] * In[idx[t][p]][ci]  (f32 slabs, one per
@@ -177,9 +181,12 @@ int rbvae_lstm_bwd(const float* wblk, const float* acts, const float* cs, const 
 int rbvae_lstm_wgrad(const float* dG, const float* hs_all, const float* hprev, float* gblk, int S, int T, int L,
                      int layers, int accumulate, void* stream);
 
-/* torch.optim.Adam defaults (percep_RBVAE_train.py:753,553) on a flat f32 buffer; g is scaled by gscale first. */
+/* torch.optim.Adam defaults (percep_RBVAE_train.py:753,553) on a flat f32 buffer; g is scaled by gscale
+ * first.  The step number comes from `step` or, when step_dev != NULL, from a device counter (then
+ * hyper_ws, 2 floats, receives the bias-correction terms): graph-replay safe. */
 int rbvae_adam_step(float* w, const float* g, float* m, float* v, long n, double lr, double beta1, double beta2,
-                    double eps, int step, float gscale, void* stream);
+                    double eps, int step, float gscale, const unsigned long long* step_dev, float* hyper_ws,
+                    void* stream);
 
 /* ---- hardware-map probes (diagnostics; tests/test_hw_maps.py) ------------------
  * One-wave kernels that pin the gfx950 lane maps the GEMM kernels assume. */

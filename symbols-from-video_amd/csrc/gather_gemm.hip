@@ -53,6 +53,7 @@ struct GgArgs {
     float scale;               // applied after bias/relu (dropout 1/(1-p) or gate scale)
     unsigned drop_thresh;      // keep iff hash >= thresh
     unsigned long long seed;
+    const unsigned long long* seed_dev;   // optional device step counter mixed into seed
     int nclass;
     TapClass cls[4];
 };
@@ -267,10 +268,11 @@ __global__ __launch_bounds__(256, 2) void gather_gemm_k(const GgArgs p) {
         u32x4_t val = *(const u32x4_t*)(tile + row * PITCH + ch * 16);
         T* ev = (T*)&val;
         if (p.drop_mode == 1) {
+            const unsigned long long sd = p.seed + (p.seed_dev ? p.seed_dev[0] * 0x9E3779B97F4A7C15ull : 0ull);
             const unsigned long long base = (unsigned long long)orow * p.Nout + col;
 #pragma unroll
             for (int e = 0; e < EC; ++e)
-                if (hash_u32(p.seed, base + e) < p.drop_thresh) ev[e] = 0;
+                if (hash_u32(sd, base + e) < p.drop_thresh) ev[e] = 0;
         } else if (p.drop_mode == 2) {
             const unsigned char* mk = p.mask + (size_t)orow * p.Nout + col;
 #pragma unroll
@@ -315,7 +317,8 @@ extern "C" int rbvae_gather_gemm(int dtype, const void* A, const void* W, void* 
                                  const void* gate, const void* mask, const void* zero_page, int Nimg, int IH,
                                  int IW, int TH, int TW, int sa, int OH, int OW, int so, int Kc, int Nout, int lda,
                                  int ldo, int taps_total, int nclass, const int* class_desc, int relu,
-                                 int drop_mode, float drop_p, float scale, unsigned long long seed, void* stream) {
+                                 int drop_mode, float drop_p, float scale, unsigned long long seed,
+                                 const unsigned long long* seed_dev, void* stream) {
     RBVAE_CHECK_ARG(A && W && Out && zero_page && class_desc, "gather_gemm: null pointer");
     RBVAE_CHECK_ARG(dtype == RBVAE_F32 || dtype == RBVAE_BF16, "gather_gemm: dtype %d", dtype);
     const int ES = dtype == RBVAE_F32 ? 4 : 2;
@@ -337,7 +340,7 @@ extern "C" int rbvae_gather_gemm(int dtype, const void* A, const void* W, void* 
     a.zero = (const unsigned char*)zero_page;
     a.Nimg = Nimg; a.IH = IH; a.IW = IW; a.TH = TH; a.TW = TW; a.sa = sa; a.OH = OH; a.OW = OW; a.so = so;
     a.Kc = Kc; a.Nout = Nout; a.lda = lda; a.ldo = ldo; a.taps_total = taps_total;
-    a.relu = relu; a.drop_mode = drop_mode; a.scale = scale; a.seed = seed;
+    a.relu = relu; a.drop_mode = drop_mode; a.scale = scale; a.seed = seed; a.seed_dev = seed_dev;
     a.drop_thresh = (unsigned)((double)drop_p * 4294967296.0);
     a.nclass = nclass;
     // class_desc (host ints): per class [ntaps, oh0, ow0, then ntaps x (widx, dh, dw)], classes back to back

@@ -223,7 +223,8 @@ __global__ __launch_bounds__(512) void skinny_linear_k(const T* __restrict__ A, 
 // denom = sqrt(v)/sqrt(bc2) + eps; w += -(lr/bc1) * (m/denom).
 __global__ void adam_k(float* __restrict__ w, const float* __restrict__ g, float* __restrict__ m,
                        float* __restrict__ v, long n, float step_size, float one_m_b1, float b2, float one_m_b2,
-                       float eps, float bc2_sqrt, float gscale) {
+                       float eps, float bc2_sqrt, float gscale, const float* __restrict__ hyper) {
+    if (hyper) { step_size = hyper[0]; bc2_sqrt = hyper[1]; }
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
         const float gi = g[i] * gscale;
         const float m0 = m[i];
@@ -383,14 +384,30 @@ int rbvae_skinny_linear(int dtype, const void* A, const void* B, const float* bi
     return RBVAE_OK;
 }
 
+// hyper[0] = lr / (1 - b1^step), hyper[1] = sqrt(1 - b2^step) from a DEVICE step counter
+__global__ void adam_hyper_k(const unsigned long long* __restrict__ step_dev, double lr, double b1, double b2,
+                             float* __restrict__ hyper) {
+    const double st = (double)step_dev[0];
+    hyper[0] = (float)(lr / (1.0 - pow(b1, st)));
+    hyper[1] = (float)sqrt(1.0 - pow(b2, st));
+}
+
 int rbvae_adam_step(float* w, const float* g, float* m, float* v, long n, double lr, double beta1, double beta2,
-                    double eps, int step, float gscale, void* stream) {
-    RBVAE_CHECK_ARG(w && g && m && v && n > 0 && step >= 1, "adam_step: bad arguments");
-    const double bc1 = 1.0 - pow(beta1, (double)step);
-    const double bc2 = 1.0 - pow(beta2, (double)step);
+                    double eps, int step, float gscale, const unsigned long long* step_dev, float* hyper_ws,
+                    void* stream) {
+    RBVAE_CHECK_ARG(w && g && m && v && n > 0, "adam_step: bad arguments");
+    RBVAE_CHECK_ARG(step_dev ? hyper_ws != nullptr : step >= 1, "adam_step: needs step >= 1 or step_dev + hyper_ws");
+    double bc1 = 1.0, bc2 = 1.0;
+    if (step_dev) {
+        hipLaunchKernelGGL(adam_hyper_k, dim3(1), dim3(1), 0, (hipStream_t)stream, step_dev, lr, beta1, beta2,
+                           hyper_ws);
+    } else {
+        bc1 = 1.0 - pow(beta1, (double)step);
+        bc2 = 1.0 - pow(beta2, (double)step);
+    }
     hipLaunchKernelGGL(adam_k, dim3(grid_for(n, 256, 2048)), dim3(256), 0, (hipStream_t)stream, w, g, m, v, n,
                        (float)(lr / bc1), (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps,
-                       (float)sqrt(bc2), gscale);
+                       (float)sqrt(bc2), gscale, step_dev ? hyper_ws : (const float*)nullptr);
     RBVAE_CHECK_LAUNCH("adam_step");
     return RBVAE_OK;
 }

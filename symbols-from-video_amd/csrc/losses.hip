@@ -40,12 +40,15 @@ __device__ __forceinline__ float kl_elem_grad(float v, float lp, float l1p, floa
 __global__ __launch_bounds__(RED_THREADS) void binarize_kl_fwd_k(
     const float* __restrict__ h, const float* __restrict__ U, float* __restrict__ y_soft,
     float* __restrict__ z, float* __restrict__ kl_mean, int rows, int L, float tau, float ratio,
-    float neps, int hard, float lp, float l1p, float keps, int clamp) {
+    float neps, int hard, float lp, float l1p, float keps, int clamp, unsigned long long seed,
+    const unsigned long long* __restrict__ seed_dev) {
     __shared__ float red[RED_THREADS / 64];
     const int n = rows * L;
     float acc = 0.f;
+    if (seed_dev) seed += seed_dev[0] * 0x9E3779B97F4A7C15ull;
     for (int i = threadIdx.x; i < n; i += RED_THREADS) {
-        const float u = U[i];
+        // U == null: 24-bit uniform in [0,1) from the counter hash (device-side noise)
+        const float u = U ? U[i] : (float)(hash_u32(seed, (unsigned long long)i) >> 8) * (1.0f / 16777216.0f);
         const float noise = ratio * (logf(u + neps) - logf(1.0f - u + neps));
         const float y = sigmoidf_((h[i] + noise) / tau);
         const float zz = hard ? (y > 0.5f ? 1.0f : 0.0f) : y;
@@ -350,18 +353,27 @@ using namespace rbvae;
 
 extern "C" {
 
-int rbvae_version(void) { return 100; }
+int rbvae_version(void) { return 101; }
+
+__global__ void counter_add_k(unsigned long long* c, unsigned long long inc) { c[0] += inc; }
+int rbvae_counter_add(unsigned long long* counter, unsigned long long inc, void* stream) {
+    RBVAE_CHECK_ARG(counter, "counter_add: null pointer");
+    hipLaunchKernelGGL(counter_add_k, dim3(1), dim3(1), 0, (hipStream_t)stream, counter, inc);
+    RBVAE_CHECK_LAUNCH("counter_add");
+    return RBVAE_OK;
+}
 const char* rbvae_last_error(void) { return err_buf(); }
 
 int rbvae_binarize_kl_fwd(const float* h, const float* U, float* y_soft, float* z, float* kl_mean, int rows,
                           int L, float tau, float noise_ratio, float noise_eps, int hard, float kl_p,
-                          float kl_eps, int kl_clamp, void* stream) {
-    RBVAE_CHECK_ARG(h && U && y_soft && z, "binarize_kl_fwd: null pointer");
+                          float kl_eps, int kl_clamp, unsigned long long seed, const unsigned long long* seed_dev,
+                          void* stream) {
+    RBVAE_CHECK_ARG(h && y_soft && z, "binarize_kl_fwd: null pointer");
     RBVAE_CHECK_ARG(rows > 0 && L > 0 && tau > 0.f, "binarize_kl_fwd: rows=%d L=%d tau=%g", rows, L, tau);
     RBVAE_CHECK_ARG(kl_p > 0.f && kl_p < 1.f, "binarize_kl_fwd: p=%g outside (0,1)", kl_p);
     hipLaunchKernelGGL(binarize_kl_fwd_k, dim3(1), dim3(RED_THREADS), 0, (hipStream_t)stream, h, U, y_soft, z,
                        kl_mean, rows, L, tau, noise_ratio, noise_eps, hard, logf(kl_p), logf(1.0f - kl_p),
-                       kl_eps, kl_clamp);
+                       kl_eps, kl_clamp, seed, seed_dev);
     RBVAE_CHECK_LAUNCH("binarize_kl_fwd");
     return RBVAE_OK;
 }

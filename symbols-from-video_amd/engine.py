@@ -183,6 +183,7 @@ class Engine:
         self._cls_dgrad, self._ncls_dgrad = dgrad_classes(k)
         self._desc_cache: Dict[Tuple, object] = {}
         self._idx_cache: Dict[Tuple, torch.Tensor] = {}
+        self.seed_dev = None           # optional device step counter (int64 tensor) for graph-replayed steps
         self._alloc_packed()
 
     # ---- packed weights -------------------------------------------------------
@@ -242,6 +243,7 @@ class Engine:
 
     def _gemm(self, A, W, out, bias, gate, mask, nimg, ih, iw, th, tw, sa, oh, ow, so, kc, nout, lda, ldo, taps,
               cls_key, relu=0, drop_mode=0, drop_p=0.0, scale=1.0, seed=0):
+        seed_dev = self.seed_dev
         if cls_key == "one":
             desc, ncls = self._desc("one", ONE_TAP), 1
         elif cls_key == "conv":
@@ -251,7 +253,7 @@ class Engine:
         import ctypes
         L.call("rbvae_gather_gemm", self.dt, A, W, out, bias, gate, mask, self.zero, nimg, ih, iw, th, tw, sa, oh, ow,
                so, kc, nout, lda, ldo, taps, ncls, ctypes.addressof(desc), relu, drop_mode, float(drop_p),
-               float(scale), int(seed))
+               float(scale), int(seed), seed_dev)
 
     def _conv_idx(self, nimg, ih, iw, oh, ow):
         key = (nimg, ih, iw, oh, ow)
@@ -352,14 +354,14 @@ class Engine:
             hs = sv.hs_enc[nl]
             sv.z = sv.hs_dec[0].view(N, Ld)
             L.call("rbvae_binarize_kl_fwd", hs, U, sv.y, sv.z, kl, N, Ld, float(tau), float(r), v.eps, int(hard),
-                   float(kl_p if kl_p is not None else 0.5), 1e-8, 1)
+                   float(kl_p if kl_p is not None else 0.5), 1e-8, 1, int(seed) * 8 + 5, self.seed_dev)
             if encode_only:
                 return {"z": sv.z.view(S, T, Ld), "hs": hs, "saved": sv}
             L.call("rbvae_lstm_fwd", wdec, sv.hs_dec, sv.hp_dec, sv.acts_dec, sv.cs_dec, S, T, Ld, nl)
         else:
             sv.z = sv.hs_enc[0].view(N, Ld)
             L.call("rbvae_binarize_kl_fwd", sv.e, U, sv.y, sv.z, None, N, Ld, float(tau), float(r), v.eps, int(hard),
-                   0.5, 1e-10, 0)
+                   0.5, 1e-10, 0, int(seed) * 8 + 5, self.seed_dev)
             L.call("rbvae_lstm_fwd", wenc, sv.hs_enc, sv.hp_enc, sv.acts_enc, sv.cs_enc, S, T, Ld, nl)
             hs = sv.hs_enc[nl]
             sv.hs_dec[0].copy_(hs)

@@ -48,7 +48,7 @@ class _BinarizeFn(torch.autograd.Function):
         y = torch.empty_like(h)
         z = torch.empty_like(h)
         L.call("rbvae_binarize_kl_fwd", h, u, y, z, None, h.shape[0], h.shape[1], float(temperature),
-               float(noise_ratio), float(eps), int(bool(hard)), 0.5, 1e-8, 1)
+               float(noise_ratio), float(eps), int(bool(hard)), 0.5, 1e-8, 1, 0, None)
         ctx.save_for_backward(y, z)
         ctx.tau = float(temperature)
         return z.reshape(shape)

@@ -1,0 +1,158 @@
+"""Fused training step of the RBVAE path: the reference trainer's inner loop
+(models/percep_RBVAE/percep_RBVAE_train.py:509-553; triplet variant
+models/triplet_RBVAE/triplet_RBVAE_train.py:443-478) as one hand-scheduled pass.
+
+  item [B,2,T,C,H,W] -> both views through the model as 2B sequences in ONE forward
+  (the model has no cross-item op, so this equals the reference's two calls),
+  recon MSE + its gradient fused into the last deconv kernel, KL fused into the
+  binarise kernel, the pairwise term in one launch, hand-scheduled backward,
+  gradient all-reduce (RCCL) when world_size > 1, fused Adam on the flat buffer.
+
+The step is captured into HIP graphs (forward+backward; Adam+repack) so a step costs
+two graph launches and, across ranks, one all-reduce between them.
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional
+
+import torch
+
+from . import _lib as L
+from .engine import VARIANTS
+
+
+class FusedTrainer:
+    def __init__(self, model, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, alpha=0.1, beta_kl=0.1, bernoulli_p=0.5,
+                 noise_ratio=0.1, margin=1.0, device_noise=True, use_graph=True, process_group=None):
+        self.model = model
+        self.v = VARIANTS[model.variant]
+        if self.v.simple_order:
+            raise ValueError("FusedTrainer covers the percep / contrastive / triplet trainers")
+        self.lr, self.betas, self.eps = lr, betas, eps
+        self.alpha, self.beta_kl, self.p, self.r, self.margin = alpha, beta_kl, bernoulli_p, noise_ratio, margin
+        self.device_noise = device_noise
+        self.use_graph = use_graph
+        self.pg = process_group
+        self.world = 1
+        if process_group is not None or (torch.distributed.is_available() and torch.distributed.is_initialized()):
+            self.world = torch.distributed.get_world_size(process_group)
+        dev = model._flat.device
+        if dev.type != "cuda":
+            raise RuntimeError("FusedTrainer: move the model to the GPU first (there is no CPU fallback)")
+        self.dev = dev
+        n = model._flat.numel()
+        self.gflat = torch.zeros(n, device=dev)
+        self.m = torch.zeros(n, device=dev)
+        self.vv = torch.zeros(n, device=dev)
+        self.step_dev = torch.zeros(1, dtype=torch.int64, device=dev)       # device step counter
+        self.hyper = torch.zeros(2, device=dev)
+        self.losses = torch.zeros(4, device=dev)                               # total, recon, kl, pair
+        self.steps = 0
+        self._graphs: Dict = {}
+        self._static: Dict = {}
+        self.eng = None
+        self.instrument = None       # optional callable(name, flops) -> context manager (bench roofline leg)
+
+    # ---- the two halves of a step (plain launches; captured below) ------------------
+    def _fwd_bwd(self, x, U, tau, B, T):
+        eng, model = self.eng, self.model
+        L.call("rbvae_counter_add", self.step_dev, 1)
+        numel = x.numel()
+        out = eng.forward(model._flat, x, U, tau, False, self.r, True, None, seed=0, need_grad=True, target=x,
+                          recon_gscale=2.0 / numel, kl_p=self.p)
+        hs = out["hs"]                       # [2B, T, L]
+        Ld = hs.shape[-1]
+        h0, h1 = hs[:B], hs[B:]
+        pair = self.losses[3:4]
+        g_hs = torch.empty_like(hs)
+        if self.model.variant == "triplet":
+            L.call("rbvae_triplet_term_fwd", h0, h1, B, T, Ld, float(self.margin), pair)
+            L.call("rbvae_triplet_term_bwd", h0, h1, B, T, Ld, float(self.margin), float(self.alpha), None,
+                   g_hs[:B], g_hs[B:])
+        else:
+            L.call("rbvae_contrast_term_fwd", h0, h1, B, T, Ld, pair)
+            L.call("rbvae_contrast_term_bwd", h0, h1, B, T, Ld, float(self.alpha), None, g_hs[:B], g_hs[B:])
+        eng.backward(model._flat, self.gflat, out["saved"], None, g_hs, None, kl_weight=self.beta_kl, kl_p=self.p)
+        self.losses[1:2].copy_(out["mse"])
+        self.losses[2:3].copy_(out["kl"])
+        torch.add(out["mse"], out["kl"], alpha=self.beta_kl, out=self.losses[0:1])
+        self.losses[0:1].add_(pair, alpha=self.alpha)
+
+    def _update(self):
+        b1, b2 = self.betas
+        L.call("rbvae_adam_step", self.model._flat, self.gflat, self.m, self.vv, self.gflat.numel(), float(self.lr),
+               float(b1), float(b2), float(self.eps), 1, 1.0 / self.world, self.step_dev, self.hyper)
+        self.eng.pack(self.model._flat)
+
+    # ---- public --------------------------------------------------------------------
+    def step(self, item: torch.Tensor, temperature: float, U: Optional[torch.Tensor] = None):
+        """One optimiser step on item [B,2,T,C,H,W] (device tensor).  U: optional [2, B*T, L] uniform
+        noise (view 0, view 1) -- default: device-side counter-hash noise (device_noise=True) or a host
+        torch.rand draw like the reference (device_noise=False).  Returns the device tensor
+        [total, recon, kl, pair] of this step (no host sync)."""
+        if item.dim() != 6 or item.shape[1] != 2:
+            raise ValueError(f"expected item of shape [B, 2, T, C, H, W], got {tuple(item.shape)}")
+        B, _, T, C, H, W = item.shape
+        if T < 2:
+            raise ZeroDivisionError("float division by zero")      # the reference's failure for one state
+        model = self.model
+        if self.eng is None:
+            self.eng = model._engine_for(item)
+            self.eng.seed_dev = self.step_dev
+            self.eng.pack(model._flat)
+        Ld = model.latent_dim
+        if U is None and not self.device_noise:
+            U = torch.rand((2, B * T, Ld)).to(item.device)
+        key = (B, T, float(temperature), U is not None)
+        st = self._static.get(key[:2])
+        if st is None:
+            st = {"x": torch.empty(2 * B, T, C, H, W, device=self.dev),
+                  "U": torch.empty(2 * B * T, Ld, device=self.dev)}
+            self._static[key[:2]] = st
+        st["x"].view(2, B, T, C, H, W).copy_(item.transpose(0, 1))
+        if U is not None:
+            st["U"].copy_(U.reshape(2 * B * T, Ld))
+        Uarg = st["U"] if U is not None else None
+        if not self.use_graph or self.instrument is not None:
+            self._fwd_bwd(st["x"], Uarg, float(temperature), B, T)
+            self._allreduce()
+            self._update()
+        else:
+            g = self._graphs.get(key)
+            if g is None:
+                g = self._capture(st["x"], Uarg, float(temperature), B, T)
+                self._graphs[key] = g
+            g[0].replay()
+            self._allreduce()
+            g[1].replay()
+        self.steps += 1
+        return self.losses
+
+    def _allreduce(self):
+        if self.world > 1:
+            torch.distributed.all_reduce(self.gflat, group=self.pg)
+
+    def _capture(self, x, U, tau, B, T):
+        # two eager warm-up steps on a side stream (allocator + lazy kernel attributes), then capture.
+        # The warm-ups are real optimiser steps; their effect on the counters is rolled back.
+        flat0, m0, v0, s0 = self.model._flat.clone(), self.m.clone(), self.vv.clone(), self.step_dev.clone()
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            for _ in range(2):
+                self._fwd_bwd(x, U, tau, B, T)
+                self._update()
+        torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize()
+        g1, g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g1):
+            self._fwd_bwd(x, U, tau, B, T)
+        with torch.cuda.graph(g2, pool=g1.pool()):
+            self._update()
+        self.model._flat.copy_(flat0)
+        self.m.copy_(m0)
+        self.vv.copy_(v0)
+        self.step_dev.copy_(s0)
+        self.eng.pack(self.model._flat)
+        torch.cuda.synchronize()
+        return g1, g2

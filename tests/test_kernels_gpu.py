@@ -38,7 +38,7 @@ def gemm(sfv, dt, A, Wp, out, bias, gate, mask, geom, kc, nout, taps, desc, ncls
     zero = torch.zeros(256, dtype=torch.uint8, device="cuda")
     d = (ctypes.c_int * len(desc))(*desc)
     sfv._lib.call("rbvae_gather_gemm", dt, A, Wp, out, bias, gate, mask, zero, *geom, kc, nout, A.shape[1],
-                  out.shape[1], taps, ncls, ctypes.addressof(d), relu, drop_mode, drop_p, scale, seed)
+                  out.shape[1], taps, ncls, ctypes.addressof(d), relu, drop_mode, drop_p, scale, seed, None)
 
 
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
@@ -217,5 +217,5 @@ def test_adam_matches_torch(sfv):
         gr = torch.randn(n, generator=g) * 10 ** float(torch.randint(-6, 1, (1,), generator=g))
         p.grad = gr.clone()
         opt.step()
-        sfv._lib.call("rbvae_adam_step", wd, gr.cuda(), m, v, n, 1e-3, 0.9, 0.999, 1e-8, step, 1.0)
+        sfv._lib.call("rbvae_adam_step", wd, gr.cuda(), m, v, n, 1e-3, 0.9, 0.999, 1e-8, step, 1.0, None, None)
         np.testing.assert_allclose(wd.cpu().numpy(), p.detach().numpy(), atol=2e-7, rtol=0)

@@ -27,7 +27,7 @@ def test_binarize_codes_vs_reference_fixture(L):
         h, U = dev(g[f"bin/{i}/logits"]), dev(g[f"bin/{i}/U"])
         y, z = torch.empty_like(h), torch.empty_like(h)
         L.call("rbvae_binarize_kl_fwd", h, U, y, z, None, h.shape[0], h.shape[1], tau, r, eps, int(hard),
-               0.5, 1e-8, 1)
+               0.5, 1e-8, 1, 0, None)
         ref = g[f"bin/{i}/y"]
         if hard:
             # codes are bit-exact wherever the pre-activation is not within rounding of 0
@@ -72,7 +72,7 @@ def test_binarize_kl_fused_bwd(L):
         loss = (z * gz).sum() + 0.3 * O.kl_binary_concrete(z.reshape(4, 6, Ld), 0.1)
         (gh,) = torch.autograd.grad(loss, h)
         y, zd, kl = torch.empty(rows, Ld, device="cuda"), torch.empty(rows, Ld, device="cuda"), torch.empty(1, device="cuda")
-        L.call("rbvae_binarize_kl_fwd", h.detach().cuda(), U.cuda(), y, zd, kl, rows, Ld, tau, r, 1e-8, hard, 0.1, 1e-8, 1)
+        L.call("rbvae_binarize_kl_fwd", h.detach().cuda(), U.cuda(), y, zd, kl, rows, Ld, tau, r, 1e-8, hard, 0.1, 1e-8, 1, 0, None)
         assert abs(kl.item() - O.kl_binary_concrete(z.detach(), 0.1).item()) < 1e-5
         dh = torch.full((rows, Ld), 7.0, device="cuda")
         L.call("rbvae_binarize_kl_bwd", gz.cuda(), y, zd, dh, 0, rows, Ld, tau, 0.3, None, 0.1, 1e-8, 1)
