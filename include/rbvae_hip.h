@@ -117,12 +117,15 @@ int rbvae_mse_bwd(const float* a, const float* b, long n, float scale, const flo
  *   class_desc is a HOST int array: per class [ntaps, oh0, ow0, ntaps x (widx, dh, dw)].
  *   epilogue: +bias, relu, *scale, dropout (drop_mode 1: counter hash of (seed, element index),
  *   2: explicit u8 keep-mask [rows][Nout]), then zero where gate <= 0 (saved activation:
- *   ReLU/dropout backward).  zero_page: >= 128 zero bytes.  Kc % (128/sizeof T) == 0, Nout % 8 == 0. */
+ *   ReLU/dropout backward).  zero_page: >= 128 zero bytes.  Kc % (128/sizeof T) == 0, Nout % 8 == 0.
+ *   colsum_ws (optional, [nclass * ceil(rows/128)][Nout] f32): per-tile column sums of the stored
+ *   values -- the bias gradient, finished by rbvae_reduce_rows. */
 int rbvae_gather_gemm(int dtype, const void* A, const void* W, void* Out, const float* bias, const void* gate,
                       const void* mask, const void* zero_page, int Nimg, int IH, int IW, int TH, int TW, int sa,
                       int OH, int OW, int so, int Kc, int Nout, int lda, int ldo, int taps_total, int nclass,
                       const int* class_desc, int relu, int drop_mode, float drop_p, float scale,
-                      unsigned long long seed, const unsigned long long* seed_dev, void* stream);
+                      unsigned long long seed, const unsigned long long* seed_dev, float* colsum_ws,
+                      void* stream);
 
 /* ---- weight-gradient GEMM ---------------------------------------------------------
  * dW[ks][co][t][ci] = sum over K-slice ks of Dy[p][co] * In[idx[t][p]][ci]  (f32 slabs, one per
@@ -145,6 +148,7 @@ int rbvae_pack3(int dtype, const float* in, void* out, int d0, int d1, int d2, l
 int rbvae_permute_reduce(const float* in, int nslab, long slab_stride, float* out, int d0, int d1, int d2, long s0,
                          long s1, long s2, float scale, int accumulate, void* stream);
 int rbvae_cast_pad(int dtype, const float* in, void* out, int rows, int L, int Lpad, void* stream);
+int rbvae_reduce_rows(const float* ws, int rows, int C, float* out, float scale, int accumulate, void* stream);
 size_t rbvae_colsum_ws_floats(int P, int C);
 int rbvae_colsum(int dtype, const void* X, int P, int C, int ld, float* out, float* ws, float scale, int accumulate,
                  void* stream);

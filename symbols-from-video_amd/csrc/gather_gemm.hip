@@ -54,6 +54,7 @@ struct GgArgs {
     unsigned drop_thresh;      // keep iff hash >= thresh
     unsigned long long seed;
     const unsigned long long* seed_dev;   // optional device step counter mixed into seed
+    float* colsum_ws;          // optional [nclass * m-tiles][Nout]: per-tile column sums of the stored values
     int nclass;
     TapClass cls[4];
 };
@@ -260,8 +261,11 @@ __global__ __launch_bounds__(256, 2) void gather_gemm_k(const GgArgs p) {
 
     // ---- store phase: whole 16-B chunks of NHWC rows; dropout / gate zeroing happens here
     constexpr int CPR = BN / EC;
+    float csum[EC];
+#pragma unroll
+    for (int e = 0; e < EC; ++e) csum[e] = 0.f;
     for (int idx = tid; idx < GG_BM * CPR; idx += 256) {
-        const int row = idx / CPR, ch = idx - row * CPR;
+        const int row = idx / CPR, ch = idx - row * CPR;     // ch == tid % CPR on every pass
         const int orow = s_orow[row];
         const int col = n0 + ch * EC;
         if (orow < 0 || col >= p.Nout) continue;
@@ -287,6 +291,25 @@ __global__ __launch_bounds__(256, 2) void gather_gemm_k(const GgArgs p) {
                 if (!elem_pos<T>((const unsigned char*)&gv, e)) ev[e] = 0;
         }
         *(u32x4_t*)(p.Out + ((size_t)orow * p.ldo + col) * ES) = val;
+        if (p.colsum_ws) {
+#pragma unroll
+            for (int e = 0; e < EC; ++e) csum[e] += Elem<T>::load(ev + e);
+        }
+    }
+    if (p.colsum_ws) {
+        // bias gradient: column sums of this tile's stored rows, reduced over the 256/CPR row lanes in LDS
+        __syncthreads();
+        float* red = (float*)smem;                     // [256/CPR][BN]
+        const int rl = tid / CPR, ch = tid - rl * CPR;
+#pragma unroll
+        for (int e = 0; e < EC; ++e) red[rl * BN + ch * EC + e] = csum[e];
+        __syncthreads();
+        if (tid < BN && n0 + tid < p.Nout) {
+            float t = 0.f;
+#pragma unroll
+            for (int k = 0; k < 256 / CPR; ++k) t += red[k * BN + tid];
+            p.colsum_ws[((size_t)blockIdx.z * gridDim.x + blockIdx.x) * p.Nout + n0 + tid] = t;
+        }
     }
 }
 
@@ -318,7 +341,7 @@ extern "C" int rbvae_gather_gemm(int dtype, const void* A, const void* W, void* 
                                  int IW, int TH, int TW, int sa, int OH, int OW, int so, int Kc, int Nout, int lda,
                                  int ldo, int taps_total, int nclass, const int* class_desc, int relu,
                                  int drop_mode, float drop_p, float scale, unsigned long long seed,
-                                 const unsigned long long* seed_dev, void* stream) {
+                                 const unsigned long long* seed_dev, float* colsum_ws, void* stream) {
     RBVAE_CHECK_ARG(A && W && Out && zero_page && class_desc, "gather_gemm: null pointer");
     RBVAE_CHECK_ARG(dtype == RBVAE_F32 || dtype == RBVAE_BF16, "gather_gemm: dtype %d", dtype);
     const int ES = dtype == RBVAE_F32 ? 4 : 2;
@@ -340,7 +363,7 @@ extern "C" int rbvae_gather_gemm(int dtype, const void* A, const void* W, void* 
     a.zero = (const unsigned char*)zero_page;
     a.Nimg = Nimg; a.IH = IH; a.IW = IW; a.TH = TH; a.TW = TW; a.sa = sa; a.OH = OH; a.OW = OW; a.so = so;
     a.Kc = Kc; a.Nout = Nout; a.lda = lda; a.ldo = ldo; a.taps_total = taps_total;
-    a.relu = relu; a.drop_mode = drop_mode; a.scale = scale; a.seed = seed; a.seed_dev = seed_dev;
+    a.relu = relu; a.drop_mode = drop_mode; a.scale = scale; a.seed = seed; a.seed_dev = seed_dev; a.colsum_ws = colsum_ws;
     a.drop_thresh = (unsigned)((double)drop_p * 4294967296.0);
     a.nclass = nclass;
     // class_desc (host ints): per class [ntaps, oh0, ow0, then ntaps x (widx, dh, dw)], classes back to back

@@ -48,40 +48,43 @@ __global__ void cast_pad_k(const float* __restrict__ in, T* __restrict__ out, in
 }
 
 // ---- column sums: X [P][ld] -> partial [nblk][C] -> out[C] -------------------
-constexpr int CS_ROWS = 256;   // rows per block
+// grid = (row blocks of `rpb` rows, 256-column groups); thread -> (column, row lane)
 template <typename T>
-__global__ __launch_bounds__(256) void colsum_partial_k(const T* __restrict__ X, int P, int C, int ld,
+__global__ __launch_bounds__(256) void colsum_partial_k(const T* __restrict__ X, int P, int C, int ld, int rpb,
                                                         float* __restrict__ ws) {
-    // thread -> (column c = tid % cw, row lane = tid / cw); cw = min(C, 256) columns per pass
     __shared__ float red[256];
     const int cw = C < 256 ? C : 256;
     const int rl = 256 / cw;
     const int tc = threadIdx.x % cw, tr = threadIdx.x / cw;
-    const int r0 = blockIdx.x * CS_ROWS;
-    const int r1 = min(P, r0 + CS_ROWS);
-    for (int c0 = 0; c0 < C; c0 += cw) {
-        const int c = c0 + tc;
-        float acc = 0.f;
-        if (tr < rl && c < C)
-            for (int r = r0 + tr; r < r1; r += rl) acc += Elem<T>::load(X + (long)r * ld + c);
-        red[threadIdx.x] = acc;
-        __syncthreads();
-        if (tr == 0 && c < C) {
-            float t = 0.f;
-            for (int k = 0; k < rl; ++k) t += red[k * cw + tc];
-            ws[(long)blockIdx.x * C + c] = t;
-        }
-        __syncthreads();
+    const int r0 = blockIdx.x * rpb;
+    const int r1 = min(P, r0 + rpb);
+    const int c = blockIdx.y * 256 + tc;
+    float acc = 0.f;
+    if (tr < rl && c < C)
+        for (int r = r0 + tr; r < r1; r += rl) acc += Elem<T>::load(X + (long)r * ld + c);
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    if (tr == 0 && c < C) {
+        float t = 0.f;
+        for (int k = 0; k < rl; ++k) t += red[k * cw + tc];
+        ws[(long)blockIdx.x * C + c] = t;
     }
 }
-__global__ void colsum_final_k(const float* __restrict__ ws, int nblk, int C, float* __restrict__ out, float scale,
-                               int accumulate) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+// out[c] (+)= scale * sum_b ws[b][c]: 64 columns per block, 4 row lanes, fixed order
+__global__ __launch_bounds__(256) void colsum_final_k(const float* __restrict__ ws, int nblk, int C,
+                                                      float* __restrict__ out, float scale, int accumulate) {
+    __shared__ float red[256];
+    const int tc = threadIdx.x & 63, tr = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + tc;
     float t = 0.f;
-    for (int b = 0; b < nblk; ++b) t += ws[(long)b * C + c];
-    t *= scale;
-    out[c] = accumulate ? out[c] + t : t;
+    if (c < C)
+        for (int b = tr; b < nblk; b += 4) t += ws[(long)b * C + c];
+    red[threadIdx.x] = t;
+    __syncthreads();
+    if (tr == 0 && c < C) {
+        t = (red[tc] + red[64 + tc] + red[128 + tc] + red[192 + tc]) * scale;
+        out[c] = accumulate ? out[c] + t : t;
+    }
 }
 
 // ---- im2col: strided f32 source -> col[P][Kpad] (column (kh*KW+kw)*C + c) ----
@@ -289,23 +292,34 @@ int rbvae_cast_pad(int dtype, const float* in, void* out, int rows, int L, int L
     return RBVAE_OK;
 }
 
-size_t rbvae_colsum_ws_floats(int P, int C) { return (size_t)cdiv(P, CS_ROWS) * C; }
+static inline int colsum_rpb(int P) { return max(64, ((cdiv(P, 256) + 63) / 64) * 64); }
+size_t rbvae_colsum_ws_floats(int P, int C) { return (size_t)cdiv(P, colsum_rpb(P)) * C; }
 
 int rbvae_colsum(int dtype, const void* X, int P, int C, int ld, float* out, float* ws, float scale, int accumulate,
                  void* stream) {
     RBVAE_CHECK_ARG(X && out && ws && P > 0 && C > 0 && ld >= C, "colsum: bad arguments");
-    const int nblk = cdiv(P, CS_ROWS);
+    const int rpb = colsum_rpb(P);
+    const int nblk = cdiv(P, rpb);
+    const dim3 grid(nblk, cdiv(C, 256));
     if (dtype == RBVAE_F32)
-        hipLaunchKernelGGL(colsum_partial_k<float>, dim3(nblk), dim3(256), 0, (hipStream_t)stream, (const float*)X,
-                           P, C, ld, ws);
+        hipLaunchKernelGGL(colsum_partial_k<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)X,
+                           P, C, ld, rpb, ws);
     else if (dtype == RBVAE_BF16)
-        hipLaunchKernelGGL(colsum_partial_k<bf16_t>, dim3(nblk), dim3(256), 0, (hipStream_t)stream,
-                           (const bf16_t*)X, P, C, ld, ws);
+        hipLaunchKernelGGL(colsum_partial_k<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream,
+                           (const bf16_t*)X, P, C, ld, rpb, ws);
     else
         return fail(RBVAE_E_INVALID, "colsum: dtype %d", dtype);
-    hipLaunchKernelGGL(colsum_final_k, dim3(cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, ws, nblk, C, out, scale,
+    hipLaunchKernelGGL(colsum_final_k, dim3(cdiv(C, 64)), dim3(256), 0, (hipStream_t)stream, ws, nblk, C, out, scale,
                        accumulate);
     RBVAE_CHECK_LAUNCH("colsum");
+    return RBVAE_OK;
+}
+
+int rbvae_reduce_rows(const float* ws, int rows, int C, float* out, float scale, int accumulate, void* stream) {
+    RBVAE_CHECK_ARG(ws && out && rows > 0 && C > 0, "reduce_rows: bad arguments");
+    hipLaunchKernelGGL(colsum_final_k, dim3(cdiv(C, 64)), dim3(256), 0, (hipStream_t)stream, ws, rows, C, out, scale,
+                       accumulate);
+    RBVAE_CHECK_LAUNCH("reduce_rows");
     return RBVAE_OK;
 }
 

@@ -242,7 +242,8 @@ class Engine:
         return d
 
     def _gemm(self, A, W, out, bias, gate, mask, nimg, ih, iw, th, tw, sa, oh, ow, so, kc, nout, lda, ldo, taps,
-              cls_key, relu=0, drop_mode=0, drop_p=0.0, scale=1.0, seed=0):
+              cls_key, relu=0, drop_mode=0, drop_p=0.0, scale=1.0, seed=0, bias_grad=None, colsum_ws=None):
+        """bias_grad: f32 [nout] tensor that receives the column sums of the stored output."""
         seed_dev = self.seed_dev
         if cls_key == "one":
             desc, ncls = self._desc("one", ONE_TAP), 1
@@ -251,9 +252,15 @@ class Engine:
         else:
             desc, ncls = self._desc("dgrad", self._cls_dgrad), self._ncls_dgrad
         import ctypes
+        ws = colsum_ws
+        if bias_grad is not None:
+            prow = ncls * (-(-(nimg * th * tw) // 128))
+            ws = torch.empty(prow * nout, dtype=torch.float32, device=self.device)
         L.call("rbvae_gather_gemm", self.dt, A, W, out, bias, gate, mask, self.zero, nimg, ih, iw, th, tw, sa, oh, ow,
                so, kc, nout, lda, ldo, taps, ncls, ctypes.addressof(desc), relu, drop_mode, float(drop_p),
-               float(scale), int(seed), seed_dev)
+               float(scale), int(seed), seed_dev, ws)
+        if bias_grad is not None:
+            L.call("rbvae_reduce_rows", ws, prow, nout, bias_grad, 1.0, 0)
 
     def _conv_idx(self, nimg, ih, iw, oh, ow):
         key = (nimg, ih, iw, oh, ow)
@@ -437,16 +444,14 @@ class Engine:
                     (c1, oc, kk), (self.K3, 1, oc))
         dd2 = self._E(P1, c1)
         self._gemm(col3, self.V3f, dd2, None, sv.d2, None, P1, 1, 1, 1, 1, 1, 1, 1, 1, self.K3, c1, self.K3, c1, 1,
-                   "one", scale=gs)
+                   "one", scale=gs, bias_grad=G(f"decoder_cnn.deconv.{i1}.bias"))
         # --- deconv1 (c2 -> c1): input grad = conv forward of dd2 with the same weights
-        self._colsum(self.dt, dd2, P1, c1, c1, G(f"decoder_cnn.deconv.{i1}.bias"))
         self._wgrad(sv.d1, dd2, self._conv_idx(N, h1, w1, h2, w2), P2, c2, c1, c2, c1, kk,
                     G(f"decoder_cnn.deconv.{i1}.weight"), (c2, c1, kk), (kk * c1, 1, c1))
         dd1 = self._E(P2, c2)
         self._gemm(dd2, self.V2f, dd1, None, sv.d1, None, N, h1, w1, h2, w2, 2, h2, w2, 1, c1, c2, c1, c2, kk, "conv",
-                   scale=gs)
+                   scale=gs, bias_grad=G(f"decoder_cnn.deconv.{i0}.bias"))
         # --- deconv0 (c3 -> c2)
-        self._colsum(self.dt, dd1, P2, c2, c2, G(f"decoder_cnn.deconv.{i0}.bias"))
         self._wgrad(sv.f, dd1, self._conv_idx(N, h2, w2, h3, w3), P3, c3, c2, c3, c2, kk,
                     G(f"decoder_cnn.deconv.{i0}.weight"), (c3, c2, kk), (kk * c2, 1, c2))
         df = self._E(P3, c3)
@@ -495,23 +500,25 @@ class Engine:
         L.call("rbvae_wgrad_gemm", self.dt, de_pad, sv.a3, gw, None, self.zero, N, self.Lp, self.F3, self.Lp, self.F3, 1, 1)
         L.call("rbvae_permute_reduce", gw, 1, 0, G("encoder_cnn.fc.weight"), Ld, c3, g3, self.F3, 1, c3, 1.0, 0)
         da3 = self._E(P3, c3)
+        # the GEMM sees da3 as [N][F3]; its fused column sums [m-tiles][F3] are [m-tiles*g3][c3] rows,
+        # so the conv3 bias gradient is one reduce_rows over them
+        mt = -(-N // 128)
+        ws3 = self._E(mt * self.F3, dtype=torch.float32)
         self._gemm(de_pad, self.WfcT, da3, None, sv.a3 if v.simple_order else None, None, N, 1, 1, 1, 1, 1, 1, 1, 1,
-                   self.Lp, self.F3, self.Lp, self.F3, 1, "one")
+                   self.Lp, self.F3, self.Lp, self.F3, 1, "one", colsum_ws=ws3)
+        L.call("rbvae_reduce_rows", ws3, mt * g3, c3, G(f"encoder_cnn.conv.{i2}.bias"), 1.0, 0)
         # --- conv3
-        self._colsum(self.dt, da3, P3, c3, c3, G(f"encoder_cnn.conv.{i2}.bias"))
         self._wgrad(da3, sv.a2, self._conv_idx(N, h2, w2, h3, w3), P3, c3, c2, c3, c2, kk,
                     G(f"encoder_cnn.conv.{i2}.weight"), (c3, c2, kk), (kk * c2, 1, c2))
         da2 = self._E(P2, c2)
         self._gemm(da3, self.W3d, da2, None, sv.a2, None, N, h3, w3, h3, w3, 1, h2, w2, 2, c3, c2, c3, c2, kk, "dgrad",
-                   scale=gs)
+                   scale=gs, bias_grad=G(f"encoder_cnn.conv.{i1}.bias"))
         # --- conv2
-        self._colsum(self.dt, da2, P2, c2, c2, G(f"encoder_cnn.conv.{i1}.bias"))
         self._wgrad(da2, sv.a1, self._conv_idx(N, h1, w1, h2, w2), P2, c2, c1, c2, c1, kk,
                     G(f"encoder_cnn.conv.{i1}.weight"), (c2, c1, kk), (kk * c1, 1, c1))
         da1 = self._E(P1, c1)
         self._gemm(da2, self.W2d, da1, None, sv.a1, None, N, h2, w2, h2, w2, 1, h1, w1, 2, c2, c1, c2, c1, kk, "dgrad",
-                   scale=gs)
+                   scale=gs, bias_grad=G(f"encoder_cnn.conv.{i0}.bias"))
         # --- conv1 (1-tap GEMM over the saved im2col columns)
-        self._colsum(self.dt, da1, P1, c1, c1, G(f"encoder_cnn.conv.{i0}.bias"))
         self._wgrad(da1, sv.col1, None, P1, c1, self.K1, c1, self.K1, 1, G(f"encoder_cnn.conv.{i0}.weight"),
                     (c1, self.in_ch, kk), (self.K1, 1, self.in_ch))

@@ -38,7 +38,7 @@ def gemm(sfv, dt, A, Wp, out, bias, gate, mask, geom, kc, nout, taps, desc, ncls
     zero = torch.zeros(256, dtype=torch.uint8, device="cuda")
     d = (ctypes.c_int * len(desc))(*desc)
     sfv._lib.call("rbvae_gather_gemm", dt, A, Wp, out, bias, gate, mask, zero, *geom, kc, nout, A.shape[1],
-                  out.shape[1], taps, ncls, ctypes.addressof(d), relu, drop_mode, drop_p, scale, seed, None)
+                  out.shape[1], taps, ncls, ctypes.addressof(d), relu, drop_mode, drop_p, scale, seed, None, None)
 
 
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
