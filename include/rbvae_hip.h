@@ -149,9 +149,17 @@ int rbvae_permute_reduce(const float* in, int nslab, long slab_stride, float* ou
                          long s1, long s2, float scale, int accumulate, void* stream);
 int rbvae_cast_pad(int dtype, const float* in, void* out, int rows, int L, int Lpad, void* stream);
 int rbvae_reduce_rows(const float* ws, int rows, int C, float* out, float scale, int accumulate, void* stream);
+/* first half of colsum: ws[ceil(P/rpb)][C] partial sums (rbvae_colsum_ws_floats(P, C) floats) */
+int rbvae_colsum_partial(int dtype, const void* X, int P, int C, int ld, float* ws, void* stream);
 size_t rbvae_colsum_ws_floats(int P, int C);
 int rbvae_colsum(int dtype, const void* X, int P, int C, int ld, float* out, float* ws, float scale, int accumulate,
                  void* stream);
+
+/* Batched layout jobs: njobs rows of 16 x int64 in DEVICE memory
+ *   [type, src, dst, d0, d1, d2, s0, s1, s2, nslab, slab_stride, dtype, accumulate, scale(f32 bits, low word), 0, 0]
+ * type 0 = pack3, 1 = permute_reduce, 2 = reduce_rows (out[c] = scale*sum_k src[k*slab+c], c < d0*d1*d2).
+ * One launch (grid.y = job) replaces the per-tensor launches of a step. */
+int rbvae_run_jobs(const void* jobs_dev, int njobs, int blocks_per_job, void* stream);
 
 /* im2col of a strided f32 image (element strides sn,sc,sh,sw) into col[N*OH*OW][Kpad], column
  * (kh*KW+kw)*C + c: the 3/4-channel first Conv2d (percep_RBVAE_model.py:51) and the last

@@ -22,6 +22,7 @@
 // lane owns 4 consecutive output channels of one pixel; the tile goes through
 // LDS once more and leaves as whole 16-B chunks of NHWC rows.
 #include "common.h"
+#include <stdlib.h>
 
 namespace rbvae {
 
@@ -92,26 +93,43 @@ template <> __device__ __forceinline__ bool elem_pos<bf16_t>(const unsigned char
 
 constexpr int GG_BM = 128;
 
-template <typename T, int NT>
-__global__ __launch_bounds__(256, 2) void gather_gemm_k(const GgArgs p) {
+template <int N> __device__ __forceinline__ void wait_vmcnt_barrier() {
+    // counted wait (LDS-DMA of the slice about to be read has landed for THIS wave), then the
+    // workgroup barrier; no vmcnt(0) drain, so younger slices stay in flight across the barrier
+    asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::"n"(N) : "memory");
+}
+
+// GG_NS = LDS ring depth.  3: two K-slices in flight behind the one being multiplied (one workgroup per
+// CU, deep K); 2: classic double buffer, two workgroups per CU; 1: single buffer for 1-2 slice problems
+// where four workgroups per CU overlap each other's load / store latencies instead.
+template <typename T, int NT, int WAVES, int GG_NS>
+__global__ __launch_bounds__(WAVES * 64, 1) void gather_gemm_k(const GgArgs p) {
+    constexpr int THREADS = WAVES * 64;
     constexpr int BN = NT * 32;
     constexpr int ES = sizeof(T);
     constexpr int KE = 128 / ES;                 // k elements per staged row slice
     constexpr int EC = 16 / ES;                  // elements per 16-B chunk
     constexpr int A_BYTES = GG_BM * 128, B_BYTES = BN * 128;
+    constexpr int STAGE = A_BYTES + B_BYTES;
     constexpr int PITCH = BN * ES + 16;          // epilogue tile row pitch
+    // wave grid WR x WC over the 128 x BN tile; a wave owns MT x NTW MFMA tiles (16 x 16 each)
+    constexpr int WR = 2, WC = WAVES / 2;
+    constexpr int MT = 8 / WR, NTW = (2 * NT) / WC;
+    constexpr int A_INSTR = 16 / WAVES, B_INSTR = (BN / 8) / WAVES;   // LDS-DMA instructions per wave per slice
+    constexpr int LOADS = A_INSTR + B_INSTR;
+    static_assert(NTW >= 1 && B_INSTR >= 1, "tile too narrow for this many waves");
+    constexpr int RING = GG_NS * STAGE > GG_BM * PITCH ? GG_NS * STAGE : GG_BM * PITCH;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned char* sA = smem;                    // 2 x A_BYTES
-    unsigned char* sB = smem + 2 * A_BYTES;      // 2 x B_BYTES
-    int* s_orow = (int*)(smem + (2 * A_BYTES + 2 * B_BYTES > GG_BM * PITCH ? 2 * A_BYTES + 2 * B_BYTES
-                                                                            : GG_BM * PITCH));
+    int* s_orow = (int*)(smem + RING);           // [128]
+    int* s_tap = s_orow + GG_BM;                 // [16][4]: widx, dh, dw of this class
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const TapClass& tc = p.cls[blockIdx.z];
     const int Mc = p.Nimg * p.TH * p.TW;
     const int m0 = blockIdx.x * GG_BM, n0 = blockIdx.y * BN;
+    const int ntaps = tc.ntaps;
 
-    // output row of every tile row (for the store phase)
+    // output row of every tile row (for the store phase) and the class's tap table
     if (tid < GG_BM) {
         const int m = m0 + tid;
         int o = -1;
@@ -122,16 +140,22 @@ __global__ __launch_bounds__(256, 2) void gather_gemm_k(const GgArgs p) {
             if (oh < p.OH && ow < p.OW) o = (n * p.OH + oh) * p.OW + ow;
         }
         s_orow[tid] = o;
+    } else if (tid < GG_BM + 16) {
+        const int j = tid - GG_BM;
+        s_tap[j * 4 + 0] = tc.widx[j];
+        s_tap[j * 4 + 1] = tc.dh[j];
+        s_tap[j * 4 + 2] = tc.dw[j];
     }
+    __syncthreads();
 
     // staging roles: one LDS-DMA instruction moves 8 rows x 128 B; wave w issues rows
-    // (w*4+i)*8 .. +7 of A (i<4) and (w*NT+i)*8 .. +7 of B (i<NT)
+    // (w*A_INSTR+i)*8 .. +7 of A and (w*B_INSTR+i)*8 .. +7 of B
     const int srow = lane >> 3, schunk = lane & 7;
-    int an[4], aa[4], ab[4];
-    unsigned a_sw[4];
+    int an[A_INSTR], aa[A_INSTR], ab[A_INSTR];
+    unsigned a_sw[A_INSTR];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int r = (w * 4 + i) * 8 + srow;
+    for (int i = 0; i < A_INSTR; ++i) {
+        const int r = (w * A_INSTR + i) * 8 + srow;
         const int m = m0 + r;
         a_sw[i] = (unsigned)((schunk ^ ((r >> 1) & 7)) * 16);
         if (m < Mc) {
@@ -141,11 +165,11 @@ __global__ __launch_bounds__(256, 2) void gather_gemm_k(const GgArgs p) {
             an[i] = -1; aa[i] = 0; ab[i] = 0;
         }
     }
-    const unsigned char* bptr[NT];
-    bool bval[NT];
+    const unsigned char* bptr[B_INSTR];
+    bool bval[B_INSTR];
 #pragma unroll
-    for (int i = 0; i < NT; ++i) {
-        const int r = (w * NT + i) * 8 + srow;
+    for (int i = 0; i < B_INSTR; ++i) {
+        const int r = (w * B_INSTR + i) * 8 + srow;
         const int n = n0 + r;
         bval[i] = n < p.Nout;
         bptr[i] = p.W + ((size_t)(bval[i] ? n : 0) * p.taps_total * p.Kc) * ES + (schunk ^ ((r >> 1) & 7)) * 16;
@@ -153,75 +177,92 @@ __global__ __launch_bounds__(256, 2) void gather_gemm_k(const GgArgs p) {
     const unsigned char* zsrc = p.zero + schunk * 16;
 
     const int kchunks = p.Kc / KE;
-    const int nsteps = tc.ntaps * kchunks;
+    const int nsteps = ntaps * kchunks;
 
-    const unsigned char* aptr[4];
+    // producer state: the (tap, k-chunk) of the next slice to stage
+    const unsigned char* aptr[A_INSTR];
+    size_t woff = 0;
+    int pj = -1, pkc = 0, pbuf = 0;
     auto tap_setup = [&](int j) {
-        const int dh = tc.dh[j], dw = tc.dw[j];
+        const int widx = s_tap[j * 4 + 0], dh = s_tap[j * 4 + 1], dw = s_tap[j * 4 + 2];
+        woff = ((size_t)widx * p.Kc) * ES;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < A_INSTR; ++i) {
             const int ih = aa[i] * p.sa + dh, iw = ab[i] * p.sa + dw;
             const bool v = an[i] >= 0 && ih >= 0 && ih < p.IH && iw >= 0 && iw < p.IW;
             aptr[i] = v ? p.A + ((size_t)((an[i] * p.IH + ih) * p.IW + iw) * p.lda) * ES + a_sw[i] : nullptr;
         }
     };
-    auto stage = [&](int j, int kc, int buf) {
-        unsigned char* la = sA + buf * A_BYTES + (w * 4) * 1024;
+    auto stage_next = [&]() {
+        if (pj < 0 || pkc == kchunks) { ++pj; pkc = 0; tap_setup(pj); }
+        unsigned char* la = smem + pbuf * STAGE + (w * A_INSTR) * 1024;
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-            glds16(aptr[i] ? aptr[i] + (size_t)kc * 128 : zsrc, la + i * 1024);
-        unsigned char* lb = sB + buf * B_BYTES + (w * NT) * 1024;
-        const size_t woff = ((size_t)tc.widx[j] * p.Kc) * ES + (size_t)kc * 128;
+        for (int i = 0; i < A_INSTR; ++i)
+            glds16(aptr[i] ? aptr[i] + (size_t)pkc * 128 : zsrc, la + i * 1024);
+        unsigned char* lb = smem + pbuf * STAGE + A_BYTES + (w * B_INSTR) * 1024;
 #pragma unroll
-        for (int i = 0; i < NT; ++i)
-            glds16(bval[i] ? bptr[i] + woff : zsrc, lb + i * 1024);
+        for (int i = 0; i < B_INSTR; ++i)
+            glds16(bval[i] ? bptr[i] + woff + (size_t)pkc * 128 : zsrc, lb + i * 1024);
+        ++pkc;
+        pbuf = (pbuf + 1 == GG_NS) ? 0 : pbuf + 1;
     };
 
     // fragment read offsets (swizzle depends on the lane only: tile rows are multiples of 16)
     const int fi = lane & 15, fg = lane >> 4;
     const int fsw = (fi >> 1) & 7;
-    const int wr = w >> 1, wc = w & 1;
+    const int wr = w / WC, wc = w - wr * WC;
     int offA[2], offB[2];
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
         const int ch = ((4 * kk + fg) ^ fsw) * 16;
-        offA[kk] = (wr * 64 + fi) * 128 + ch;
-        offB[kk] = (wc * NT * 16 + fi) * 128 + ch;
+        offA[kk] = (wr * MT * 16 + fi) * 128 + ch;
+        offB[kk] = A_BYTES + (wc * NTW * 16 + fi) * 128 + ch;
     }
 
-    f32x4_t acc[4][NT];
+    f32x4_t acc[MT][NTW];
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt)
+    for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        for (int nt = 0; nt < NTW; ++nt) acc[mt][nt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-    int j = 0, kc = 0;
-    tap_setup(0);
-    stage(0, 0, 0);
-    for (int s = 0; s < nsteps; ++s) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        // advance (j, kc) to step s+1 and prefetch it into the other buffer
-        int kn = kc + 1, jn = j;
-        if (kn == kchunks) { kn = 0; jn = j + 1; }
-        if (s + 1 < nsteps) {
-            if (jn != j) tap_setup(jn);
-            stage(jn, kn, (s + 1) & 1);
-        }
-        j = jn; kc = kn;
-        const unsigned char* la = sA + (s & 1) * A_BYTES;
-        const unsigned char* lb = sB + (s & 1) * B_BYTES;
+    auto multiply = [&](const unsigned char* lbase) {
+        u32x4_t fa[2][MT], fb[2][NTW];
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
-            u32x4_t fa[4], fb[NT];
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt) fa[mt] = *(const u32x4_t*)(la + offA[kk] + mt * 2048);
+            for (int mt = 0; mt < MT; ++mt) fa[kk][mt] = *(const u32x4_t*)(lbase + offA[kk] + mt * 2048);
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) fb[nt] = *(const u32x4_t*)(lb + offB[kk] + nt * 2048);
+            for (int nt = 0; nt < NTW; ++nt) fb[kk][nt] = *(const u32x4_t*)(lbase + offB[kk] + nt * 2048);
+        }
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt)
+        for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) Mma<T>::run(acc[mt][nt], fb[nt], fa[mt]);
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NTW; ++nt) Mma<T>::run(acc[mt][nt], fb[kk][nt], fa[kk][mt]);
+    };
+    if constexpr (GG_NS == 1) {
+        for (int s = 0; s < nsteps; ++s) {
+            if (s > 0) __syncthreads();              // everyone is done reading the single buffer
+            stage_next();
+            wait_vmcnt_barrier<0>();
+            multiply(smem);
+        }
+    } else {
+        // prologue: GG_NS-1 slices in flight
+#pragma unroll
+        for (int i = 0; i < GG_NS - 1; ++i)
+            if (i < nsteps) stage_next();
+        int cbuf = 0;
+        for (int s = 0; s < nsteps; ++s) {
+            // slice s must have landed; younger slices stay in flight across the barrier
+            if (GG_NS > 2 && nsteps - s - 1 >= GG_NS - 2)
+                wait_vmcnt_barrier<(GG_NS > 2 ? GG_NS - 2 : 0) * LOADS>();
+            else
+                wait_vmcnt_barrier<0>();      // tail (or double buffer): nothing younger is in flight
+            if (s + GG_NS - 1 < nsteps) stage_next();   // refills the buffer multiplied in step s-1
+            multiply(smem + cbuf * STAGE);
+            cbuf = (cbuf + 1 == GG_NS) ? 0 : cbuf + 1;
         }
     }
     __syncthreads();
@@ -229,16 +270,16 @@ __global__ __launch_bounds__(256, 2) void gather_gemm_k(const GgArgs p) {
     // ---- epilogue, register phase: bias, relu, scale; lane owns pixel fi, channels 4*fg..+3
     unsigned char* tile = smem;
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-        const int cb = wc * NT * 16 + nt * 16 + 4 * fg;      // tile-local channel
+    for (int nt = 0; nt < NTW; ++nt) {
+        const int cb = (wc * NTW + nt) * 16 + 4 * fg;        // tile-local channel
         float bz[4] = {0.f, 0.f, 0.f, 0.f};
         if (p.bias && n0 + cb < p.Nout) {
             const float4 b4 = *(const float4*)(p.bias + n0 + cb);
             bz[0] = b4.x; bz[1] = b4.y; bz[2] = b4.z; bz[3] = b4.w;
         }
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt) {
-            const int row = wr * 64 + mt * 16 + fi;
+        for (int mt = 0; mt < MT; ++mt) {
+            const int row = (wr * MT + mt) * 16 + fi;
             float v[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -261,10 +302,11 @@ __global__ __launch_bounds__(256, 2) void gather_gemm_k(const GgArgs p) {
 
     // ---- store phase: whole 16-B chunks of NHWC rows; dropout / gate zeroing happens here
     constexpr int CPR = BN / EC;
+    constexpr int RL = THREADS / CPR;            // row lanes of the store phase
     float csum[EC];
 #pragma unroll
     for (int e = 0; e < EC; ++e) csum[e] = 0.f;
-    for (int idx = tid; idx < GG_BM * CPR; idx += 256) {
+    for (int idx = tid; idx < GG_BM * CPR; idx += THREADS) {
         const int row = idx / CPR, ch = idx - row * CPR;     // ch == tid % CPR on every pass
         const int orow = s_orow[row];
         const int col = n0 + ch * EC;
@@ -297,9 +339,9 @@ __global__ __launch_bounds__(256, 2) void gather_gemm_k(const GgArgs p) {
         }
     }
     if (p.colsum_ws) {
-        // bias gradient: column sums of this tile's stored rows, reduced over the 256/CPR row lanes in LDS
+        // bias gradient: column sums of this tile's stored rows, reduced over the row lanes in LDS
         __syncthreads();
-        float* red = (float*)smem;                     // [256/CPR][BN]
+        float* red = (float*)smem;                     // [RL][BN]
         const int rl = tid / CPR, ch = tid - rl * CPR;
 #pragma unroll
         for (int e = 0; e < EC; ++e) red[rl * BN + ch * EC + e] = csum[e];
@@ -307,29 +349,42 @@ __global__ __launch_bounds__(256, 2) void gather_gemm_k(const GgArgs p) {
         if (tid < BN && n0 + tid < p.Nout) {
             float t = 0.f;
 #pragma unroll
-            for (int k = 0; k < 256 / CPR; ++k) t += red[k * BN + tid];
+            for (int k = 0; k < RL; ++k) t += red[k * BN + tid];
             p.colsum_ws[((size_t)blockIdx.z * gridDim.x + blockIdx.x) * p.Nout + n0 + tid] = t;
         }
     }
 }
 
-template <typename T, int NT>
+template <typename T, int NT, int WAVES, int NS>
 static int launch_gg(const GgArgs& a, hipStream_t st) {
     constexpr int BN = NT * 32;
     constexpr int ES = sizeof(T);
     const int Mc = a.Nimg * a.TH * a.TW;
-    const size_t stage_bytes = 2 * GG_BM * 128 + 2 * BN * 128;
-    const size_t tile_bytes = (size_t)GG_BM * (BN * ES + 16);
-    const size_t lds = (stage_bytes > tile_bytes ? stage_bytes : tile_bytes) + GG_BM * sizeof(int);
+    const size_t ring = (size_t)NS * (GG_BM * 128 + BN * 128);
+    const size_t tile = (size_t)GG_BM * (BN * ES + 16);
+    const size_t lds = (ring > tile ? ring : tile) + GG_BM * sizeof(int) + 64 * sizeof(int);
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute((const void*)gather_gemm_k<T, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipFuncSetAttribute((const void*)gather_gemm_k<T, NT, WAVES, NS>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)lds);
         attr_set = true;
     }
     dim3 grid(cdiv(Mc, GG_BM), cdiv(a.Nout, BN), a.nclass);
-    hipLaunchKernelGGL((gather_gemm_k<T, NT>), grid, dim3(256), lds, st, a);
+    hipLaunchKernelGGL((gather_gemm_k<T, NT, WAVES, NS>), grid, dim3(WAVES * 64), lds, st, a);
     RBVAE_CHECK_LAUNCH("gather_gemm");
     return RBVAE_OK;
+}
+
+template <typename T>
+static int dispatch_gg(const GgArgs& a, hipStream_t st, int max_steps) {
+    const long blocks = (long)cdiv(a.Nimg * a.TH * a.TW, GG_BM) * cdiv(a.Nout, a.Nout > 64 ? 128 : 64) * a.nclass;
+    static const int force = getenv("RBVAE_GG_NS") ? atoi(getenv("RBVAE_GG_NS")) : 0;
+    int ns = max_steps <= 2 ? 1 : (blocks > 256 ? 2 : 3);
+    if (force) ns = force;
+    if (a.Nout <= 64) return ns == 1 ? launch_gg<T, 2, 4, 1>(a, st) : launch_gg<T, 2, 4, 2>(a, st);
+    if (ns == 1) return launch_gg<T, 4, 4, 1>(a, st);
+    if (ns == 2) return launch_gg<T, 4, 8, 2>(a, st);
+    return launch_gg<T, 4, 8, 3>(a, st);
 }
 
 }  // namespace rbvae
@@ -380,7 +435,8 @@ extern "C" int rbvae_gather_gemm(int dtype, const void* A, const void* W, void* 
         }
     }
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == RBVAE_F32)
-        return Nout > 64 ? launch_gg<float, 4>(a, st) : launch_gg<float, 2>(a, st);
-    return Nout > 64 ? launch_gg<bf16_t, 4>(a, st) : launch_gg<bf16_t, 2>(a, st);
+    int max_taps = 0;
+    for (int c = 0; c < nclass; ++c) max_taps = a.cls[c].ntaps > max_taps ? a.cls[c].ntaps : max_taps;
+    const int max_steps = max_taps * (Kc / KE);
+    return dtype == RBVAE_F32 ? dispatch_gg<float>(a, st, max_steps) : dispatch_gg<bf16_t>(a, st, max_steps);
 }

@@ -315,6 +315,22 @@ int rbvae_colsum(int dtype, const void* X, int P, int C, int ld, float* out, flo
     return RBVAE_OK;
 }
 
+int rbvae_colsum_partial(int dtype, const void* X, int P, int C, int ld, float* ws, void* stream) {
+    RBVAE_CHECK_ARG(X && ws && P > 0 && C > 0 && ld >= C, "colsum_partial: bad arguments");
+    const int rpb = colsum_rpb(P);
+    const dim3 grid(cdiv(P, rpb), cdiv(C, 256));
+    if (dtype == RBVAE_F32)
+        hipLaunchKernelGGL(colsum_partial_k<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)X, P, C, ld,
+                           rpb, ws);
+    else if (dtype == RBVAE_BF16)
+        hipLaunchKernelGGL(colsum_partial_k<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)X, P, C,
+                           ld, rpb, ws);
+    else
+        return fail(RBVAE_E_INVALID, "colsum_partial: dtype %d", dtype);
+    RBVAE_CHECK_LAUNCH("colsum_partial");
+    return RBVAE_OK;
+}
+
 int rbvae_reduce_rows(const float* ws, int rows, int C, float* out, float scale, int accumulate, void* stream) {
     RBVAE_CHECK_ARG(ws && out && rows > 0 && C > 0, "reduce_rows: bad arguments");
     hipLaunchKernelGGL(colsum_final_k, dim3(cdiv(C, 64)), dim3(256), 0, (hipStream_t)stream, ws, rows, C, out, scale,

@@ -208,6 +208,268 @@ __global__ __launch_bounds__(256) void lstm_wgrad_k(const float* __restrict__ dG
     *dst = accumulate ? *dst + acc : acc;
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Wavefront variants: every layer gets its own group of G = roundup64(4L) threads with its weight
+// rows in registers, and the (layer, time) cells run along anti-diagonals: layer l works on time
+// d - l at diagonal d.  The dependent chain shrinks from layers*T cells to T + layers - 1 steps,
+// barriers wait on LDS only (global stores of the saved state stay in flight).
+// ---------------------------------------------------------------------------------------------
+// sigmoid / tanh on the hardware exp2 and reciprocal (about 1 ulp each): the wavefront kernels sit on a
+// short dependent chain where the library expf/tanhf sequences would dominate.
+__device__ __forceinline__ float fast_sigmoid(float x) {
+    return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
+}
+__device__ __forceinline__ float fast_tanh(float x) {
+    return 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-2.8853900817779268f * x)) - 1.0f;
+}
+
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+template <int LMAX, bool VEC>
+__global__ __launch_bounds__(1024) void lstm_fwd_wave_k(const float* __restrict__ wblk, float* __restrict__ hs_all,
+                                                        float* __restrict__ hprev, float* __restrict__ acts,
+                                                        float* __restrict__ cs, int S, int T, int L, int layers,
+                                                        int G) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* hbuf = sm;                               // [layers+1][T][L]
+    float* gates = hbuf + (layers + 1) * T * L;     // [layers][4L]  ACTIVATED gates i, f, g, o
+    const int l = threadIdx.x / G, j = threadIdx.x - l * G;
+    const int s = blockIdx.x;
+    const bool row = j < 4 * L;
+    const bool is_g = j >= 2 * L && j < 3 * L;      // the tanh gate
+    for (int i = threadIdx.x; i < T * L; i += blockDim.x) hbuf[i] = hs_all[((long)s * T) * L + i];
+    const float* wl = wblk + l * lstm_layer_floats(L);
+    float wih[LMAX], whh[LMAX];
+    float bsum = 0.f;
+    {
+        const int jc = row ? j : 0;
+        bsum = wl[8l * L * L + jc] + wl[8l * L * L + 4 * L + jc];
+        const float* pi = wl + jc * L;
+        const float* ph = pi + 4 * L * L;
+#pragma unroll
+        for (int k = 0; k < LMAX; ++k) {
+            const int kk = k < L ? k : L - 1;
+            const float a = pi[kk], b = ph[kk];
+            wih[k] = k < L ? a : 0.f;
+            whh[k] = k < L ? b : 0.f;
+        }
+    }
+    float c = 0.f;
+    // slots 1.. are read (times a zero factor) before they are written: keep them finite
+    for (int i = T * L + threadIdx.x; i < (layers + 1) * T * L; i += blockDim.x) hbuf[i] = 0.f;
+    __syncthreads();
+    const int ndiag = T + layers - 1;
+    for (int d = 0; d < ndiag; ++d) {
+        const int t = d - l;
+        const bool active = t >= 0 && t < T;
+        if (active && row) {
+            const float* xt = hbuf + (l * T + t) * L;
+            const float* hp = hbuf + ((l + 1) * T + (t > 0 ? t - 1 : 0)) * L;
+            const float hscale = t > 0 ? 1.f : 0.f;      // h_{-1} = 0
+            float a0 = bsum, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+            float b0 = 0.f, b1 = 0.f, b2 = 0.f, b3 = 0.f;
+            if constexpr (VEC) {
+#pragma unroll
+                for (int k = 0; k < LMAX; k += 4) {
+                    if (k < L) {
+                        const float4 xv = *(const float4*)(xt + k), hv = *(const float4*)(hp + k);
+                        a0 = fmaf(wih[k], xv.x, a0); a1 = fmaf(wih[k + 1], xv.y, a1);
+                        a2 = fmaf(wih[k + 2], xv.z, a2); a3 = fmaf(wih[k + 3], xv.w, a3);
+                        b0 = fmaf(whh[k], hv.x, b0); b1 = fmaf(whh[k + 1], hv.y, b1);
+                        b2 = fmaf(whh[k + 2], hv.z, b2); b3 = fmaf(whh[k + 3], hv.w, b3);
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < LMAX; ++k)
+                    if (k < L) { a0 = fmaf(wih[k], xt[k], a0); b0 = fmaf(whh[k], hp[k], b0); }
+            }
+            const float pre = ((a0 + a1) + (a2 + a3)) + hscale * ((b0 + b1) + (b2 + b3));
+            const float av = is_g ? fast_tanh(pre) : fast_sigmoid(pre);
+            gates[l * 4 * L + j] = av;
+            if (acts) acts[(((long)l * S + s) * T + t) * 4 * L + j] = av;
+        }
+        lds_barrier();
+        if (active && j < L) {
+            const float* gl = gates + l * 4 * L;
+            const float ig = gl[j], fg = gl[L + j], gg = gl[2 * L + j], og = gl[3 * L + j];
+            const float hp = t > 0 ? hbuf[((l + 1) * T + t - 1) * L + j] : 0.f;
+            c = fg * c + ig * gg;
+            const float h = og * fast_tanh(c);
+            hbuf[((l + 1) * T + t) * L + j] = h;
+            const long o = (((long)l * S + s) * T + t);
+            if (acts) {
+                cs[o * L + j] = c;
+                hprev[o * L + j] = hp;
+            }
+            hs_all[(((long)(l + 1) * S + s) * T + t) * L + j] = h;
+        }
+        lds_barrier();
+    }
+}
+
+template <int LMAX>
+__global__ __launch_bounds__(1024) void lstm_bwd_wave_k(const float* __restrict__ wblk, const float* __restrict__ acts,
+                                                        const float* __restrict__ cs, const float* __restrict__ g_top,
+                                                        float* __restrict__ dG, float* __restrict__ dx, int S, int T,
+                                                        int L, int layers, int G) {
+    extern __shared__ float sm[];
+    float* gtop = sm;                              // [T][L]
+    float* sacts = gtop + T * L;                   // [layers][T][4L]
+    float* scs = sacts + layers * T * 4 * L;       // [layers][T][L]
+    float* dg = scs + layers * T * L;              // [layers][4L]
+    float* part = dg + layers * 4 * L;             // [layers][4][2][L]
+    const int l = threadIdx.x / G, j = threadIdx.x - l * G;
+    const int s = blockIdx.x;
+    const bool row = j < 4 * L;
+    const int kcol = j % L, prt = j / L;
+    for (int i = threadIdx.x; i < T * L; i += blockDim.x) gtop[i] = g_top[((long)s * T) * L + i];
+    for (int ll = 0; ll < layers; ++ll) {
+        const long o = ((long)ll * S + s) * T;
+        for (int i = threadIdx.x; i < T * 4 * L; i += blockDim.x) sacts[ll * T * 4 * L + i] = acts[o * 4 * L + i];
+        for (int i = threadIdx.x; i < T * L; i += blockDim.x) scs[ll * T * L + i] = cs[o * L + i];
+    }
+    const float* wl = wblk + l * lstm_layer_floats(L);
+    float wic[LMAX], whc[LMAX];
+    if (row) {
+        const float* pi = wl + prt * L * L + kcol;
+        const float* ph = pi + 4 * L * L;
+#pragma unroll
+        for (int jj = 0; jj < LMAX; ++jj) {
+            const int o = (jj < L ? jj : L - 1) * L;
+            const float a = pi[o], b = ph[o];
+            wic[jj] = jj < L ? a : 0.f;
+            whc[jj] = jj < L ? b : 0.f;
+        }
+    }
+    float dc_next = 0.f;
+    __syncthreads();
+    const int top = layers - 1;
+    const int ndiag = T + layers - 1;
+    for (int e = 0; e < ndiag; ++e) {
+        const int q = e - (top - l);
+        const int t = T - 1 - q;
+        const bool active = q >= 0 && q < T;
+        if (j < L) {
+            // layer 0: the input gradient of the step finished at the previous diagonal (time t+1)
+            if (l == 0 && q >= 1 && q <= T) {
+                const float* p0 = part;
+                dx[((long)s * T + t + 1) * L + j] = p0[0 * L + j] + p0[2 * L + j] + p0[4 * L + j] + p0[6 * L + j];
+            }
+            if (active) {
+                float dh;
+                if (l == top) dh = gtop[t * L + j];
+                else {
+                    const float* pu = part + (l + 1) * 8 * L;
+                    dh = pu[0 * L + j] + pu[2 * L + j] + pu[4 * L + j] + pu[6 * L + j];
+                }
+                if (q > 0) {
+                    const float* pm = part + l * 8 * L;
+                    dh += pm[1 * L + j] + pm[3 * L + j] + pm[5 * L + j] + pm[7 * L + j];
+                }
+                const float* ap = sacts + (l * T + t) * 4 * L;
+                const float ig = ap[j], fg = ap[L + j], gg = ap[2 * L + j], og = ap[3 * L + j];
+                const float c = scs[(l * T + t) * L + j];
+                const float cprev = t > 0 ? scs[(l * T + t - 1) * L + j] : 0.f;
+                const float tc = fast_tanh(c);
+                const float dc = dc_next + dh * og * (1.f - tc * tc);
+                const float d_o = dh * tc * og * (1.f - og);
+                const float d_i = dc * gg * ig * (1.f - ig);
+                const float d_f = dc * cprev * fg * (1.f - fg);
+                const float d_g = dc * ig * (1.f - gg * gg);
+                dc_next = dc * fg;
+                float* dl = dg + l * 4 * L;
+                dl[j] = d_i; dl[L + j] = d_f; dl[2 * L + j] = d_g; dl[3 * L + j] = d_o;
+                float* gp = dG + (((long)l * S + s) * T + t) * 4 * L;
+                gp[j] = d_i; gp[L + j] = d_f; gp[2 * L + j] = d_g; gp[3 * L + j] = d_o;
+            }
+        }
+        lds_barrier();
+        if (active && row) {
+            float ax0 = 0.f, ax1 = 0.f, ah0 = 0.f, ah1 = 0.f;
+            const float* dgp = dg + l * 4 * L + prt * L;
+#pragma unroll
+            for (int jj = 0; jj < LMAX; jj += 2) {
+                if (jj + 1 < L) {
+                    const float d0 = dgp[jj], d1 = dgp[jj + 1];
+                    ax0 = fmaf(wic[jj], d0, ax0); ax1 = fmaf(wic[jj + 1], d1, ax1);
+                    ah0 = fmaf(whc[jj], d0, ah0); ah1 = fmaf(whc[jj + 1], d1, ah1);
+                } else if (jj < L) {
+                    const float d0 = dgp[jj];
+                    ax0 = fmaf(wic[jj], d0, ax0); ah0 = fmaf(whc[jj], d0, ah0);
+                }
+            }
+            part[l * 8 * L + (prt * 2 + 0) * L + kcol] = ax0 + ax1;
+            part[l * 8 * L + (prt * 2 + 1) * L + kcol] = ah0 + ah1;
+        }
+        lds_barrier();
+    }
+    if (l == 0 && j < L) dx[((long)s * T) * L + j] = part[0 * L + j] + part[2 * L + j] + part[4 * L + j] + part[6 * L + j];
+}
+
+// Weight gradients, LDS-tiled: block = (32 gate rows, ih|hh, layer); thread (jj, kq) owns gate row jj and
+// the columns kq, kq+8, ... (column L = the bias).  Rows of dG / X stream through LDS 128 at a time.
+constexpr int LW_ROWS = 128;
+constexpr int LW_KMAX = 17;     // ceil((128 + 1) / 8)
+__global__ __launch_bounds__(256) void lstm_wgrad_tiled_k(const float* __restrict__ dG, const float* __restrict__ hs_all,
+                                                          const float* __restrict__ hprev, float* __restrict__ gblk,
+                                                          int S, int T, int L, int accumulate) {
+    extern __shared__ float sm[];
+    float* sg = sm;                      // [LW_ROWS][32 gate rows]
+    float* sx = sg + LW_ROWS * 32;       // [LW_ROWS][L]
+    const int l = blockIdx.z, hh = blockIdx.y, j0 = blockIdx.x * 32;
+    const int jj = threadIdx.x & 31, kq = threadIdx.x >> 5;
+    const int R = S * T;
+    const float* g = dG + (long)l * R * 4 * L;
+    const float* x = hh ? hprev + (long)l * R * L : hs_all + (long)l * R * L;
+    float acc[LW_KMAX];
+#pragma unroll
+    for (int i = 0; i < LW_KMAX; ++i) acc[i] = 0.f;
+    for (int r0 = 0; r0 < R; r0 += LW_ROWS) {
+        const int nr = min(LW_ROWS, R - r0);
+        // clamped indices: every load is unconditional, so the 16 loads of a thread are all in flight
+#pragma unroll
+        for (int it = 0; it < LW_ROWS * 32 / 256; ++it) {
+            const int i = threadIdx.x + it * 256;
+            const int r = i >> 5, c = i & 31;
+            const float v = g[(long)(r0 + min(r, nr - 1)) * 4 * L + min(j0 + c, 4 * L - 1)];
+            sg[i] = (r < nr && j0 + c < 4 * L) ? v : 0.f;
+        }
+        for (int i0 = 0; i0 < LW_ROWS * L; i0 += 256 * 8) {
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const int i = i0 + threadIdx.x + it * 256;
+                const float v = x[(long)r0 * L + min(i, nr * L - 1)];
+                if (i < LW_ROWS * L) sx[i] = i < nr * L ? v : 0.f;
+            }
+        }
+        __syncthreads();
+        for (int r = 0; r < nr; ++r) {
+            const float gv = sg[r * 32 + jj];
+            const float* xr = sx + r * L;
+#pragma unroll
+            for (int i = 0; i < LW_KMAX; ++i) {
+                const int k = kq + 8 * i;
+                if (k <= L) acc[i] = fmaf(gv, k < L ? xr[k] : 1.f, acc[i]);
+            }
+        }
+        __syncthreads();
+    }
+    const int jrow = j0 + jj;
+    if (jrow >= 4 * L) return;
+    float* out = gblk + l * (8l * L * L + 8l * L);
+#pragma unroll
+    for (int i = 0; i < LW_KMAX; ++i) {
+        const int k = kq + 8 * i;
+        if (k > L) continue;
+        float* dst = k < L ? out + (hh ? 4l * L * L : 0) + (long)jrow * L + k : out + 8l * L * L + (hh ? 4 * L : 0) + jrow;
+        *dst = accumulate ? *dst + acc[i] : acc[i];
+    }
+}
+
 }  // namespace rbvae
 
 using namespace rbvae;
@@ -224,6 +486,18 @@ int rbvae_lstm_fwd(const float* wblk, float* hs_all, float* hprev, float* acts, 
     const size_t lds = (size_t)(2 * T * L + 5 * L) * sizeof(float);
     RBVAE_CHECK_ARG(lds <= 64 * 1024, "lstm_fwd: T*L=%d too large", T * L);
     hipStream_t st = (hipStream_t)stream;
+    // wavefront kernel: one thread group per layer (weights in registers, L <= 32)
+    const size_t wlds = (size_t)((layers + 1) * T * L + layers * 4 * L) * sizeof(float);
+    if (L <= 32 && layers * threads <= 1024 && wlds <= 64 * 1024) {
+        if (L % 4 == 0)
+            hipLaunchKernelGGL((lstm_fwd_wave_k<32, true>), dim3(S), dim3(layers * threads), wlds, st, wblk, hs_all,
+                               hprev, acts, cs, S, T, L, layers, threads);
+        else
+            hipLaunchKernelGGL((lstm_fwd_wave_k<32, false>), dim3(S), dim3(layers * threads), wlds, st, wblk, hs_all,
+                               hprev, acts, cs, S, T, L, layers, threads);
+        RBVAE_CHECK_LAUNCH("lstm_fwd_wave");
+        return RBVAE_OK;
+    }
     if (L <= 32)
         hipLaunchKernelGGL(lstm_fwd_k<32>, dim3(S), dim3(threads), lds, st, wblk, hs_all, hprev, acts, cs, S, T, L, layers);
     else if (L <= 64)
@@ -243,6 +517,13 @@ int rbvae_lstm_bwd(const float* wblk, const float* acts, const float* cs, const 
     const size_t lds = (size_t)(2 * T * L + 13 * L) * sizeof(float);
     RBVAE_CHECK_ARG(lds <= 64 * 1024, "lstm_bwd: T*L=%d too large", T * L);
     hipStream_t st = (hipStream_t)stream;
+    const size_t wlds = (size_t)(T * L + layers * T * 5 * L + layers * 12 * L) * sizeof(float);
+    if (L <= 32 && layers * threads <= 1024 && wlds <= 64 * 1024) {
+        hipLaunchKernelGGL(lstm_bwd_wave_k<32>, dim3(S), dim3(layers * threads), wlds, st, wblk, acts, cs, g_top, dG,
+                           dx, S, T, L, layers, threads);
+        RBVAE_CHECK_LAUNCH("lstm_bwd_wave");
+        return RBVAE_OK;
+    }
     if (L <= 32)
         hipLaunchKernelGGL(lstm_bwd_k<32>, dim3(S), dim3(threads), lds, st, wblk, acts, cs, g_top, dG, dx, S, T, L, layers);
     else if (L <= 64)
@@ -256,8 +537,9 @@ int rbvae_lstm_bwd(const float* wblk, const float* acts, const float* cs, const 
 int rbvae_lstm_wgrad(const float* dG, const float* hs_all, const float* hprev, float* gblk, int S, int T, int L,
                      int layers, int accumulate, void* stream) {
     RBVAE_CHECK_ARG(dG && hs_all && hprev && gblk && S > 0 && T > 0 && L > 0 && layers > 0, "lstm_wgrad: bad arguments");
-    dim3 grid(cdiv(4 * L * (L + 1), 256), 2, layers);
-    hipLaunchKernelGGL(lstm_wgrad_k, grid, dim3(256), 0, (hipStream_t)stream, dG, hs_all, hprev, gblk, S, T, L,
+    dim3 grid(cdiv(4 * L, 32), 2, layers);
+    const size_t lds = (size_t)(LW_ROWS * 32 + LW_ROWS * L) * sizeof(float);
+    hipLaunchKernelGGL(lstm_wgrad_tiled_k, grid, dim3(256), lds, (hipStream_t)stream, dG, hs_all, hprev, gblk, S, T, L,
                        accumulate);
     RBVAE_CHECK_LAUNCH("lstm_wgrad");
     return RBVAE_OK;

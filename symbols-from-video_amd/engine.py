@@ -138,6 +138,36 @@ def dgrad_classes(k: int) -> Tuple[List[int], int]:
 
 ONE_TAP = [1, 0, 0, 0, 0, 0]
 
+JOB_PACK, JOB_PERMUTE, JOB_ROWS = 0, 1, 2
+
+
+class JobList:
+    """Rows of the rbvae_run_jobs table (16 x int64 each), uploaded once and replayed."""
+
+    def __init__(self):
+        self.rows: List[List[int]] = []
+        self.keep = []          # tensors whose addresses the table holds
+
+    def add(self, kind, src, dst, dims, strides, nslab=1, slab=0, dtype=0, accumulate=0, scale=1.0):
+        import struct
+        bits = struct.unpack("<I", struct.pack("<f", float(scale)))[0]
+        # consecutive threads walk the index whose stride on the strided side is 1 (coalesced on that side;
+        # the contiguous side then sees short strides that the caches absorb)
+        fast = 2
+        for ax in (2, 1, 0):
+            if strides[ax] == 1 and dims[ax] > 1:
+                fast = ax
+                break
+        self.rows.append([kind, src.data_ptr(), dst.data_ptr(), dims[0], dims[1], dims[2], strides[0], strides[1],
+                          strides[2], nslab, slab, dtype, int(accumulate), bits | (fast << 32), 0, 0])
+        self.keep += [src, dst]
+
+    def upload(self, device):
+        return torch.tensor(self.rows, dtype=torch.int64).to(device)
+
+    def signature(self):
+        return tuple(tuple(r) for r in self.rows)
+
 
 class Saved:
     """Activations one forward call keeps for its backward."""
@@ -184,6 +214,10 @@ class Engine:
         self._desc_cache: Dict[Tuple, object] = {}
         self._idx_cache: Dict[Tuple, torch.Tensor] = {}
         self.seed_dev = None           # optional device step counter (int64 tensor) for graph-replayed steps
+        self._pack_tab: Dict = {}
+        self._bufs: Dict = {}          # persistent backward temporaries, keyed by (N, tag)
+        self._bwd_tab: Dict = {}       # uploaded reduce-job tables, keyed by their signature
+        self._jobs: Optional[JobList] = None
         self._alloc_packed()
 
     # ---- packed weights -------------------------------------------------------
@@ -205,32 +239,44 @@ class Engine:
         self.V3f = z(c1, self.K3)                      # [c1][(t,co) padded]
 
     def pack(self, flat: torch.Tensor):
-        """f32 parameters (reference layouts) -> the packed T copies the GEMMs read."""
+        """f32 parameters (reference layouts) -> the packed T copies the GEMMs read (one launch)."""
+        key = flat.data_ptr()
+        tab = self._pack_tab.get(key)
+        if tab is None:
+            jl = self._pack_jobs(flat)
+            tab = (jl.upload(self.device), len(jl.rows), jl)
+            self._pack_tab = {key: tab}
+        L.call("rbvae_run_jobs", tab[0], tab[1], 256)
+
+    def _pack_jobs(self, flat: torch.Tensor) -> JobList:
         lay, dt = self.layout, self.dt
         c1, c2, c3 = self.v.channels
         kk = self.k * self.k
         g3 = self.g3[0] * self.g3[1]
         i0, i1, i2 = lay.conv_idx
         P = lambda name: lay.view(flat, name)
+        jl = JobList()
+        pk = lambda src, dst, dims, strides, d=None: jl.add(JOB_PACK, src, dst, dims, strides, dtype=dt if d is None else d)
         # conv1 [c1][cin][kk] -> [c1][t*cin + ci]
-        L.call("rbvae_pack3", dt, P(f"encoder_cnn.conv.{i0}.weight"), self.W1p, c1, self.in_ch, kk, self.K1, 1, self.in_ch)
+        pk(P(f"encoder_cnn.conv.{i0}.weight"), self.W1p, (c1, self.in_ch, kk), (self.K1, 1, self.in_ch))
         for name, wf, wd, co, ci in ((f"encoder_cnn.conv.{i1}.weight", self.W2f, self.W2d, c2, c1),
                                      (f"encoder_cnn.conv.{i2}.weight", self.W3f, self.W3d, c3, c2),
                                      (f"decoder_cnn.deconv.{i0}.weight", self.V1f, self.V1d, c3, c2),
                                      (f"decoder_cnn.deconv.{i1}.weight", self.V2f, self.V2d, c2, c1)):
-            w = P(name)                                                  # [co][ci][kk]
-            L.call("rbvae_pack3", dt, w, wf, co, ci, kk, kk * ci, 1, ci)  # [co][t][ci]
-            L.call("rbvae_pack3", dt, w, wd, co, ci, kk, 1, kk * co, co)  # [ci][t][co]
-        v3 = P(f"decoder_cnn.deconv.{i2}.weight")                        # [c1][out][kk]
-        L.call("rbvae_pack3", dt, v3, self.V3p, c1, self.out_ch, kk, 1, c1, self.out_ch * c1)      # [(t*out+co)][c1]
-        L.call("rbvae_pack3", dt, v3, self.V3f, c1, self.out_ch, kk, self.K3, 1, self.out_ch)      # [c1][t*out+co]
-        wfc = P("encoder_cnn.fc.weight")                                 # [L][c3][g3]
-        L.call("rbvae_pack3", dt, wfc, self.Wfc, self.latent, c3, g3, self.F3, 1, c3)
-        L.call("rbvae_pack3", dt, wfc, self.WfcT, self.latent, c3, g3, 1, self.Lp, c3 * self.Lp)
-        wd = P("decoder_cnn.fc.weight")                                  # [c3][g3][L]
-        L.call("rbvae_pack3", dt, wd, self.Wdfc, c3, g3, self.latent, self.Lp, c3 * self.Lp, 1)
-        L.call("rbvae_pack3", dt, wd, self.WdfcT, c3, g3, self.latent, 1, c3, self.F3)
-        L.call("rbvae_pack3", F32, P("decoder_cnn.fc.bias"), self.bdfc, c3, g3, 1, 1, c3, 0)
+            w = P(name)                                               # [co][ci][kk]
+            pk(w, wf, (co, ci, kk), (kk * ci, 1, ci))                 # [co][t][ci]
+            pk(w, wd, (co, ci, kk), (1, kk * co, co))                 # [ci][t][co]
+        v3 = P(f"decoder_cnn.deconv.{i2}.weight")                     # [c1][out][kk]
+        pk(v3, self.V3p, (c1, self.out_ch, kk), (1, c1, self.out_ch * c1))       # [(t*out+co)][c1]
+        pk(v3, self.V3f, (c1, self.out_ch, kk), (self.K3, 1, self.out_ch))       # [c1][t*out+co]
+        wfc = P("encoder_cnn.fc.weight")                              # [L][c3][g3]
+        pk(wfc, self.Wfc, (self.latent, c3, g3), (self.F3, 1, c3))
+        pk(wfc, self.WfcT, (self.latent, c3, g3), (1, self.Lp, c3 * self.Lp))
+        wd = P("decoder_cnn.fc.weight")                               # [c3][g3][L]
+        pk(wd, self.Wdfc, (c3, g3, self.latent), (self.Lp, c3 * self.Lp, 1))
+        pk(wd, self.WdfcT, (c3, g3, self.latent), (1, c3, self.F3))
+        pk(P("decoder_cnn.fc.bias"), self.bdfc, (c3, g3, 1), (1, c3, 0), F32)
+        return jl
 
     # ---- helpers ---------------------------------------------------------------
     def _desc(self, key, ints):
@@ -241,9 +287,20 @@ class Engine:
             self._desc_cache[key] = d
         return d
 
+    def _buf(self, tag, numel, dtype=torch.float32):
+        """Persistent temporary (same address every step, so uploaded job tables stay valid)."""
+        key = (tag, numel, dtype)
+        t = self._bufs.get(key)
+        if t is None:
+            t = torch.empty(numel, dtype=dtype, device=self.device)
+            self._bufs[key] = t
+        return t
+
     def _gemm(self, A, W, out, bias, gate, mask, nimg, ih, iw, th, tw, sa, oh, ow, so, kc, nout, lda, ldo, taps,
-              cls_key, relu=0, drop_mode=0, drop_p=0.0, scale=1.0, seed=0, bias_grad=None, colsum_ws=None):
-        """bias_grad: f32 [nout] tensor that receives the column sums of the stored output."""
+              cls_key, relu=0, drop_mode=0, drop_p=0.0, scale=1.0, seed=0, bias_grad=None, colsum_ws=None,
+              tag=None):
+        """bias_grad: f32 [nout] tensor that receives the column sums of the stored output (a reduce job
+        over the kernel's per-tile partial sums, run with the other jobs at the end of backward)."""
         seed_dev = self.seed_dev
         if cls_key == "one":
             desc, ncls = self._desc("one", ONE_TAP), 1
@@ -255,12 +312,11 @@ class Engine:
         ws = colsum_ws
         if bias_grad is not None:
             prow = ncls * (-(-(nimg * th * tw) // 128))
-            ws = torch.empty(prow * nout, dtype=torch.float32, device=self.device)
+            ws = self._buf(("colsum", tag), prow * nout)
+            self._jobs.add(JOB_ROWS, ws, bias_grad, (1, 1, nout), (0, 0, 1), nslab=prow, slab=nout)
         L.call("rbvae_gather_gemm", self.dt, A, W, out, bias, gate, mask, self.zero, nimg, ih, iw, th, tw, sa, oh, ow,
                so, kc, nout, lda, ldo, taps, ncls, ctypes.addressof(desc), relu, drop_mode, float(drop_p),
                float(scale), int(seed), seed_dev, ws)
-        if bias_grad is not None:
-            L.call("rbvae_reduce_rows", ws, prow, nout, bias_grad, 1.0, 0)
 
     def _conv_idx(self, nimg, ih, iw, oh, ow):
         key = (nimg, ih, iw, oh, ow)
@@ -271,19 +327,31 @@ class Engine:
             self._idx_cache[key] = t
         return t
 
-    def _wgrad(self, Dy, In, idx, P, Co, Ci, ldy, ldi, taps, out, dims, strides, accumulate=False):
-        """wgrad GEMM into K-slice slabs, then the fixed-order reduction into the torch layout."""
+    def _wgrad(self, Dy, In, idx, P, Co, Ci, ldy, ldi, taps, out, dims, strides, tag=None):
+        """wgrad GEMM into K-slice slabs; their fixed-order reduction into the torch layout is a job."""
         bm = 128 if (Co > 64 and Ci > 64) else 64
         blocks = -(-Co // bm) * -(-Ci // bm) * taps
         ks = max(1, min(32, 512 // max(blocks, 1), P // 256 if P >= 256 else 1))
-        slabs = torch.empty(ks * Co * taps * Ci, dtype=torch.float32, device=self.device)
+        ks = max(ks, -(-P // 4096))            # the kernel keeps a K-slice's gather indices in LDS
+        slabs = self._buf(("slabs", tag), ks * Co * taps * Ci)
         L.call("rbvae_wgrad_gemm", self.dt, Dy, In, slabs, idx, self.zero, P, Co, Ci, ldy, ldi, taps, ks)
-        L.call("rbvae_permute_reduce", slabs, ks, Co * taps * Ci, out, dims[0], dims[1], dims[2],
-               strides[0], strides[1], strides[2], 1.0, int(accumulate))
+        self._jobs.add(JOB_PERMUTE, slabs, out, dims, strides, nslab=ks, slab=Co * taps * Ci)
 
-    def _colsum(self, dt, X, P, C, ld, out, accumulate=False):
-        ws = torch.empty(L.query("rbvae_colsum_ws_floats", P, C), dtype=torch.float32, device=self.device)
-        L.call("rbvae_colsum", dt, X, P, C, ld, out, ws, 1.0, int(accumulate))
+    def _colsum(self, dt, X, P, C, ld, out, tag=None):
+        """Column sums of a tensor no GEMM epilogue produced: partial kernel now, final reduction as a job."""
+        nf = L.query("rbvae_colsum_ws_floats", P, C)
+        ws = self._buf(("cs", tag), nf)
+        L.call("rbvae_colsum_partial", dt, X, P, C, ld, ws)
+        self._jobs.add(JOB_ROWS, ws, out, (1, 1, C), (0, 0, 1), nslab=nf // C, slab=C)
+
+    def _run_jobs(self):
+        jl, self._jobs = self._jobs, None
+        sig = jl.signature()
+        tab = self._bwd_tab.get(sig)
+        if tab is None:
+            tab = (jl.upload(self.device), len(jl.rows), jl)
+            self._bwd_tab[sig] = tab
+        L.call("rbvae_run_jobs", tab[0], tab[1], 256)
 
     def _E(self, *shape, dtype=None):
         return torch.empty(*shape, dtype=dtype or self.tdt, device=self.device)
@@ -428,55 +496,64 @@ class Engine:
         gs = sv.gate_scale
         P1, P2, P3 = N * h1 * w1, N * h2 * w2, N * h3 * w3
         g3 = h3 * w3
+        oc = self.out_ch
+        self._jobs = JobList()
+        f32 = torch.float32
+
+        def tmp(tag, *shape, dtype=None):
+            n = math.prod(shape)
+            return self._buf((N, tag), n, dtype or self.tdt).view(*shape)
+
         # --- last deconv
         if g_xr is not None:
-            dpre3 = self._E(N, H, W, self.out_ch, dtype=torch.float32)
-            L.call("rbvae_sigmoid_bwd_nhwc", g_xr.contiguous(), sv.xr, dpre3, N, self.out_ch, H, W)
+            dpre3 = tmp("dpre3", N, H, W, oc, dtype=f32)
+            L.call("rbvae_sigmoid_bwd_nhwc", g_xr.contiguous(), sv.xr, dpre3, N, oc, H, W)
         else:
             dpre3 = sv.dpre3
             if dpre3 is None:
                 raise RuntimeError("backward without g_xr needs forward(target=..., need_grad=True)")
-        self._colsum(F32, dpre3, N * H * W, self.out_ch, self.out_ch, G(f"decoder_cnn.deconv.{i2}.bias"))
-        col3 = self._E(P1, self.K3)
-        oc = self.out_ch
+        self._colsum(F32, dpre3, N * H * W, oc, oc, G(f"decoder_cnn.deconv.{i2}.bias"), tag=(N, "b3"))
+        col3 = tmp("col3", P1, self.K3)
         L.call("rbvae_im2col", self.dt, dpre3, H * W * oc, 1, W * oc, oc, N, oc, H, W, h1, w1, k, k, 2, 1, self.K3, col3)
         self._wgrad(sv.d2, col3, None, P1, c1, self.K3, c1, self.K3, 1, G(f"decoder_cnn.deconv.{i2}.weight"),
-                    (c1, oc, kk), (self.K3, 1, oc))
-        dd2 = self._E(P1, c1)
+                    (c1, oc, kk), (self.K3, 1, oc), tag=(N, "V3"))
+        dd2 = tmp("dd2", P1, c1)
         self._gemm(col3, self.V3f, dd2, None, sv.d2, None, P1, 1, 1, 1, 1, 1, 1, 1, 1, self.K3, c1, self.K3, c1, 1,
-                   "one", scale=gs, bias_grad=G(f"decoder_cnn.deconv.{i1}.bias"))
+                   "one", scale=gs, bias_grad=G(f"decoder_cnn.deconv.{i1}.bias"), tag=(N, "dd2"))
         # --- deconv1 (c2 -> c1): input grad = conv forward of dd2 with the same weights
         self._wgrad(sv.d1, dd2, self._conv_idx(N, h1, w1, h2, w2), P2, c2, c1, c2, c1, kk,
-                    G(f"decoder_cnn.deconv.{i1}.weight"), (c2, c1, kk), (kk * c1, 1, c1))
-        dd1 = self._E(P2, c2)
+                    G(f"decoder_cnn.deconv.{i1}.weight"), (c2, c1, kk), (kk * c1, 1, c1), tag=(N, "V2"))
+        dd1 = tmp("dd1", P2, c2)
         self._gemm(dd2, self.V2f, dd1, None, sv.d1, None, N, h1, w1, h2, w2, 2, h2, w2, 1, c1, c2, c1, c2, kk, "conv",
-                   scale=gs, bias_grad=G(f"decoder_cnn.deconv.{i0}.bias"))
+                   scale=gs, bias_grad=G(f"decoder_cnn.deconv.{i0}.bias"), tag=(N, "dd1"))
         # --- deconv0 (c3 -> c2)
         self._wgrad(sv.f, dd1, self._conv_idx(N, h2, w2, h3, w3), P3, c3, c2, c3, c2, kk,
-                    G(f"decoder_cnn.deconv.{i0}.weight"), (c3, c2, kk), (kk * c2, 1, c2))
-        df = self._E(P3, c3)
+                    G(f"decoder_cnn.deconv.{i0}.weight"), (c3, c2, kk), (kk * c2, 1, c2), tag=(N, "V1"))
+        df = tmp("df", P3, c3)
         self._gemm(dd1, self.V1f, df, None, None, None, N, h2, w2, h3, w3, 2, h3, w3, 1, c2, c3, c2, c3, kk, "conv")
-        # --- decoder fc
-        tmp = self._E(self.F3, dtype=torch.float32)
-        self._colsum(self.dt, df, N, self.F3, self.F3, tmp)
-        L.call("rbvae_permute_reduce", tmp, 1, 0, G("decoder_cnn.fc.bias"), c3, g3, 1, 1, c3, 0, 1.0, 0)
+        # --- decoder fc: bias = per (position, channel) sum over frames, permuted to the torch (c, hw) order
+        nf = L.query("rbvae_colsum_ws_floats", N, self.F3)
+        wsf = self._buf((N, "bdfc"), nf)
+        L.call("rbvae_colsum_partial", self.dt, df, N, self.F3, self.F3, wsf)
+        self._jobs.add(JOB_PERMUTE, wsf, G("decoder_cnn.fc.bias"), (c3, g3, 1), (1, c3, 0), nslab=nf // self.F3,
+                       slab=self.F3)
         self._wgrad(df, sv.ds_pad, None, N, self.F3, self.Lp, self.F3, self.Lp, 1, G("decoder_cnn.fc.weight"),
-                    (c3, g3, Ld), (self.Lp, c3 * self.Lp, 1))
-        dds = self._E(N, Ld, dtype=torch.float32)
+                    (c3, g3, Ld), (self.Lp, c3 * self.Lp, 1), tag=(N, "Wdfc"))
+        dds = tmp("dds", N, Ld, dtype=f32)
         L.call("rbvae_skinny_linear", self.dt, df, self.WdfcT, None, dds, N, Ld, self.F3, self.F3, self.F3, Ld)
         # --- decoder LSTM
         wenc, wdec = P("encoder_rnn.lstm.weight_ih_l0"), P("decoder_rnn.lstm.weight_ih_l0")
-        dG = self._E(nl, S, T, 4 * Ld, dtype=torch.float32)
-        d_in_dec = self._E(N, Ld, dtype=torch.float32)
+        dG = tmp("dG", nl, S, T, 4 * Ld, dtype=f32)
+        d_in_dec = tmp("d_in_dec", N, Ld, dtype=f32)
         L.call("rbvae_lstm_bwd", wdec, sv.acts_dec, sv.cs_dec, dds, dG, d_in_dec, S, T, Ld, nl)
         L.call("rbvae_lstm_wgrad", dG, sv.hs_dec, sv.hp_dec, G("decoder_rnn.lstm.weight_ih_l0"), S, T, Ld, nl, 0)
-        de = self._E(N, Ld, dtype=torch.float32)
+        de = tmp("de", N, Ld, dtype=f32)
         if not v.simple_order:
             # z -> binarise backward (+ fused KL) -> gradient of h_seq
             gz = d_in_dec
             if g_z is not None:
                 gz = gz + g_z.reshape(N, Ld)
-            dh = self._E(N, Ld, dtype=torch.float32)
+            dh = tmp("dh", N, Ld, dtype=f32)
             L.call("rbvae_binarize_kl_bwd", gz, sv.y, sv.z, dh, 0, N, Ld, float(sv.tau), float(kl_weight), None,
                    float(kl_p), 1e-8, 1)
             if g_hs is not None:
@@ -485,40 +562,40 @@ class Engine:
             L.call("rbvae_lstm_wgrad", dG, sv.hs_enc, sv.hp_enc, G("encoder_rnn.lstm.weight_ih_l0"), S, T, Ld, nl, 0)
         else:
             # decoder stack input = encoder stack output
-            dz = self._E(N, Ld, dtype=torch.float32)
+            dz = tmp("dz", N, Ld, dtype=f32)
             L.call("rbvae_lstm_bwd", wenc, sv.acts_enc, sv.cs_enc, d_in_dec, dG, dz, S, T, Ld, nl)
             L.call("rbvae_lstm_wgrad", dG, sv.hs_enc, sv.hp_enc, G("encoder_rnn.lstm.weight_ih_l0"), S, T, Ld, nl, 0)
             L.call("rbvae_binarize_kl_bwd", dz, sv.y, sv.z, de, 0, N, Ld, float(sv.tau), 0.0, None, 0.5, 1e-10, 0)
             if g_e is not None:
                 de = de + g_e.reshape(N, Ld)
         # --- encoder fc
-        self._colsum(F32, de, N, Ld, Ld, G("encoder_cnn.fc.bias"))
-        de_pad = self._E(N, self.Lp)
+        self._colsum(F32, de, N, Ld, Ld, G("encoder_cnn.fc.bias"), tag=(N, "bfc"))
+        de_pad = tmp("de_pad", N, self.Lp)
         L.call("rbvae_cast_pad", self.dt, de, de_pad, N, Ld, self.Lp)
-        gw = self._E(self.Lp, self.F3, dtype=torch.float32)
-        bm = 64
-        L.call("rbvae_wgrad_gemm", self.dt, de_pad, sv.a3, gw, None, self.zero, N, self.Lp, self.F3, self.Lp, self.F3, 1, 1)
-        L.call("rbvae_permute_reduce", gw, 1, 0, G("encoder_cnn.fc.weight"), Ld, c3, g3, self.F3, 1, c3, 1.0, 0)
-        da3 = self._E(P3, c3)
+        self._wgrad(de_pad, sv.a3, None, N, self.Lp, self.F3, self.Lp, self.F3, 1, G("encoder_cnn.fc.weight"),
+                    (Ld, c3, g3), (self.F3, 1, c3), tag=(N, "Wfc"))
+        da3 = tmp("da3", P3, c3)
         # the GEMM sees da3 as [N][F3]; its fused column sums [m-tiles][F3] are [m-tiles*g3][c3] rows,
-        # so the conv3 bias gradient is one reduce_rows over them
+        # so the conv3 bias gradient is one row-reduce job over them
         mt = -(-N // 128)
-        ws3 = self._E(mt * self.F3, dtype=torch.float32)
+        ws3 = self._buf((N, "ws3"), mt * self.F3)
         self._gemm(de_pad, self.WfcT, da3, None, sv.a3 if v.simple_order else None, None, N, 1, 1, 1, 1, 1, 1, 1, 1,
                    self.Lp, self.F3, self.Lp, self.F3, 1, "one", colsum_ws=ws3)
-        L.call("rbvae_reduce_rows", ws3, mt * g3, c3, G(f"encoder_cnn.conv.{i2}.bias"), 1.0, 0)
+        self._jobs.add(JOB_ROWS, ws3, G(f"encoder_cnn.conv.{i2}.bias"), (1, 1, c3), (0, 0, 1), nslab=mt * g3, slab=c3)
         # --- conv3
         self._wgrad(da3, sv.a2, self._conv_idx(N, h2, w2, h3, w3), P3, c3, c2, c3, c2, kk,
-                    G(f"encoder_cnn.conv.{i2}.weight"), (c3, c2, kk), (kk * c2, 1, c2))
-        da2 = self._E(P2, c2)
+                    G(f"encoder_cnn.conv.{i2}.weight"), (c3, c2, kk), (kk * c2, 1, c2), tag=(N, "W3"))
+        da2 = tmp("da2", P2, c2)
         self._gemm(da3, self.W3d, da2, None, sv.a2, None, N, h3, w3, h3, w3, 1, h2, w2, 2, c3, c2, c3, c2, kk, "dgrad",
-                   scale=gs, bias_grad=G(f"encoder_cnn.conv.{i1}.bias"))
+                   scale=gs, bias_grad=G(f"encoder_cnn.conv.{i1}.bias"), tag=(N, "da2"))
         # --- conv2
         self._wgrad(da2, sv.a1, self._conv_idx(N, h1, w1, h2, w2), P2, c2, c1, c2, c1, kk,
-                    G(f"encoder_cnn.conv.{i1}.weight"), (c2, c1, kk), (kk * c1, 1, c1))
-        da1 = self._E(P1, c1)
+                    G(f"encoder_cnn.conv.{i1}.weight"), (c2, c1, kk), (kk * c1, 1, c1), tag=(N, "W2"))
+        da1 = tmp("da1", P1, c1)
         self._gemm(da2, self.W2d, da1, None, sv.a1, None, N, h2, w2, h2, w2, 1, h1, w1, 2, c2, c1, c2, c1, kk, "dgrad",
-                   scale=gs, bias_grad=G(f"encoder_cnn.conv.{i0}.bias"))
+                   scale=gs, bias_grad=G(f"encoder_cnn.conv.{i0}.bias"), tag=(N, "da1"))
         # --- conv1 (1-tap GEMM over the saved im2col columns)
         self._wgrad(da1, sv.col1, None, P1, c1, self.K1, c1, self.K1, 1, G(f"encoder_cnn.conv.{i0}.weight"),
-                    (c1, self.in_ch, kk), (self.K1, 1, self.in_ch))
+                    (c1, self.in_ch, kk), (self.K1, 1, self.in_ch), tag=(N, "W1"))
+        # every slab / partial-sum reduction of this pass in one launch
+        self._run_jobs()

@@ -88,7 +88,7 @@ class _ForwardFn(torch.autograd.Function):
         model, eng, sv = ctx.model, ctx.eng, ctx.sv
         if sv.acts_enc is None:
             raise RuntimeError("backward through a forward that ran without gradient tracking")
-        gflat = torch.zeros_like(model._flat)
+        gflat = model._gflat_ws()
         if g_xr is None:
             g_xr = torch.zeros_like(sv.xr)
         if ctx.simple:
@@ -212,6 +212,14 @@ class Seq2SeqBinaryVAE(nn.Module):
             if self._packed_version != (id(eng), ver):
                 eng.pack(self._flat)
                 self._packed_version = (id(eng), ver)
+
+    def _gflat_ws(self):
+        """Persistent flat gradient workspace (stable address: the engine's job tables point into it)."""
+        g = getattr(self, "_gflat", None)
+        if g is None or g.device != self._flat.device or g.numel() != self._flat.numel():
+            g = torch.zeros_like(self._flat)
+            self._gflat = g
+        return g
 
     def _next_seed(self):
         self._seed += 1

@@ -1,0 +1,39 @@
+#!/usr/bin/env python3
+"""Summarise a rocprofv3 --kernel-trace CSV: per-kernel time per step and the GEMM launches of one step."""
+import csv
+import glob
+import sys
+import collections
+
+d = sys.argv[1]
+f = glob.glob(f"{d}/**/*_kernel_trace.csv", recursive=True)[0]
+rows = list(csv.DictReader(open(f)))
+rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+names = [r["Kernel_Name"] for r in rows]
+marks = [i for i, n in enumerate(names) if "counter_add" in n]
+a, b = marks[-12], marks[-2]          # 10 steps
+steps = 10
+agg = collections.OrderedDict()
+for r in rows[a:b]:
+    n = r["Kernel_Name"].replace("void rbvae::", "").replace("rbvae::", "").split("(")[0][:48]
+    t = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+    c = agg.setdefault(n, [0, 0.0, 1e9, 0.0])
+    c[0] += 1
+    c[1] += t
+    c[2] = min(c[2], t)
+    c[3] = max(c[3], t)
+span = (int(rows[b]["Start_Timestamp"]) - int(rows[a]["Start_Timestamp"])) / 1e3 / steps
+busy = sum(v[1] for v in agg.values()) / steps
+print(f"step span {span:.1f} us, kernel busy {busy:.1f} us, kernels/step {(b - a) / steps:.0f}")
+try:
+    for n, (c, t, mn, mx) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+        print(f"  {n:48s} x{c / steps:5.1f}  {t / steps:8.1f} us/step  avg {t / c:7.1f}  min {mn:7.1f} max {mx:7.1f}")
+except BrokenPipeError:
+    pass
+if len(sys.argv) > 2:
+    a, b = marks[-3], marks[-2]
+    for r in rows[a:b]:
+        n = r["Kernel_Name"]
+        if "gemm" in n:
+            t = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+            print(f"    {n.replace('void rbvae::', '')[:44]:44s} grid=({int(r['Grid_Size_X']) // int(r['Workgroup_Size_X'])},{r['Grid_Size_Y']},{r['Grid_Size_Z']}) {t:7.1f} us")
