@@ -185,9 +185,10 @@ int rbvae_skinny_linear(int dtype, const void* A, const void* B, const float* bi
 /* ---- stacked LSTM (percep_RBVAE_model.py:94-122) ------------------------------------
  * wblk: per layer w_ih[4L][L], w_hh[4L][L], b_ih[4L], b_hh[4L] (the reference's registration
  * order).  hs_all [layers+1][S][T][L]: slot 0 = input (caller fills), slot l+1 = layer l output.
- * Training also saves hprev/cs [layers][S][T][L] and acts [layers][S][T][4L]. */
-int rbvae_lstm_fwd(const float* wblk, float* hs_all, float* hprev, float* acts, float* cs, int S, int T, int L,
-                   int layers, void* stream);
+ * Training also saves hprev/cs [layers][S][T][L] and acts [layers][S][T][4L].
+ * wT (optional): transposed weight copies [layers][ih|hh][L][4L] for coalesced loads. */
+int rbvae_lstm_fwd(const float* wblk, const float* wT, float* hs_all, float* hprev, float* acts, float* cs, int S,
+                   int T, int L, int layers, void* stream);
 int rbvae_lstm_bwd(const float* wblk, const float* acts, const float* cs, const float* g_top, float* dG, float* dx,
                    int S, int T, int L, int layers, void* stream);
 int rbvae_lstm_wgrad(const float* dG, const float* hs_all, const float* hprev, float* gblk, int S, int T, int L,

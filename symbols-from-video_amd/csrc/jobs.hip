@@ -59,7 +59,13 @@ __global__ __launch_bounds__(256) void run_jobs_k(const Job* __restrict__ jobs) 
             const float* p = j.src + so;
             float a = 0.f;
             const unsigned ns = (unsigned)j.nslab;
-            for (unsigned k = 0; k < ns; ++k) a += p[(size_t)k * j.slab];
+            unsigned k = 0;
+            for (; k + 4 <= ns; k += 4) {           // 4 independent loads in flight, fixed summation order
+                const float v0 = p[(size_t)k * j.slab], v1 = p[(size_t)(k + 1) * j.slab];
+                const float v2 = p[(size_t)(k + 2) * j.slab], v3 = p[(size_t)(k + 3) * j.slab];
+                a = (((a + v0) + v1) + v2) + v3;
+            }
+            for (; k < ns; ++k) a += p[(size_t)k * j.slab];
             a *= j.scale;
             float* out = (float*)j.dst;
             out[lin] = j.accumulate ? out[lin] + a : a;

@@ -88,25 +88,47 @@ __global__ __launch_bounds__(256) void colsum_final_k(const float* __restrict__ 
 }
 
 // ---- im2col: strided f32 source -> col[P][Kpad] (column (kh*KW+kw)*C + c) ----
+// one thread = 8 consecutive columns of one row (Kpad % 8 == 0): one 16-B (bf16) / two 16-B (f32) stores
 template <typename T>
 __global__ void im2col_k(const float* __restrict__ src, long sn, long sc, long sh, long sw, int N, int C, int IH,
                          int IW, int OH, int OW, int KH, int KW, int stride, int pad, int Kpad,
                          T* __restrict__ col) {
-    const long tot = (long)N * OH * OW * Kpad;
+    const int gpr = Kpad >> 3;                          // column groups per row
+    const long tot = (long)N * OH * OW * gpr;
+    const int kreal = KH * KW * C;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < tot; i += (long)gridDim.x * blockDim.x) {
-        const int kx = (int)(i % Kpad);
-        const long pp = i / Kpad;
-        float v = 0.f;
-        if (kx < KH * KW * C) {
-            const int t = kx / C, c = kx - t * C;
+        const int kg = (int)(i % gpr);
+        const long pp = i / gpr;
+        const int ow = (int)(pp % OW);
+        const long r = pp / OW;
+        const int oh = (int)(r % OH), n = (int)(r / OH);
+        const int ih0 = oh * stride - pad, iw0 = ow * stride - pad;
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int kx = kg * 8 + e;
+            const int kxc = kx < kreal ? kx : 0;
+            const int t = kxc / C, c = kxc - t * C;
             const int kh = t / KW, kw = t - kh * KW;
-            const int ow = (int)(pp % OW);
-            const long r = pp / OW;
-            const int oh = (int)(r % OH), n = (int)(r / OH);
-            const int ih = oh * stride - pad + kh, iw = ow * stride - pad + kw;
-            if (ih >= 0 && ih < IH && iw >= 0 && iw < IW) v = src[n * sn + c * sc + ih * sh + iw * sw];
+            const int ih = ih0 + kh, iw = iw0 + kw;
+            const bool ok = kx < kreal && ih >= 0 && ih < IH && iw >= 0 && iw < IW;
+            // clamped address: the load is unconditional (all 8 in flight), the select zeroes padding
+            const int ihc = min(max(ih, 0), IH - 1), iwc = min(max(iw, 0), IW - 1);
+            const float x = src[n * sn + c * sc + ihc * sh + iwc * sw];
+            v[e] = ok ? x : 0.f;
         }
-        Elem<T>::store(col + i, v);
+        T* dst = col + pp * Kpad + kg * 8;
+        if constexpr (sizeof(T) == 2) {
+            uint4 pk;
+            pk.x = (unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16);
+            pk.y = (unsigned)f32_to_bf16(v[2]) | ((unsigned)f32_to_bf16(v[3]) << 16);
+            pk.z = (unsigned)f32_to_bf16(v[4]) | ((unsigned)f32_to_bf16(v[5]) << 16);
+            pk.w = (unsigned)f32_to_bf16(v[6]) | ((unsigned)f32_to_bf16(v[7]) << 16);
+            *(uint4*)dst = pk;
+        } else {
+            *(float4*)dst = make_float4(v[0], v[1], v[2], v[3]);
+            *(float4*)(dst + 4) = make_float4(v[4], v[5], v[6], v[7]);
+        }
     }
 }
 
@@ -342,7 +364,8 @@ int rbvae_reduce_rows(const float* ws, int rows, int C, float* out, float scale,
 int rbvae_im2col(int dtype, const float* src, long sn, long sc, long sh, long sw, int N, int C, int IH, int IW,
                  int OH, int OW, int KH, int KW, int stride, int pad, int Kpad, void* col, void* stream) {
     RBVAE_CHECK_ARG(src && col && N > 0 && C > 0 && Kpad >= KH * KW * C, "im2col: bad arguments");
-    const long tot = (long)N * OH * OW * Kpad;
+    RBVAE_CHECK_ARG(Kpad % 8 == 0 && (uintptr_t)col % 16 == 0, "im2col: Kpad=%d must be a multiple of 8, col 16-byte aligned", Kpad);
+    const long tot = (long)N * OH * OW * (Kpad / 8);
     if (dtype == RBVAE_F32)
         hipLaunchKernelGGL(im2col_k<float>, dim3(grid_for(tot, 256, 8192)), dim3(256), 0, (hipStream_t)stream, src,
                            sn, sc, sh, sw, N, C, IH, IW, OH, OW, KH, KW, stride, pad, Kpad, (float*)col);

@@ -229,7 +229,8 @@ __device__ __forceinline__ void lds_barrier() {
 }
 
 template <int LMAX, bool VEC>
-__global__ __launch_bounds__(1024) void lstm_fwd_wave_k(const float* __restrict__ wblk, float* __restrict__ hs_all,
+__global__ __launch_bounds__(1024) void lstm_fwd_wave_k(const float* __restrict__ wblk, const float* __restrict__ wT,
+                                                        float* __restrict__ hs_all,
                                                         float* __restrict__ hprev, float* __restrict__ acts,
                                                         float* __restrict__ cs, int S, int T, int L, int layers,
                                                         int G) {
@@ -247,11 +248,13 @@ __global__ __launch_bounds__(1024) void lstm_fwd_wave_k(const float* __restrict_
     {
         const int jc = row ? j : 0;
         bsum = wl[8l * L * L + jc] + wl[8l * L * L + 4 * L + jc];
-        const float* pi = wl + jc * L;
-        const float* ph = pi + 4 * L * L;
+        // transposed copies ([k][gate row]): consecutive threads read consecutive addresses
+        const float* pi = wT ? wT + (long)(l * 2) * L * 4 * L + jc : wl + jc * L;
+        const float* ph = wT ? pi + L * 4 * L : pi + 4 * L * L;
+        const int kstride = wT ? 4 * L : 1;
 #pragma unroll
         for (int k = 0; k < LMAX; ++k) {
-            const int kk = k < L ? k : L - 1;
+            const int kk = (k < L ? k : L - 1) * kstride;
             const float a = pi[kk], b = ph[kk];
             wih[k] = k < L ? a : 0.f;
             whh[k] = k < L ? b : 0.f;
@@ -410,19 +413,20 @@ __global__ __launch_bounds__(1024) void lstm_bwd_wave_k(const float* __restrict_
     if (l == 0 && j < L) dx[((long)s * T) * L + j] = part[0 * L + j] + part[2 * L + j] + part[4 * L + j] + part[6 * L + j];
 }
 
-// Weight gradients, LDS-tiled: block = (32 gate rows, ih|hh, layer); thread (jj, kq) owns gate row jj and
-// the columns kq, kq+8, ... (column L = the bias).  Rows of dG / X stream through LDS 128 at a time.
+// Weight gradients, LDS-tiled: block = (8 gate rows, ih|hh, layer); thread (jj, kq) owns gate row jj and
+// the columns kq, kq+32, ... (column L = the bias).  Rows of dG / X stream through LDS 128 at a time.
 constexpr int LW_ROWS = 128;
-constexpr int LW_KMAX = 17;     // ceil((128 + 1) / 8)
+constexpr int LW_JT = 8;
+template <int LW_KMAX>          // ceil((L + 1) / 32): 2 for L <= 32, 3 for L <= 64, 5 for L <= 128
 __global__ __launch_bounds__(256) void lstm_wgrad_tiled_k(const float* __restrict__ dG, const float* __restrict__ hs_all,
                                                           const float* __restrict__ hprev, float* __restrict__ gblk,
                                                           int S, int T, int L, int accumulate) {
     extern __shared__ float sm[];
-    float* sg = sm;                      // [LW_ROWS][32 gate rows]
-    float* sx = sg + LW_ROWS * 32;       // [LW_ROWS][L]
-    const int l = blockIdx.z, hh = blockIdx.y, j0 = blockIdx.x * 32;
-    const int jj = threadIdx.x & 31, kq = threadIdx.x >> 5;
-    const int R = S * T;
+    float* sg = sm;                         // [LW_ROWS][LW_JT gate rows]
+    float* sx = sg + LW_ROWS * LW_JT;       // [LW_ROWS][L + 1]   (column L holds 1.0: the bias column)
+    const int l = blockIdx.z, hh = blockIdx.y, j0 = blockIdx.x * LW_JT;
+    const int jj = threadIdx.x & (LW_JT - 1), kq = threadIdx.x / LW_JT;     // kq in [0, 32)
+    const int R = S * T, LP = L + 1;
     const float* g = dG + (long)l * R * 4 * L;
     const float* x = hh ? hprev + (long)l * R * L : hs_all + (long)l * R * L;
     float acc[LW_KMAX];
@@ -430,11 +434,11 @@ __global__ __launch_bounds__(256) void lstm_wgrad_tiled_k(const float* __restric
     for (int i = 0; i < LW_KMAX; ++i) acc[i] = 0.f;
     for (int r0 = 0; r0 < R; r0 += LW_ROWS) {
         const int nr = min(LW_ROWS, R - r0);
-        // clamped indices: every load is unconditional, so the 16 loads of a thread are all in flight
+        // clamped indices: every load is unconditional, so a thread's loads are all in flight together
 #pragma unroll
-        for (int it = 0; it < LW_ROWS * 32 / 256; ++it) {
+        for (int it = 0; it < LW_ROWS * LW_JT / 256; ++it) {
             const int i = threadIdx.x + it * 256;
-            const int r = i >> 5, c = i & 31;
+            const int r = i / LW_JT, c = i & (LW_JT - 1);
             const float v = g[(long)(r0 + min(r, nr - 1)) * 4 * L + min(j0 + c, 4 * L - 1)];
             sg[i] = (r < nr && j0 + c < 4 * L) ? v : 0.f;
         }
@@ -443,17 +447,19 @@ __global__ __launch_bounds__(256) void lstm_wgrad_tiled_k(const float* __restric
             for (int it = 0; it < 8; ++it) {
                 const int i = i0 + threadIdx.x + it * 256;
                 const float v = x[(long)r0 * L + min(i, nr * L - 1)];
-                if (i < LW_ROWS * L) sx[i] = i < nr * L ? v : 0.f;
+                if (i < LW_ROWS * L) { const int r = i / L; sx[r * LP + (i - r * L)] = i < nr * L ? v : 0.f; }
             }
         }
+        if (threadIdx.x < LW_ROWS) sx[threadIdx.x * LP + L] = threadIdx.x < nr ? 1.f : 0.f;
         __syncthreads();
-        for (int r = 0; r < nr; ++r) {
-            const float gv = sg[r * 32 + jj];
-            const float* xr = sx + r * L;
+#pragma unroll 8
+        for (int r = 0; r < LW_ROWS; ++r) {
+            const float gv = sg[r * LW_JT + jj];
+            const float* xr = sx + r * LP;
 #pragma unroll
             for (int i = 0; i < LW_KMAX; ++i) {
-                const int k = kq + 8 * i;
-                if (k <= L) acc[i] = fmaf(gv, k < L ? xr[k] : 1.f, acc[i]);
+                const int k = min(kq + 32 * i, L);           // clamped: column L is the ones column
+                acc[i] = fmaf(gv, xr[k], acc[i]);
             }
         }
         __syncthreads();
@@ -463,7 +469,7 @@ __global__ __launch_bounds__(256) void lstm_wgrad_tiled_k(const float* __restric
     float* out = gblk + l * (8l * L * L + 8l * L);
 #pragma unroll
     for (int i = 0; i < LW_KMAX; ++i) {
-        const int k = kq + 8 * i;
+        const int k = kq + 32 * i;
         if (k > L) continue;
         float* dst = k < L ? out + (hh ? 4l * L * L : 0) + (long)jrow * L + k : out + 8l * L * L + (hh ? 4 * L : 0) + jrow;
         *dst = accumulate ? *dst + acc[i] : acc[i];
@@ -476,8 +482,8 @@ using namespace rbvae;
 
 extern "C" {
 
-int rbvae_lstm_fwd(const float* wblk, float* hs_all, float* hprev, float* acts, float* cs, int S, int T, int L,
-                   int layers, void* stream) {
+int rbvae_lstm_fwd(const float* wblk, const float* wT, float* hs_all, float* hprev, float* acts, float* cs, int S,
+                   int T, int L, int layers, void* stream) {
     RBVAE_CHECK_ARG(wblk && hs_all && S > 0 && T > 0 && L > 0 && layers > 0, "lstm_fwd: bad arguments");
     RBVAE_CHECK_ARG(L <= 128, "lstm_fwd: latent_dim %d > 128 is not supported", L);
     RBVAE_CHECK_ARG((acts == nullptr) == (cs == nullptr) && (acts == nullptr) == (hprev == nullptr),
@@ -490,10 +496,10 @@ int rbvae_lstm_fwd(const float* wblk, float* hs_all, float* hprev, float* acts, 
     const size_t wlds = (size_t)((layers + 1) * T * L + layers * 4 * L) * sizeof(float);
     if (L <= 32 && layers * threads <= 1024 && wlds <= 64 * 1024) {
         if (L % 4 == 0)
-            hipLaunchKernelGGL((lstm_fwd_wave_k<32, true>), dim3(S), dim3(layers * threads), wlds, st, wblk, hs_all,
+            hipLaunchKernelGGL((lstm_fwd_wave_k<32, true>), dim3(S), dim3(layers * threads), wlds, st, wblk, wT, hs_all,
                                hprev, acts, cs, S, T, L, layers, threads);
         else
-            hipLaunchKernelGGL((lstm_fwd_wave_k<32, false>), dim3(S), dim3(layers * threads), wlds, st, wblk, hs_all,
+            hipLaunchKernelGGL((lstm_fwd_wave_k<32, false>), dim3(S), dim3(layers * threads), wlds, st, wblk, wT, hs_all,
                                hprev, acts, cs, S, T, L, layers, threads);
         RBVAE_CHECK_LAUNCH("lstm_fwd_wave");
         return RBVAE_OK;
@@ -537,10 +543,18 @@ int rbvae_lstm_bwd(const float* wblk, const float* acts, const float* cs, const 
 int rbvae_lstm_wgrad(const float* dG, const float* hs_all, const float* hprev, float* gblk, int S, int T, int L,
                      int layers, int accumulate, void* stream) {
     RBVAE_CHECK_ARG(dG && hs_all && hprev && gblk && S > 0 && T > 0 && L > 0 && layers > 0, "lstm_wgrad: bad arguments");
-    dim3 grid(cdiv(4 * L, 32), 2, layers);
-    const size_t lds = (size_t)(LW_ROWS * 32 + LW_ROWS * L) * sizeof(float);
-    hipLaunchKernelGGL(lstm_wgrad_tiled_k, grid, dim3(256), lds, (hipStream_t)stream, dG, hs_all, hprev, gblk, S, T, L,
-                       accumulate);
+    dim3 grid(cdiv(4 * L, LW_JT), 2, layers);
+    const size_t lds = (size_t)(LW_ROWS * LW_JT + LW_ROWS * (L + 1)) * sizeof(float);
+    RBVAE_CHECK_ARG(lds <= 64 * 1024, "lstm_wgrad: L=%d too large", L);
+    if (L <= 32)
+        hipLaunchKernelGGL(lstm_wgrad_tiled_k<2>, grid, dim3(256), lds, (hipStream_t)stream, dG, hs_all, hprev, gblk, S,
+                           T, L, accumulate);
+    else if (L <= 64)
+        hipLaunchKernelGGL(lstm_wgrad_tiled_k<3>, grid, dim3(256), lds, (hipStream_t)stream, dG, hs_all, hprev, gblk, S,
+                           T, L, accumulate);
+    else
+        hipLaunchKernelGGL(lstm_wgrad_tiled_k<5>, grid, dim3(256), lds, (hipStream_t)stream, dG, hs_all, hprev, gblk, S,
+                           T, L, accumulate);
     RBVAE_CHECK_LAUNCH("lstm_wgrad");
     return RBVAE_OK;
 }

@@ -237,6 +237,9 @@ class Engine:
         self.V2f, self.V2d = z(c2, kk, c1), z(c1, kk, c2)   # deconv1: c2 -> c1
         self.V3p = z(self.NY, c1)                      # [(t,co)][c1]: per-tap products of the last deconv
         self.V3f = z(c1, self.K3)                      # [c1][(t,co) padded]
+        nl, Ld = self.v.lstm_layers, self.latent
+        self.wT_enc = torch.zeros(nl, 2, Ld, 4 * Ld, dtype=torch.float32, device=self.device)   # [k][gate row]
+        self.wT_dec = torch.zeros(nl, 2, Ld, 4 * Ld, dtype=torch.float32, device=self.device)
 
     def pack(self, flat: torch.Tensor):
         """f32 parameters (reference layouts) -> the packed T copies the GEMMs read (one launch)."""
@@ -276,6 +279,11 @@ class Engine:
         pk(wd, self.Wdfc, (c3, g3, self.latent), (self.Lp, c3 * self.Lp, 1))
         pk(wd, self.WdfcT, (c3, g3, self.latent), (1, c3, self.F3))
         pk(P("decoder_cnn.fc.bias"), self.bdfc, (c3, g3, 1), (1, c3, 0), F32)
+        Ld = self.latent
+        for stack, wT in (("encoder_rnn", self.wT_enc), ("decoder_rnn", self.wT_dec)):
+            for l in range(self.v.lstm_layers):
+                for m, nm in enumerate(("weight_ih", "weight_hh")):
+                    pk(P(f"{stack}.lstm.{nm}_l{l}"), wT[l, m], (4 * Ld, Ld, 1), (1, 4 * Ld, 0), F32)
         return jl
 
     # ---- helpers ---------------------------------------------------------------
@@ -331,8 +339,10 @@ class Engine:
         """wgrad GEMM into K-slice slabs; their fixed-order reduction into the torch layout is a job."""
         bm = 128 if (Co > 64 and Ci > 64) else 64
         blocks = -(-Co // bm) * -(-Ci // bm) * taps
-        ks = max(1, min(32, 512 // max(blocks, 1), P // 256 if P >= 256 else 1))
-        ks = max(ks, -(-P // 4096))            # the kernel keeps a K-slice's gather indices in LDS
+        # K-slices: enough workgroups to cover the chip (~2 per CU), each with >= 256 pixels, and at most
+        # ~16 MB of f32 slabs to reduce afterwards
+        ks = max(1, min(256, 512 // max(blocks, 1), P // 256 if P >= 256 else 1,
+                        max(1, (4 << 20) // (Co * taps * Ci))))
         slabs = self._buf(("slabs", tag), ks * Co * taps * Ci)
         L.call("rbvae_wgrad_gemm", self.dt, Dy, In, slabs, idx, self.zero, P, Co, Ci, ldy, ldi, taps, ks)
         self._jobs.add(JOB_PERMUTE, slabs, out, dims, strides, nslab=ks, slab=Co * taps * Ci)
@@ -425,22 +435,22 @@ class Engine:
         kl = self._E(1, dtype=torch.float32) if kl_p is not None else None
         wenc, wdec = P("encoder_rnn.lstm.weight_ih_l0"), P("decoder_rnn.lstm.weight_ih_l0")
         if not v.simple_order:
-            L.call("rbvae_lstm_fwd", wenc, sv.hs_enc, sv.hp_enc, sv.acts_enc, sv.cs_enc, S, T, Ld, nl)
+            L.call("rbvae_lstm_fwd", wenc, self.wT_enc, sv.hs_enc, sv.hp_enc, sv.acts_enc, sv.cs_enc, S, T, Ld, nl)
             hs = sv.hs_enc[nl]
             sv.z = sv.hs_dec[0].view(N, Ld)
             L.call("rbvae_binarize_kl_fwd", hs, U, sv.y, sv.z, kl, N, Ld, float(tau), float(r), v.eps, int(hard),
                    float(kl_p if kl_p is not None else 0.5), 1e-8, 1, int(seed) * 8 + 5, self.seed_dev)
             if encode_only:
                 return {"z": sv.z.view(S, T, Ld), "hs": hs, "saved": sv}
-            L.call("rbvae_lstm_fwd", wdec, sv.hs_dec, sv.hp_dec, sv.acts_dec, sv.cs_dec, S, T, Ld, nl)
+            L.call("rbvae_lstm_fwd", wdec, self.wT_dec, sv.hs_dec, sv.hp_dec, sv.acts_dec, sv.cs_dec, S, T, Ld, nl)
         else:
             sv.z = sv.hs_enc[0].view(N, Ld)
             L.call("rbvae_binarize_kl_fwd", sv.e, U, sv.y, sv.z, None, N, Ld, float(tau), float(r), v.eps, int(hard),
                    0.5, 1e-10, 0, int(seed) * 8 + 5, self.seed_dev)
-            L.call("rbvae_lstm_fwd", wenc, sv.hs_enc, sv.hp_enc, sv.acts_enc, sv.cs_enc, S, T, Ld, nl)
+            L.call("rbvae_lstm_fwd", wenc, self.wT_enc, sv.hs_enc, sv.hp_enc, sv.acts_enc, sv.cs_enc, S, T, Ld, nl)
             hs = sv.hs_enc[nl]
             sv.hs_dec[0].copy_(hs)
-            L.call("rbvae_lstm_fwd", wdec, sv.hs_dec, sv.hp_dec, sv.acts_dec, sv.cs_dec, S, T, Ld, nl)
+            L.call("rbvae_lstm_fwd", wdec, self.wT_dec, sv.hs_dec, sv.hp_dec, sv.acts_dec, sv.cs_dec, S, T, Ld, nl)
         ds = sv.hs_dec[nl]
         # decoder CNN
         sv.ds_pad = self._E(N, self.Lp)

@@ -161,7 +161,7 @@ def test_lstm_forward_backward(sfv, L, layers, S, T):
     hs[0] = x.detach().cuda()
     hp, cs, acts = torch.empty(layers, S, T, L, device="cuda"), torch.empty(layers, S, T, L, device="cuda"), \
         torch.empty(layers, S, T, 4 * L, device="cuda")
-    sfv._lib.call("rbvae_lstm_fwd", wblk, hs, hp, acts, cs, S, T, L, layers)
+    sfv._lib.call("rbvae_lstm_fwd", wblk, None, hs, hp, acts, cs, S, T, L, layers)
     np.testing.assert_allclose(hs[layers].cpu().numpy(), y.detach().numpy(), atol=2e-6)
     dG, dx = torch.empty(layers, S, T, 4 * L, device="cuda"), torch.empty(S, T, L, device="cuda")
     sfv._lib.call("rbvae_lstm_bwd", wblk, acts, cs, gt.cuda(), dG, dx, S, T, L, layers)
