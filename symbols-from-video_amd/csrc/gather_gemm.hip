@@ -102,7 +102,7 @@ template <int N> __device__ __forceinline__ void wait_vmcnt_barrier() {
 // GG_NS = LDS ring depth.  3: two K-slices in flight behind the one being multiplied (one workgroup per
 // CU, deep K); 2: classic double buffer, two workgroups per CU; 1: single buffer for 1-2 slice problems
 // where four workgroups per CU overlap each other's load / store latencies instead.
-template <typename T, int NT, int WAVES, int GG_NS>
+template <typename T, int NT, int WAVES, int GG_NS, int DBG = 0>
 __global__ __launch_bounds__(WAVES * 64, 1) void gather_gemm_k(const GgArgs p) {
     constexpr int THREADS = WAVES * 64;
     constexpr int BN = NT * 32;
@@ -123,7 +123,8 @@ __global__ __launch_bounds__(WAVES * 64, 1) void gather_gemm_k(const GgArgs p) {
     int* s_orow = (int*)(smem + RING);           // [128]
     int* s_tap = s_orow + GG_BM;                 // [16][4]: widx, dh, dw of this class
 
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave id, provably uniform (scalar LDS addressing)
     const TapClass& tc = p.cls[blockIdx.z];
     const int Mc = p.Nimg * p.TH * p.TW;
     const int m0 = blockIdx.x * GG_BM, n0 = blockIdx.y * BN;
@@ -179,30 +180,40 @@ __global__ __launch_bounds__(WAVES * 64, 1) void gather_gemm_k(const GgArgs p) {
     const int kchunks = p.Kc / KE;
     const int nsteps = ntaps * kchunks;
 
-    // producer state: the (tap, k-chunk) of the next slice to stage
-    const unsigned char* aptr[A_INSTR];
-    size_t woff = 0;
+    // producer state: the (tap, k-chunk) of the next slice to stage.  Per tap every row gets a current
+    // source pointer and a per-chunk stride (128 B, or 0 for rows that read the zero page), so staging a
+    // slice costs one 64-bit add per LDS-DMA instruction.
+    const unsigned char* acur[A_INSTR];
+    unsigned astep[A_INSTR];
+    const unsigned char* bcur[B_INSTR];
     int pj = -1, pkc = 0, pbuf = 0;
     auto tap_setup = [&](int j) {
         const int widx = s_tap[j * 4 + 0], dh = s_tap[j * 4 + 1], dw = s_tap[j * 4 + 2];
-        woff = ((size_t)widx * p.Kc) * ES;
+        const size_t woff = ((size_t)widx * p.Kc) * ES;
 #pragma unroll
         for (int i = 0; i < A_INSTR; ++i) {
             const int ih = aa[i] * p.sa + dh, iw = ab[i] * p.sa + dw;
             const bool v = an[i] >= 0 && ih >= 0 && ih < p.IH && iw >= 0 && iw < p.IW;
-            aptr[i] = v ? p.A + ((size_t)((an[i] * p.IH + ih) * p.IW + iw) * p.lda) * ES + a_sw[i] : nullptr;
+            acur[i] = v ? p.A + ((size_t)((an[i] * p.IH + ih) * p.IW + iw) * p.lda) * ES + a_sw[i] : zsrc;
+            astep[i] = v ? 128u : 0u;
         }
+#pragma unroll
+        for (int i = 0; i < B_INSTR; ++i) bcur[i] = bval[i] ? bptr[i] + woff : zsrc;
     };
     auto stage_next = [&]() {
         if (pj < 0 || pkc == kchunks) { ++pj; pkc = 0; tap_setup(pj); }
         unsigned char* la = smem + pbuf * STAGE + (w * A_INSTR) * 1024;
 #pragma unroll
-        for (int i = 0; i < A_INSTR; ++i)
-            glds16(aptr[i] ? aptr[i] + (size_t)pkc * 128 : zsrc, la + i * 1024);
+        for (int i = 0; i < A_INSTR; ++i) {
+            glds16(acur[i], la + i * 1024);
+            acur[i] += astep[i];
+        }
         unsigned char* lb = smem + pbuf * STAGE + A_BYTES + (w * B_INSTR) * 1024;
 #pragma unroll
-        for (int i = 0; i < B_INSTR; ++i)
-            glds16(bval[i] ? bptr[i] + woff + (size_t)pkc * 128 : zsrc, lb + i * 1024);
+        for (int i = 0; i < B_INSTR; ++i) {
+            glds16(bcur[i], lb + i * 1024);
+            bcur[i] += bval[i] ? 128 : 0;
+        }
         ++pkc;
         pbuf = (pbuf + 1 == GG_NS) ? 0 : pbuf + 1;
     };
@@ -234,6 +245,9 @@ __global__ __launch_bounds__(WAVES * 64, 1) void gather_gemm_k(const GgArgs p) {
 #pragma unroll
             for (int nt = 0; nt < NTW; ++nt) fb[kk][nt] = *(const u32x4_t*)(lbase + offB[kk] + nt * 2048);
         }
+        // pin the order: every fragment read of the slice is in flight before the first MFMA, so the LDS
+        // serves the second half while the matrix pipe works on the first (counted lgkmcnt waits follow)
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
@@ -260,8 +274,8 @@ __global__ __launch_bounds__(WAVES * 64, 1) void gather_gemm_k(const GgArgs p) {
                 wait_vmcnt_barrier<(GG_NS > 2 ? GG_NS - 2 : 0) * LOADS>();
             else
                 wait_vmcnt_barrier<0>();      // tail (or double buffer): nothing younger is in flight
-            if (s + GG_NS - 1 < nsteps) stage_next();   // refills the buffer multiplied in step s-1
-            multiply(smem + cbuf * STAGE);
+            if (s + GG_NS - 1 < nsteps && DBG != 1) stage_next();   // refills the buffer multiplied in step s-1
+            if (DBG != 2) multiply(smem + cbuf * STAGE);
             cbuf = (cbuf + 1 == GG_NS) ? 0 : cbuf + 1;
         }
     }
@@ -355,7 +369,7 @@ __global__ __launch_bounds__(WAVES * 64, 1) void gather_gemm_k(const GgArgs p) {
     }
 }
 
-template <typename T, int NT, int WAVES, int NS>
+template <typename T, int NT, int WAVES, int NS, int DBG = 0>
 static int launch_gg(const GgArgs& a, hipStream_t st) {
     constexpr int BN = NT * 32;
     constexpr int ES = sizeof(T);
@@ -365,12 +379,12 @@ static int launch_gg(const GgArgs& a, hipStream_t st) {
     const size_t lds = (ring > tile ? ring : tile) + GG_BM * sizeof(int) + 64 * sizeof(int);
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute((const void*)gather_gemm_k<T, NT, WAVES, NS>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        hipFuncSetAttribute((const void*)gather_gemm_k<T, NT, WAVES, NS, DBG>, hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)lds);
         attr_set = true;
     }
     dim3 grid(cdiv(Mc, GG_BM), cdiv(a.Nout, BN), a.nclass);
-    hipLaunchKernelGGL((gather_gemm_k<T, NT, WAVES, NS>), grid, dim3(WAVES * 64), lds, st, a);
+    hipLaunchKernelGGL((gather_gemm_k<T, NT, WAVES, NS, DBG>), grid, dim3(WAVES * 64), lds, st, a);
     RBVAE_CHECK_LAUNCH("gather_gemm");
     return RBVAE_OK;
 }
@@ -384,6 +398,10 @@ static int dispatch_gg(const GgArgs& a, hipStream_t st, int max_steps) {
     if (a.Nout <= 64) return ns == 1 ? launch_gg<T, 2, 4, 1>(a, st) : launch_gg<T, 2, 4, 2>(a, st);
     if (ns == 1) return launch_gg<T, 4, 4, 1>(a, st);
     if (ns == 2) return launch_gg<T, 4, 8, 2>(a, st);
+    static const int dbg = getenv("RBVAE_GG_DBG") ? atoi(getenv("RBVAE_GG_DBG")) : 0;
+    if (dbg == 1) return launch_gg<T, 4, 8, 3, 1>(a, st);
+    if (dbg == 2) return launch_gg<T, 4, 8, 3, 2>(a, st);
+    if (ns >= 4) return launch_gg<T, 4, 8, 4>(a, st);
     return launch_gg<T, 4, 8, 3>(a, st);
 }
 

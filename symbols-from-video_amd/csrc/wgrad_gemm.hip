@@ -8,8 +8,9 @@
 // the LDS image's ROW: fragments are read with the transposing LDS read
 // (ds_read_b64_tr_b16) for bf16 and with plain dword reads for f32.
 //
-// Tile: (32*MT) x (32*NT) (co x ci) per 256-thread workgroup, 32 pixels per K step,
-// double-buffered LDS-DMA staging.  grid = (co tiles, ci tiles, taps * ksplit); each
+// Tile: 128 x (64*NT) (co x ci) per 512-thread workgroup (8 waves, two per SIMD), 32 pixels per K
+// step, a 3-deep LDS-DMA ring with counted vmcnt waits; the K-slice's gather indices are read into
+// LDS once so no register load sits between the LDS-DMA issues.  grid = (co tiles, ci tiles, taps * ksplit); each
 // K-slice writes its own f32 slab (summed later in a fixed order by
 // rbvae_permute_reduce, so gradients are bitwise reproducible -- no float atomics).
 #include "common.h"
@@ -41,31 +42,48 @@ template <int RB> __device__ __forceinline__ int tr_swz(int row) {
     else return (((row >> 1) & 1) | (((row >> 3) & 1) << 1)) << 1;                // 128-B rows: 4 pairs
 }
 
-constexpr int WG_BK = 32;   // pixels per K step
+constexpr int WG_BK = 32;       // pixels per K step
+constexpr int WG_BM = 128;      // co per workgroup
+constexpr int WG_NS = 3;        // LDS ring depth (two K steps in flight behind the one being multiplied)
+constexpr int WG_MAXP = 4096;   // pixels of one K-slice (their gather indices live in LDS)
 
-template <typename T, int MT, int NT>   // wave tile = (16*MT) x (16*NT); block = 2x2 waves
-__global__ __launch_bounds__(256, 2) void wgrad_gemm_k(const WgArgs p) {
+template <int N> __device__ __forceinline__ void wg_wait_barrier() {
+    asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::"n"(N) : "memory");
+}
+
+// 8 waves as 2 (co) x 4 (ci); a wave owns 64 co x 16*NT ci; BN = 64*NT ci per workgroup.
+template <typename T, int NT>
+__global__ __launch_bounds__(512, 1) void wgrad_gemm_k(const WgArgs p) {
     constexpr int ES = sizeof(T);
-    constexpr int BM = 32 * MT, BN = 32 * NT;
+    constexpr int MT = 4;
+    constexpr int BM = WG_BM, BN = 64 * NT;
     constexpr int RBA = BM * ES, RBB = BN * ES;           // image row bytes
     constexpr int A_BYTES = WG_BK * RBA, B_BYTES = WG_BK * RBB;
-    constexpr int A_INSTR = A_BYTES / 1024 / 4, B_INSTR = B_BYTES / 1024 / 4;   // LDS-DMA per wave per step
-    static_assert(A_INSTR >= 1 && B_INSTR >= 1, "tile too small for 4 staging waves");
+    constexpr int STAGE = A_BYTES + B_BYTES;
+    constexpr int A_TOT = A_BYTES / 1024, B_TOT = B_BYTES / 1024;   // LDS-DMA instructions per stage
+    constexpr int A_INSTR = A_TOT / 8;                               // per wave (A_TOT is 8 or 16)
+    constexpr int B_INSTR = (B_TOT + 7) / 8;                         // waves >= B_TOT issue none when B_TOT < 8
     constexpr bool SWZ = (ES == 2);
-    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * A_BYTES + 2 * B_BYTES];
-    unsigned char* sA = smem;
-    unsigned char* sB = smem + 2 * A_BYTES;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    int* s_idx = (int*)(smem + WG_NS * STAGE);            // [WG_MAXP]
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int co0 = blockIdx.x * BM, ci0 = blockIdx.y * BN;
     const int tap = blockIdx.z / p.ksplit, ks = blockIdx.z - tap * p.ksplit;
     const int pbeg = ks * p.Pper;
     const int pend = min(p.P, pbeg + p.Pper);
-    const int nsteps = (pend - pbeg + WG_BK - 1) / WG_BK;
-    const int* idx = p.idx ? p.idx + (size_t)tap * p.P : nullptr;
+    const int npix = max(pend - pbeg, 0);
+    const int nsteps = (npix + WG_BK - 1) / WG_BK;
 
-    // staging roles.  One instruction = 1 KiB = (1024/RB) image rows; wave w issues
-    // instructions w*INSTR .. of each image.
+    // gather indices of this K-slice -> LDS (identity when there is no table)
+    {
+        const int* idx = p.idx ? p.idx + (size_t)tap * p.P + pbeg : nullptr;
+        const int padded = nsteps * WG_BK;
+        for (int i = tid; i < padded; i += 512) s_idx[i] = i < npix ? (idx ? idx[i] : pbeg + i) : -1;
+    }
+    __syncthreads();
+
+    // staging roles.  One instruction = 1 KiB = (1024/RB) image rows.
     constexpr int A_LPR = RBA / 16, B_LPR = RBB / 16;     // lanes (chunks) per row
     constexpr int A_RPI = 64 / A_LPR, B_RPI = 64 / B_LPR; // rows per instruction
     int a_row[A_INSTR], a_coff[A_INSTR];
@@ -78,42 +96,41 @@ __global__ __launch_bounds__(256, 2) void wgrad_gemm_k(const WgArgs p) {
         a_coff[i] = c * 16;
         a_cval[i] = co0 + c * (16 / ES) < p.Co;
     }
+    const bool b_wave = (w * B_INSTR) < B_TOT;            // does this wave stage part of B?
     int b_row[B_INSTR], b_coff[B_INSTR];
     bool b_cval[B_INSTR];
 #pragma unroll
     for (int i = 0; i < B_INSTR; ++i) {
         const int r = (w * B_INSTR + i) * B_RPI + lane / B_LPR;
-        const int c = (lane % B_LPR) ^ (SWZ ? tr_swz<RBB>(r) : 0);
-        b_row[i] = r;
+        const int c = (lane % B_LPR) ^ (SWZ ? tr_swz<RBB>(r & (WG_BK - 1)) : 0);
+        b_row[i] = r & (WG_BK - 1);
         b_coff[i] = c * 16;
-        b_cval[i] = ci0 + c * (16 / ES) < p.Ci;
+        b_cval[i] = b_wave && ci0 + c * (16 / ES) < p.Ci;
     }
-
-    int b_src[B_INSTR];          // gathered In row of the NEXT step to stage
-    auto load_idx = [&](int step) {
-#pragma unroll
-        for (int i = 0; i < B_INSTR; ++i) {
-            const int pp = pbeg + step * WG_BK + b_row[i];
-            b_src[i] = (pp < pend) ? (idx ? idx[pp] : pp) : -1;
-        }
-    };
-    auto stage = [&](int step, int buf) {
-        unsigned char* la = sA + buf * A_BYTES + (w * A_INSTR) * 1024;
+    int pstep = 0, pbuf = 0;
+    auto stage_next = [&]() {
+        unsigned char* la = smem + pbuf * STAGE + (w * A_INSTR) * 1024;
+        const int base = pstep * WG_BK;
 #pragma unroll
         for (int i = 0; i < A_INSTR; ++i) {
-            const int pp = pbeg + step * WG_BK + a_row[i];
-            const bool v = a_cval[i] && pp < pend;
-            glds16w(v ? p.Dy + ((size_t)pp * p.ldy + co0) * ES + a_coff[i] : p.zero, la + i * 1024);
+            const int pp = base + a_row[i];
+            const bool v = a_cval[i] && pp < npix;
+            glds16w(v ? p.Dy + ((size_t)(pbeg + pp) * p.ldy + co0) * ES + a_coff[i] : p.zero, la + i * 1024);
         }
-        unsigned char* lb = sB + buf * B_BYTES + (w * B_INSTR) * 1024;
+        if (b_wave) {
+            unsigned char* lb = smem + pbuf * STAGE + A_BYTES + (w * B_INSTR) * 1024;
 #pragma unroll
-        for (int i = 0; i < B_INSTR; ++i) {
-            const bool v = b_cval[i] && b_src[i] >= 0;
-            glds16w(v ? p.In + ((size_t)b_src[i] * p.ldi + ci0) * ES + b_coff[i] : p.zero, lb + i * 1024);
+            for (int i = 0; i < B_INSTR; ++i) {
+                const int src = s_idx[base + b_row[i]];
+                const bool v = b_cval[i] && src >= 0;
+                glds16w(v ? p.In + ((size_t)src * p.ldi + ci0) * ES + b_coff[i] : p.zero, lb + i * 1024);
+            }
         }
+        ++pstep;
+        pbuf = (pbuf + 1 == WG_NS) ? 0 : pbuf + 1;
     };
 
-    const int wr = w >> 1, wc = w & 1;
+    const int wr = w >> 2, wc = w & 3;
     const int fi = lane & 15, fg = lane >> 4;
     f32x4_t acc[MT][NT];
 #pragma unroll
@@ -135,38 +152,25 @@ __global__ __launch_bounds__(256, 2) void wgrad_gemm_k(const WgArgs p) {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
             const int chunk = ((wc * NT + nt) * 2 + (pp >> 1)) ^ tr_swz<RBB>(row);
-            offB[nt] = row * RBB + chunk * 16 + (pp & 1) * 8;
+            offB[nt] = A_BYTES + row * RBB + chunk * 16 + (pp & 1) * 8;
         }
     } else {
         // f32: lane (i, g) reads element (row 4s+g, channel cb+i)
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) offA[mt] = fg * RBA + ((wr * MT + mt) * 16 + fi) * 4;
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) offB[nt] = fg * RBB + ((wc * NT + nt) * 16 + fi) * 4;
+        for (int nt = 0; nt < NT; ++nt) offB[nt] = A_BYTES + fg * RBB + ((wc * NT + nt) * 16 + fi) * 4;
     }
 
-    if (nsteps > 0) {
-        load_idx(0);
-        stage(0, 0);
-        if (nsteps > 1) load_idx(1);
-    }
-    for (int s = 0; s < nsteps; ++s) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (s + 1 < nsteps) {
-            stage(s + 1, (s + 1) & 1);
-            if (s + 2 < nsteps) load_idx(s + 2);
-        }
-        const unsigned char* la = sA + (s & 1) * A_BYTES;
-        const unsigned char* lb = sB + (s & 1) * B_BYTES;
+    auto multiply = [&](const unsigned char* lb) {
         if constexpr (ES == 2) {
             bf16x8_t fa[MT], fb[NT];
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
                 const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                    (__attribute__((address_space(3))) s16x4_t*)(la + offA[mt]));
+                    (__attribute__((address_space(3))) s16x4_t*)(lb + offA[mt]));
                 const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                    (__attribute__((address_space(3))) s16x4_t*)(la + offA[mt] + 4 * RBA));
+                    (__attribute__((address_space(3))) s16x4_t*)(lb + offA[mt] + 4 * RBA));
                 fa[mt] = bf16x8_t{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
             }
 #pragma unroll
@@ -177,17 +181,18 @@ __global__ __launch_bounds__(256, 2) void wgrad_gemm_k(const WgArgs p) {
                     (__attribute__((address_space(3))) s16x4_t*)(lb + offB[nt] + 4 * RBB));
                 fb[nt] = bf16x8_t{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
             }
+            __builtin_amdgcn_sched_barrier(0);      // all transposed reads in flight before the first MFMA
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
+            for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt)
+                for (int mt = 0; mt < MT; ++mt)
                     acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[nt], fa[mt], acc[mt][nt], 0, 0, 0);
         } else {
 #pragma unroll
             for (int sub = 0; sub < WG_BK / 4; ++sub) {
                 float fa[MT], fb[NT];
 #pragma unroll
-                for (int mt = 0; mt < MT; ++mt) fa[mt] = *(const float*)(la + offA[mt] + sub * 4 * RBA);
+                for (int mt = 0; mt < MT; ++mt) fa[mt] = *(const float*)(lb + offA[mt] + sub * 4 * RBA);
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) fb[nt] = *(const float*)(lb + offB[nt] + sub * 4 * RBB);
 #pragma unroll
@@ -197,6 +202,25 @@ __global__ __launch_bounds__(256, 2) void wgrad_gemm_k(const WgArgs p) {
                         acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(fb[nt], fa[mt], acc[mt][nt], 0, 0, 0);
             }
         }
+    };
+
+    // this wave's LDS-DMA count per stage (waves that stage no B rows issue fewer)
+    const int my_loads = A_INSTR + (b_wave ? B_INSTR : 0);
+#pragma unroll
+    for (int i = 0; i < WG_NS - 1; ++i)
+        if (i < nsteps) stage_next();
+    int cbuf = 0;
+    for (int s = 0; s < nsteps; ++s) {
+        if (nsteps - s - 1 >= WG_NS - 2) {
+            // WG_NS-2 younger stages stay in flight; the immediate must match this wave's own load count
+            if (my_loads == A_INSTR + B_INSTR) wg_wait_barrier<(WG_NS - 2) * (A_INSTR + B_INSTR)>();
+            else wg_wait_barrier<(WG_NS - 2) * A_INSTR>();
+        } else {
+            wg_wait_barrier<0>();       // tail: drain (conservative)
+        }
+        if (s + WG_NS - 1 < nsteps) stage_next();
+        multiply(smem + cbuf * STAGE);
+        cbuf = (cbuf + 1 == WG_NS) ? 0 : cbuf + 1;
     }
 
     // D[row = ci 4g+r][col = co i]: lane owns 4 consecutive ci of one co -> one 16-B store
@@ -228,10 +252,17 @@ __global__ void conv_gather_index_k(int* __restrict__ idx, int Nimg, int IH, int
     idx[i] = (ih >= 0 && ih < IH && iw >= 0 && iw < IW) ? (n * IH + ih) * IW + iw : -1;
 }
 
-template <typename T, int MT, int NT>
+template <typename T, int NT>
 static int launch_wg(const WgArgs& a, hipStream_t st) {
-    dim3 grid(cdiv(a.Co, 32 * MT), cdiv(a.Ci, 32 * NT), a.taps * a.ksplit);
-    hipLaunchKernelGGL((wgrad_gemm_k<T, MT, NT>), grid, dim3(256), 0, st, a);
+    constexpr int ES = sizeof(T);
+    const size_t lds = (size_t)WG_NS * WG_BK * (WG_BM + 64 * NT) * ES + WG_MAXP * sizeof(int);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute((const void*)wgrad_gemm_k<T, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    dim3 grid(cdiv(a.Co, WG_BM), cdiv(a.Ci, 64 * NT), a.taps * a.ksplit);
+    hipLaunchKernelGGL((wgrad_gemm_k<T, NT>), grid, dim3(512), lds, st, a);
     RBVAE_CHECK_LAUNCH("wgrad_gemm");
     return RBVAE_OK;
 }
@@ -272,10 +303,12 @@ int rbvae_wgrad_gemm(int dtype, const void* Dy, const void* In, float* dW_slabs,
     a.zero = (const unsigned char*)zero_page;
     a.P = P; a.Co = Co; a.Ci = Ci; a.ldy = ldy; a.ldi = ldi; a.taps = taps; a.ksplit = ksplit;
     a.Pper = ((cdiv(P, ksplit) + WG_BK - 1) / WG_BK) * WG_BK;
+    RBVAE_CHECK_ARG(a.Pper <= WG_MAXP, "wgrad_gemm: %d pixels per K-slice exceed %d: raise ksplit (>= %d)", a.Pper,
+                    WG_MAXP, cdiv(P, WG_MAXP));
     hipStream_t st = (hipStream_t)stream;
-    const bool big = Co > 64 && Ci > 64;
-    if (dtype == RBVAE_F32) return big ? launch_wg<float, 4, 4>(a, st) : launch_wg<float, 2, 2>(a, st);
-    return big ? launch_wg<bf16_t, 4, 4>(a, st) : launch_wg<bf16_t, 2, 2>(a, st);
+    const bool wide = Ci > 64;
+    if (dtype == RBVAE_F32) return wide ? launch_wg<float, 2>(a, st) : launch_wg<float, 1>(a, st);
+    return wide ? launch_wg<bf16_t, 2>(a, st) : launch_wg<bf16_t, 1>(a, st);
 }
 
 }  // extern "C"

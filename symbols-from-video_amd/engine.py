@@ -218,6 +218,11 @@ class Engine:
         self._bufs: Dict = {}          # persistent backward temporaries, keyed by (N, tag)
         self._bwd_tab: Dict = {}       # uploaded reduce-job tables, keyed by their signature
         self._jobs: Optional[JobList] = None
+        self._side: Optional[torch.cuda.Stream] = None
+        # run wgrad / bias-grad kernels on a side stream beside the dgrad chain (measured slower on MI355X at
+        # the bench shapes: every kernel already spans all CUs, so the fork only adds dependency edges)
+        import os
+        self.overlap = os.environ.get("RBVAE_OVERLAP", "0") == "1"
         self._alloc_packed()
 
     # ---- packed weights -------------------------------------------------------
@@ -337,22 +342,48 @@ class Engine:
 
     def _wgrad(self, Dy, In, idx, P, Co, Ci, ldy, ldi, taps, out, dims, strides, tag=None):
         """wgrad GEMM into K-slice slabs; their fixed-order reduction into the torch layout is a job."""
-        bm = 128 if (Co > 64 and Ci > 64) else 64
-        blocks = -(-Co // bm) * -(-Ci // bm) * taps
+        blocks = -(-Co // 128) * -(-Ci // (128 if Ci > 64 else 64)) * taps
         # K-slices: enough workgroups to cover the chip (~2 per CU), each with >= 256 pixels, and at most
         # ~16 MB of f32 slabs to reduce afterwards
         ks = max(1, min(256, 512 // max(blocks, 1), P // 256 if P >= 256 else 1,
                         max(1, (4 << 20) // (Co * taps * Ci))))
+        ks = max(ks, -(-P // 4096))            # the kernel keeps a K-slice's gather indices in LDS (<= 4096)
         slabs = self._buf(("slabs", tag), ks * Co * taps * Ci)
+        side = self._side_begin()
         L.call("rbvae_wgrad_gemm", self.dt, Dy, In, slabs, idx, self.zero, P, Co, Ci, ldy, ldi, taps, ks)
+        self._side_end(side)
         self._jobs.add(JOB_PERMUTE, slabs, out, dims, strides, nslab=ks, slab=Co * taps * Ci)
 
     def _colsum(self, dt, X, P, C, ld, out, tag=None):
         """Column sums of a tensor no GEMM epilogue produced: partial kernel now, final reduction as a job."""
         nf = L.query("rbvae_colsum_ws_floats", P, C)
         ws = self._buf(("cs", tag), nf)
+        side = self._side_begin()
         L.call("rbvae_colsum_partial", dt, X, P, C, ld, ws)
+        self._side_end(side)
         self._jobs.add(JOB_ROWS, ws, out, (1, 1, C), (0, 0, 1), nslab=nf // C, slab=C)
+
+    # ---- side stream: weight-gradient work runs beside the data-gradient chain -------------------
+    def _side_begin(self):
+        """Fork: work issued until _side_end() runs on the side stream, after everything already queued
+        on the main stream.  (Inside HIP-graph capture this becomes a fork edge of the graph.)"""
+        if not self.overlap:
+            return None
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=self.device)
+        main = torch.cuda.current_stream()
+        self._side.wait_stream(main)
+        ctx = torch.cuda.stream(self._side)
+        ctx.__enter__()
+        return ctx
+
+    def _side_end(self, ctx):
+        if ctx is not None:
+            ctx.__exit__(None, None, None)
+
+    def _side_join(self):
+        if self.overlap and self._side is not None:
+            torch.cuda.current_stream().wait_stream(self._side)
 
     def _run_jobs(self):
         jl, self._jobs = self._jobs, None
@@ -544,7 +575,9 @@ class Engine:
         # --- decoder fc: bias = per (position, channel) sum over frames, permuted to the torch (c, hw) order
         nf = L.query("rbvae_colsum_ws_floats", N, self.F3)
         wsf = self._buf((N, "bdfc"), nf)
+        side = self._side_begin()
         L.call("rbvae_colsum_partial", self.dt, df, N, self.F3, self.F3, wsf)
+        self._side_end(side)
         self._jobs.add(JOB_PERMUTE, wsf, G("decoder_cnn.fc.bias"), (c3, g3, 1), (1, c3, 0), nslab=nf // self.F3,
                        slab=self.F3)
         self._wgrad(df, sv.ds_pad, None, N, self.F3, self.Lp, self.F3, self.Lp, 1, G("decoder_cnn.fc.weight"),
@@ -553,10 +586,13 @@ class Engine:
         L.call("rbvae_skinny_linear", self.dt, df, self.WdfcT, None, dds, N, Ld, self.F3, self.F3, self.F3, Ld)
         # --- decoder LSTM
         wenc, wdec = P("encoder_rnn.lstm.weight_ih_l0"), P("decoder_rnn.lstm.weight_ih_l0")
-        dG = tmp("dG", nl, S, T, 4 * Ld, dtype=f32)
+        dG = tmp("dG_dec", nl, S, T, 4 * Ld, dtype=f32)
+        dGe = tmp("dG_enc", nl, S, T, 4 * Ld, dtype=f32)
         d_in_dec = tmp("d_in_dec", N, Ld, dtype=f32)
         L.call("rbvae_lstm_bwd", wdec, sv.acts_dec, sv.cs_dec, dds, dG, d_in_dec, S, T, Ld, nl)
+        side = self._side_begin()
         L.call("rbvae_lstm_wgrad", dG, sv.hs_dec, sv.hp_dec, G("decoder_rnn.lstm.weight_ih_l0"), S, T, Ld, nl, 0)
+        self._side_end(side)
         de = tmp("de", N, Ld, dtype=f32)
         if not v.simple_order:
             # z -> binarise backward (+ fused KL) -> gradient of h_seq
@@ -568,13 +604,17 @@ class Engine:
                    float(kl_p), 1e-8, 1)
             if g_hs is not None:
                 dh = dh + g_hs.reshape(N, Ld)
-            L.call("rbvae_lstm_bwd", wenc, sv.acts_enc, sv.cs_enc, dh, dG, de, S, T, Ld, nl)
-            L.call("rbvae_lstm_wgrad", dG, sv.hs_enc, sv.hp_enc, G("encoder_rnn.lstm.weight_ih_l0"), S, T, Ld, nl, 0)
+            L.call("rbvae_lstm_bwd", wenc, sv.acts_enc, sv.cs_enc, dh, dGe, de, S, T, Ld, nl)
+            side = self._side_begin()
+            L.call("rbvae_lstm_wgrad", dGe, sv.hs_enc, sv.hp_enc, G("encoder_rnn.lstm.weight_ih_l0"), S, T, Ld, nl, 0)
+            self._side_end(side)
         else:
             # decoder stack input = encoder stack output
             dz = tmp("dz", N, Ld, dtype=f32)
-            L.call("rbvae_lstm_bwd", wenc, sv.acts_enc, sv.cs_enc, d_in_dec, dG, dz, S, T, Ld, nl)
-            L.call("rbvae_lstm_wgrad", dG, sv.hs_enc, sv.hp_enc, G("encoder_rnn.lstm.weight_ih_l0"), S, T, Ld, nl, 0)
+            L.call("rbvae_lstm_bwd", wenc, sv.acts_enc, sv.cs_enc, d_in_dec, dGe, dz, S, T, Ld, nl)
+            side = self._side_begin()
+            L.call("rbvae_lstm_wgrad", dGe, sv.hs_enc, sv.hp_enc, G("encoder_rnn.lstm.weight_ih_l0"), S, T, Ld, nl, 0)
+            self._side_end(side)
             L.call("rbvae_binarize_kl_bwd", dz, sv.y, sv.z, de, 0, N, Ld, float(sv.tau), 0.0, None, 0.5, 1e-10, 0)
             if g_e is not None:
                 de = de + g_e.reshape(N, Ld)
@@ -607,5 +647,6 @@ class Engine:
         # --- conv1 (1-tap GEMM over the saved im2col columns)
         self._wgrad(da1, sv.col1, None, P1, c1, self.K1, c1, self.K1, 1, G(f"encoder_cnn.conv.{i0}.weight"),
                     (c1, self.in_ch, kk), (self.K1, 1, self.in_ch), tag=(N, "W1"))
-        # every slab / partial-sum reduction of this pass in one launch
+        # every slab / partial-sum reduction of this pass in one launch, once the side stream has caught up
+        self._side_join()
         self._run_jobs()
