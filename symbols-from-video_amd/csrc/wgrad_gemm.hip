@@ -42,7 +42,6 @@ template <int RB> __device__ __forceinline__ int tr_swz(int row) {
     else return (((row >> 1) & 1) | (((row >> 3) & 1) << 1)) << 1;                // 128-B rows: 4 pairs
 }
 
-constexpr int WG_BK = 32;       // pixels per K step
 constexpr int WG_BM = 128;      // co per workgroup
 constexpr int WG_NS = 3;        // LDS ring depth (two K steps in flight behind the one being multiplied)
 constexpr int WG_MAXP = 4096;   // pixels of one K-slice (their gather indices live in LDS)
@@ -55,13 +54,14 @@ template <int N> __device__ __forceinline__ void wg_wait_barrier() {
 template <typename T, int NT>
 __global__ __launch_bounds__(512, 1) void wgrad_gemm_k(const WgArgs p) {
     constexpr int ES = sizeof(T);
+    constexpr int WG_BK = (ES == 2) ? 64 : 32;            // pixels per K step (one or two 32-pixel MFMA steps)
     constexpr int MT = 4;
     constexpr int BM = WG_BM, BN = 64 * NT;
     constexpr int RBA = BM * ES, RBB = BN * ES;           // image row bytes
     constexpr int A_BYTES = WG_BK * RBA, B_BYTES = WG_BK * RBB;
     constexpr int STAGE = A_BYTES + B_BYTES;
     constexpr int A_TOT = A_BYTES / 1024, B_TOT = B_BYTES / 1024;   // LDS-DMA instructions per stage
-    constexpr int A_INSTR = A_TOT / 8;                               // per wave (A_TOT is 8 or 16)
+    constexpr int A_INSTR = A_TOT / 8;                               // per wave (A_TOT is 16)
     constexpr int B_INSTR = (B_TOT + 7) / 8;                         // waves >= B_TOT issue none when B_TOT < 8
     constexpr bool SWZ = (ES == 2);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -164,29 +164,34 @@ __global__ __launch_bounds__(512, 1) void wgrad_gemm_k(const WgArgs p) {
 
     auto multiply = [&](const unsigned char* lb) {
         if constexpr (ES == 2) {
-            bf16x8_t fa[MT], fb[NT];
+            bf16x8_t fa[WG_BK / 32][MT], fb[WG_BK / 32][NT];
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-                const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                    (__attribute__((address_space(3))) s16x4_t*)(lb + offA[mt]));
-                const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                    (__attribute__((address_space(3))) s16x4_t*)(lb + offA[mt] + 4 * RBA));
-                fa[mt] = bf16x8_t{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-            }
+            for (int ksub = 0; ksub < WG_BK / 32; ++ksub) {
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                    (__attribute__((address_space(3))) s16x4_t*)(lb + offB[nt]));
-                const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                    (__attribute__((address_space(3))) s16x4_t*)(lb + offB[nt] + 4 * RBB));
-                fb[nt] = bf16x8_t{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                for (int mt = 0; mt < MT; ++mt) {
+                    const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                        (__attribute__((address_space(3))) s16x4_t*)(lb + offA[mt] + ksub * 32 * RBA));
+                    const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                        (__attribute__((address_space(3))) s16x4_t*)(lb + offA[mt] + ksub * 32 * RBA + 4 * RBA));
+                    fa[ksub][mt] = bf16x8_t{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                }
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                        (__attribute__((address_space(3))) s16x4_t*)(lb + offB[nt] + ksub * 32 * RBB));
+                    const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                        (__attribute__((address_space(3))) s16x4_t*)(lb + offB[nt] + ksub * 32 * RBB + 4 * RBB));
+                    fb[ksub][nt] = bf16x8_t{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                }
             }
             __builtin_amdgcn_sched_barrier(0);      // all transposed reads in flight before the first MFMA
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
+            for (int ksub = 0; ksub < WG_BK / 32; ++ksub)
 #pragma unroll
-                for (int mt = 0; mt < MT; ++mt)
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[nt], fa[mt], acc[mt][nt], 0, 0, 0);
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt)
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[ksub][nt], fa[ksub][mt], acc[mt][nt], 0, 0, 0);
         } else {
 #pragma unroll
             for (int sub = 0; sub < WG_BK / 4; ++sub) {
@@ -255,7 +260,8 @@ __global__ void conv_gather_index_k(int* __restrict__ idx, int Nimg, int IH, int
 template <typename T, int NT>
 static int launch_wg(const WgArgs& a, hipStream_t st) {
     constexpr int ES = sizeof(T);
-    const size_t lds = (size_t)WG_NS * WG_BK * (WG_BM + 64 * NT) * ES + WG_MAXP * sizeof(int);
+    constexpr int BK = (ES == 2) ? 64 : 32;
+    const size_t lds = (size_t)WG_NS * BK * (WG_BM + 64 * NT) * ES + WG_MAXP * sizeof(int);
     static bool attr_set = false;
     if (!attr_set) {
         hipFuncSetAttribute((const void*)wgrad_gemm_k<T, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -302,7 +308,7 @@ int rbvae_wgrad_gemm(int dtype, const void* Dy, const void* In, float* dW_slabs,
     a.Dy = (const unsigned char*)Dy; a.In = (const unsigned char*)In; a.dW = dW_slabs; a.idx = idx;
     a.zero = (const unsigned char*)zero_page;
     a.P = P; a.Co = Co; a.Ci = Ci; a.ldy = ldy; a.ldi = ldi; a.taps = taps; a.ksplit = ksplit;
-    a.Pper = ((cdiv(P, ksplit) + WG_BK - 1) / WG_BK) * WG_BK;
+    a.Pper = ((cdiv(P, ksplit) + 63) / 64) * 64;
     RBVAE_CHECK_ARG(a.Pper <= WG_MAXP, "wgrad_gemm: %d pixels per K-slice exceed %d: raise ksplit (>= %d)", a.Pper,
                     WG_MAXP, cdiv(P, WG_MAXP));
     hipStream_t st = (hipStream_t)stream;
