@@ -236,47 +236,60 @@ __global__ __launch_bounds__(WAVES * 64, 1) void gather_gemm_k(const GgArgs p) {
 #pragma unroll
         for (int nt = 0; nt < NTW; ++nt) acc[mt][nt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-    auto multiply = [&](const unsigned char* lbase) {
-        u32x4_t fa[2][MT], fb[2][NTW];
+    // one 32-k half of a slice: its MT + NTW fragment reads, and its MT x NTW MFMAs
+    auto read_half = [&](const unsigned char* lbase, int kk, u32x4_t (&fa)[MT], u32x4_t (&fb)[NTW]) {
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
+        for (int mt = 0; mt < MT; ++mt) fa[mt] = *(const u32x4_t*)(lbase + offA[kk] + mt * 2048);
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) fa[kk][mt] = *(const u32x4_t*)(lbase + offA[kk] + mt * 2048);
-#pragma unroll
-            for (int nt = 0; nt < NTW; ++nt) fb[kk][nt] = *(const u32x4_t*)(lbase + offB[kk] + nt * 2048);
-        }
-        // pin the order: every fragment read of the slice is in flight before the first MFMA, so the LDS
-        // serves the second half while the matrix pipe works on the first (counted lgkmcnt waits follow)
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                for (int nt = 0; nt < NTW; ++nt) Mma<T>::run(acc[mt][nt], fb[kk][nt], fa[kk][mt]);
+        for (int nt = 0; nt < NTW; ++nt) fb[nt] = *(const u32x4_t*)(lbase + offB[kk] + nt * 2048);
     };
+    auto mma_half = [&](const u32x4_t (&fa)[MT], const u32x4_t (&fb)[NTW]) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NTW; ++nt) Mma<T>::run(acc[mt][nt], fb[nt], fa[mt]);
+    };
+    u32x4_t fa0[MT], fb0[NTW], fa1[MT], fb1[NTW];
     if constexpr (GG_NS == 1) {
         for (int s = 0; s < nsteps; ++s) {
             if (s > 0) __syncthreads();              // everyone is done reading the single buffer
             stage_next();
             wait_vmcnt_barrier<0>();
-            multiply(smem);
+            read_half(smem, 0, fa0, fb0);
+            read_half(smem, 1, fa1, fb1);
+            mma_half(fa0, fb0);
+            mma_half(fa1, fb1);
         }
     } else {
-        // prologue: GG_NS-1 slices in flight
+        // Software pipeline over the 32-k halves: while the matrix pipe works on one half the LDS serves
+        // the next one, and the slice barrier sits between two MFMA groups whose operands are already in
+        // registers.  Ring: slice s is being read, slices s+1 .. s+GG_NS-1 are landed or in flight.
 #pragma unroll
         for (int i = 0; i < GG_NS - 1; ++i)
-            if (i < nsteps) stage_next();
+            if (i < nsteps && DBG != 1) stage_next();
+        if (nsteps > GG_NS - 1 && GG_NS > 2) wait_vmcnt_barrier<(GG_NS > 2 ? GG_NS - 2 : 0) * LOADS>();
+        else wait_vmcnt_barrier<0>();
+        if (GG_NS - 1 < nsteps && DBG != 1) stage_next();
         int cbuf = 0;
+        read_half(smem, 0, fa0, fb0);
         for (int s = 0; s < nsteps; ++s) {
-            // slice s must have landed; younger slices stay in flight across the barrier
-            if (GG_NS > 2 && nsteps - s - 1 >= GG_NS - 2)
-                wait_vmcnt_barrier<(GG_NS > 2 ? GG_NS - 2 : 0) * LOADS>();
-            else
-                wait_vmcnt_barrier<0>();      // tail (or double buffer): nothing younger is in flight
-            if (s + GG_NS - 1 < nsteps && DBG != 1) stage_next();   // refills the buffer multiplied in step s-1
-            if (DBG != 2) multiply(smem + cbuf * STAGE);
+            const unsigned char* lcur = smem + cbuf * STAGE;
             cbuf = (cbuf + 1 == GG_NS) ? 0 : cbuf + 1;
+            read_half(lcur, 1, fa1, fb1);
+            __builtin_amdgcn_sched_barrier(0);
+            if (DBG != 2) mma_half(fa0, fb0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (s + 1 < nsteps) {
+                // slice s+1 landed (GG_NS-2 younger ones may stay in flight); after the barrier every wave
+                // holds both halves of slice s in registers, so its buffer can be refilled
+                if (GG_NS > 2 && nsteps - s - 2 >= GG_NS - 2) wait_vmcnt_barrier<(GG_NS > 2 ? GG_NS - 2 : 0) * LOADS>();
+                else wait_vmcnt_barrier<0>();
+                if (s + GG_NS < nsteps && DBG != 1) stage_next();
+                read_half(smem + cbuf * STAGE, 0, fa0, fb0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (DBG != 2) mma_half(fa1, fb1);
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
     __syncthreads();
