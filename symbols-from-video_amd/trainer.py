@@ -58,8 +58,9 @@ class FusedTrainer:
         eng, model = self.eng, self.model
         L.call("rbvae_counter_add", self.step_dev, 1)
         numel = x.numel()
-        out = eng.forward(model._flat, x, U, tau, False, self.r, True, None, seed=0, need_grad=True, target=x,
-                          recon_gscale=2.0 / numel, kl_p=self.p)
+        # dropout follows the module's mode like the reference (model.train() in train_one_epoch, :501)
+        out = eng.forward(model._flat, x, U, tau, False, self.r, bool(model.training), None, seed=0, need_grad=True,
+                          target=x, recon_gscale=2.0 / numel, kl_p=self.p)
         hs = out["hs"]                       # [2B, T, L]
         Ld = hs.shape[-1]
         h0, h1 = hs[:B], hs[B:]

@@ -1,0 +1,72 @@
+"""The fused training step against the oracle's step + Adam (dropout off so both see the same network)."""
+import numpy as np
+import pytest
+import torch
+
+import rbvae_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _oracle_step(variant, params, item, U, tau, r, p, alpha, beta, margin, steps, lr=1e-3):
+    state = {}
+    hist = []
+    for st in range(1, steps + 1):
+        for v in params.values():
+            v.grad = None
+        res = O.step_losses(variant, params, item, U, tau, r, p, alpha, beta, margin)
+        res["total"].backward()
+        hist.append({k: float(v) for k, v in res.items()})
+        grads = {k: v.grad.clone() for k, v in params.items()}
+        with torch.no_grad():
+            O.adam_step({k: v for k, v in params.items()}, grads, state, lr, st)
+    return hist, grads
+
+
+@pytest.mark.parametrize("variant,use_graph", [("percep", False), ("percep", True), ("triplet", False)])
+def test_fused_step_matches_oracle(variant, use_graph):
+    import sfv_amd as sfv
+    from importlib import import_module
+    FusedTrainer = import_module("symbols-from-video_amd.trainer").FusedTrainer
+    in_ch = 4 if variant == "percep" else 3
+    B, T, Ld, hw = 3, 4, 32, (16, 24)
+    torch.manual_seed(5)
+    m = sfv.Seq2SeqBinaryVAE(in_ch, in_ch, Ld, Ld, variant=variant, input_hw=hw, compute_dtype="f32")
+    params = {k: v.clone().requires_grad_() for k, v in m.state_dict().items()}
+    m = m.cuda().eval()                                   # eval: no dropout on either side
+    g = torch.Generator().manual_seed(6)
+    item = torch.rand(B, 2, T, in_ch, *hw, generator=g)
+    U = torch.rand(2, B * T, Ld, generator=g)
+    tau, r, p, alpha, beta, margin = 0.8, 0.1, 0.1, 1.0, 0.5, 0.2
+    steps = 3
+    hist, last_grads = _oracle_step(variant, params, item, [U[0], U[1]], tau, r, p, alpha, beta, margin, steps)
+    tr = FusedTrainer(m, lr=1e-3, alpha=alpha, beta_kl=beta, bernoulli_p=p, noise_ratio=r, margin=margin,
+                      device_noise=False, use_graph=use_graph)
+    for st in range(steps):
+        losses = tr.step(item.cuda(), tau, U=U.cuda()).cpu().tolist()
+        ref = hist[st]
+        for got, k in zip(losses, ("total", "recon", "kl", "pair")):
+            assert abs(got - ref[k]) < 2e-4 * max(1.0, abs(ref[k])), (st, k, got, ref[k])
+    # gradients of the last step and the parameters after `steps` Adam updates
+    lay = tr.eng.layout
+    for k in lay.names:
+        gr = lay.view(tr.gflat, k).cpu().double().reshape(-1)
+        rf = last_grads[k].double().reshape(-1)
+        assert float((gr - rf).norm()) <= 2e-3 * max(float(rf.norm()), 1e-7), k
+    sd = m.state_dict()
+    worst = max(float((sd[k].cpu() - params[k].detach()).abs().max()) for k in lay.names)
+    assert worst < 5e-4, worst                      # 3 Adam steps of lr 1e-3 move a weight by <= 3e-3
+
+
+def test_step_rejects_bad_input():
+    import sfv_amd as sfv
+    from importlib import import_module
+    FusedTrainer = import_module("symbols-from-video_amd.trainer").FusedTrainer
+    m = sfv.Seq2SeqBinaryVAE(4, 4, 32, 32, variant="percep", input_hw=(16, 16)).cuda()
+    tr = FusedTrainer(m)
+    with pytest.raises(ValueError):
+        tr.step(torch.zeros(2, 3, 4, 4, 16, 16, device="cuda"), 1.0)
+    with pytest.raises(ZeroDivisionError):
+        tr.step(torch.zeros(2, 2, 1, 4, 16, 16, device="cuda"), 1.0)
+    with pytest.raises(ValueError):
+        FusedTrainer(sfv.Seq2SeqBinaryVAE(3, 3, 16, 16, variant="simple").cuda())
