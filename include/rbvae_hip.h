@@ -116,12 +116,13 @@ int rbvae_mse_bwd(const float* a, const float* b, long n, float scale, const flo
  *   outside);  Out pixel (a*so+oh0, b*so+ow0) of an OH x OW grid;  grid.z = parity class.
  *   class_desc is a HOST int array: per class [ntaps, oh0, ow0, ntaps x (widx, dh, dw)].
  *   epilogue: +bias, relu, *scale, dropout (drop_mode 1: counter hash of (seed, element index),
- *   2: explicit u8 keep-mask [rows][Nout]), then zero where gate <= 0 (saved activation:
+ *   2: explicit u8 keep-mask [rows][Nout]), + addend (residual, same indexing as Out; LDM ResnetBlock /
+ *   AttnBlock skip connections, ldm/modules/diffusionmodules/model.py:141,202), then zero where gate <= 0 (saved activation:
  *   ReLU/dropout backward).  zero_page: >= 128 zero bytes.  Kc % (128/sizeof T) == 0, Nout % 8 == 0.
  *   colsum_ws (optional, [nclass * ceil(rows/128)][Nout] f32): per-tile column sums of the stored
  *   values -- the bias gradient, finished by rbvae_reduce_rows. */
 int rbvae_gather_gemm(int dtype, const void* A, const void* W, void* Out, const float* bias, const void* gate,
-                      const void* mask, const void* zero_page, int Nimg, int IH, int IW, int TH, int TW, int sa,
+                      const void* mask, const void* addend, const void* zero_page, int Nimg, int IH, int IW, int TH, int TW, int sa,
                       int OH, int OW, int so, int Kc, int Nout, int lda, int ldo, int taps_total, int nclass,
                       const int* class_desc, int relu, int drop_mode, float drop_p, float scale,
                       unsigned long long seed, const unsigned long long* seed_dev, float* colsum_ws,
@@ -200,6 +201,20 @@ int rbvae_lstm_wgrad(const float* dG, const float* hs_all, const float* hprev, f
 int rbvae_adam_step(float* w, const float* g, float* m, float* v, long n, double lr, double beta1, double beta2,
                     double eps, int step, float gscale, const unsigned long long* step_dev, float* hyper_ws,
                     void* stream);
+
+/* ---- frozen LDM / Stable-Diffusion VAE encoder (cfg 5: on-the-fly latents) ------------------------
+ * The convolutions, 1x1 projections and both attention products run on rbvae_gather_gemm (stride-1 and
+ * asymmetric-pad stride-2 tap tables, residuals through `addend`); these are the remaining pieces.
+ * GroupNorm(32, eps 1e-6, affine) + swish: src/stable-diffusion/ldm/modules/diffusionmodules/model.py:33-39
+ * (stats_ws: 2*N*groups floats).  softmax_rows: AttnBlock :186-192.  posterior_sample:
+ * ldm/modules/distributions/distributions.py:24-37 with ldm/models/diffusion/ddpm.py:542-549's scale:
+ * latent[n][c][h][w] f32 = scale * (mean + exp(0.5*clamp(logvar,-30,20)) * eps); eps NULL = posterior mode. */
+int rbvae_groupnorm_swish(int dtype, const void* x, void* y, const float* gamma, const float* beta, float* stats_ws,
+                          int N, int HW, int C, int ldx, int ldy, int groups, float eps, int swish, void* stream);
+int rbvae_softmax_rows(int dtype, const void* x, void* y, long rows, int n, int ld, void* stream);
+int rbvae_transpose2d(int dtype, const void* in, void* out, int R, int C, int ldi, int ldo, void* stream);
+int rbvae_posterior_sample(int dtype, const void* moments, int ld, const float* eps, float* latent, int N, int Z,
+                           int HW, float scale, void* stream);
 
 /* ---- hardware-map probes (diagnostics; tests/test_hw_maps.py) ------------------
  * One-wave kernels that pin the gfx950 lane maps the GEMM kernels assume. */

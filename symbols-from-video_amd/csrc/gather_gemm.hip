@@ -44,6 +44,7 @@ struct GgArgs {
     const float* bias;         // [Nout] or null
     const unsigned char* gate; // [*, ldo] T or null: zero the output where gate <= 0
     const unsigned char* mask; // [*, Nout] u8 keep-mask or null
+    const unsigned char* addend; // [*, ldo] T or null: residual added to the stored value (after bias/relu/scale)
     const unsigned char* zero; // >= 128 zero bytes
     int Nimg, IH, IW;          // pixel grid of A
     int TH, TW;                // per-class row grid: m -> (n, a, b)
@@ -352,6 +353,12 @@ __global__ __launch_bounds__(WAVES * 64, 1) void gather_gemm_k(const GgArgs p) {
             for (int e = 0; e < EC; ++e)
                 if (!mk[e]) ev[e] = 0;
         }
+        if (p.addend) {
+            const u32x4_t av = *(const u32x4_t*)(p.addend + ((size_t)orow * p.ldo + col) * ES);
+            const T* ae = (const T*)&av;
+#pragma unroll
+            for (int e = 0; e < EC; ++e) Elem<T>::store(ev + e, Elem<T>::load(ev + e) + Elem<T>::load(ae + e));
+        }
         if (p.gate) {
             const unsigned char* gp = p.gate + ((size_t)orow * p.ldo + col) * ES;
             const u32x4_t gv = *(const u32x4_t*)gp;
@@ -412,6 +419,7 @@ static int dispatch_gg(const GgArgs& a, hipStream_t st, int max_steps) {
     if (ns == 1) return launch_gg<T, 4, 4, 1>(a, st);
     if (ns == 2) return launch_gg<T, 4, 8, 2>(a, st);
     static const int dbg = getenv("RBVAE_GG_DBG") ? atoi(getenv("RBVAE_GG_DBG")) : 0;
+    if (dbg == 4) return launch_gg<T, 4, 4, 3>(a, st);       // 4 waves, 64x64 wave tiles (less LDS traffic)
     if (dbg == 1) return launch_gg<T, 4, 8, 3, 1>(a, st);
     if (dbg == 2) return launch_gg<T, 4, 8, 3, 2>(a, st);
     if (ns >= 4) return launch_gg<T, 4, 8, 4>(a, st);
@@ -423,7 +431,7 @@ static int dispatch_gg(const GgArgs& a, hipStream_t st, int max_steps) {
 using namespace rbvae;
 
 extern "C" int rbvae_gather_gemm(int dtype, const void* A, const void* W, void* Out, const float* bias,
-                                 const void* gate, const void* mask, const void* zero_page, int Nimg, int IH,
+                                 const void* gate, const void* mask, const void* addend, const void* zero_page, int Nimg, int IH,
                                  int IW, int TH, int TW, int sa, int OH, int OW, int so, int Kc, int Nout, int lda,
                                  int ldo, int taps_total, int nclass, const int* class_desc, int relu,
                                  int drop_mode, float drop_p, float scale, unsigned long long seed,
@@ -445,7 +453,7 @@ extern "C" int rbvae_gather_gemm(int dtype, const void* A, const void* W, void* 
     RBVAE_CHECK_ARG(drop_mode >= 0 && drop_mode <= 2 && (drop_mode != 2 || mask), "gather_gemm: drop_mode/mask");
     GgArgs a;
     a.A = (const unsigned char*)A; a.W = (const unsigned char*)W; a.Out = (unsigned char*)Out; a.bias = bias;
-    a.gate = (const unsigned char*)gate; a.mask = (const unsigned char*)mask;
+    a.gate = (const unsigned char*)gate; a.mask = (const unsigned char*)mask; a.addend = (const unsigned char*)addend;
     a.zero = (const unsigned char*)zero_page;
     a.Nimg = Nimg; a.IH = IH; a.IW = IW; a.TH = TH; a.TW = TW; a.sa = sa; a.OH = OH; a.OW = OW; a.so = so;
     a.Kc = Kc; a.Nout = Nout; a.lda = lda; a.ldo = ldo; a.taps_total = taps_total;

@@ -1,0 +1,190 @@
+// Kernels of the frozen LDM/Stable-Diffusion VAE encoder that are not GEMMs
+// (src/stable-diffusion/ldm/modules/diffusionmodules/model.py): GroupNorm(32, eps 1e-6) fused with
+// swish (:33-39), the softmax of the single-head mid-block attention (:186-192), a 2-D transpose for
+// its value operand, and the posterior sample of AutoencoderKL.encode
+// (ldm/modules/distributions/distributions.py:24-37; ldm/models/diffusion/ddpm.py:542-549).
+// Activations are NHWC rows [N*H*W][C] in the storage type T.
+#include "common.h"
+
+namespace rbvae {
+
+// ---- GroupNorm statistics: one workgroup per (image, group) -------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void gn_stats_k(const T* __restrict__ x, int HW, int C, int ld, int groups,
+                                                  float eps, float* __restrict__ mean, float* __restrict__ rstd) {
+    __shared__ float red[4];
+    const int n = blockIdx.x / groups, g = blockIdx.x - n * groups;
+    const int cg = C / groups;
+    const T* base = x + (size_t)n * HW * ld + g * cg;
+    // pass 1: mean
+    float s = 0.f;
+    for (int i = threadIdx.x; i < HW * cg; i += 256) {
+        const int p = i / cg, c = i - p * cg;
+        s += Elem<T>::load(base + (size_t)p * ld + c);
+    }
+    const float m = block_sum(s, red) / (float)(HW * cg);
+    // pass 2: centred second moment (no cancellation)
+    float q = 0.f;
+    for (int i = threadIdx.x; i < HW * cg; i += 256) {
+        const int p = i / cg, c = i - p * cg;
+        const float d = Elem<T>::load(base + (size_t)p * ld + c) - m;
+        q += d * d;
+    }
+    const float var = block_sum(q, red) / (float)(HW * cg);
+    if (threadIdx.x == 0) {
+        mean[blockIdx.x] = m;
+        rstd[blockIdx.x] = rsqrtf(var + eps);
+    }
+}
+
+// y = (x - mean) * rstd * gamma[c] + beta[c], optionally * sigmoid(.) (swish)
+template <typename T>
+__global__ void gn_apply_k(const T* __restrict__ x, T* __restrict__ y, const float* __restrict__ mean,
+                           const float* __restrict__ rstd, const float* __restrict__ gamma,
+                           const float* __restrict__ beta, long rows, int HW, int C, int ldx, int ldy, int groups,
+                           int swish) {
+    const int cg = C / groups;
+    const long tot = rows * C;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < tot; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        const long r = i / C;
+        const int n = (int)(r / HW);
+        const int sg = n * groups + c / cg;
+        float v = (Elem<T>::load(x + r * ldx + c) - mean[sg]) * rstd[sg] * gamma[c] + beta[c];
+        if (swish) v = v * sigmoidf_(v);
+        Elem<T>::store(y + r * ldy + c, v);
+    }
+}
+
+// ---- row softmax (in place capable): one wave per row -------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void softmax_rows_k(const T* __restrict__ x, T* __restrict__ y, long rows, int n,
+                                                      int ld) {
+    const int lane = threadIdx.x & 63;
+    const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    const T* xr = x + r * ld;
+    float mx = -3.4e38f;
+    for (int i = lane; i < n; i += 64) mx = fmaxf(mx, Elem<T>::load(xr + i));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    float s = 0.f;
+    for (int i = lane; i < n; i += 64) s += expf(Elem<T>::load(xr + i) - mx);
+    s = wave_sum(s);
+    const float inv = 1.0f / s;
+    T* yr = y + r * ld;
+    for (int i = lane; i < n; i += 64) Elem<T>::store(yr + i, expf(Elem<T>::load(xr + i) - mx) * inv);
+}
+
+// ---- out[c][r] = in[r][c]  (32x32 LDS tiles) -----------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void transpose_k(const T* __restrict__ in, T* __restrict__ out, int R, int C,
+                                                   int ldi, int ldo) {
+    __shared__ T tile[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+    for (int j = ty; j < 32; j += 8)
+        if (r0 + j < R && c0 + tx < C) tile[j][tx] = in[(size_t)(r0 + j) * ldi + c0 + tx];
+    __syncthreads();
+    for (int j = ty; j < 32; j += 8)
+        if (c0 + j < C && r0 + tx < R) out[(size_t)(c0 + j) * ldo + r0 + tx] = tile[tx][j];
+}
+
+// ---- posterior sample: latent[n][c][h][w] = scale * (mean + exp(0.5*clamp(logvar,-30,20)) * eps) -----
+template <typename T>
+__global__ void posterior_sample_k(const T* __restrict__ moments, int ld, const float* __restrict__ eps,
+                                   float* __restrict__ latent, int N, int Z, int HW, float scale) {
+    const long tot = (long)N * Z * HW;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < tot; i += (long)gridDim.x * blockDim.x) {
+        const int p = (int)(i % HW);
+        const long r = i / HW;
+        const int c = (int)(r % Z), n = (int)(r / Z);
+        const T* m = moments + ((size_t)n * HW + p) * ld;
+        const float mean = Elem<T>::load(m + c);
+        const float lv = fminf(fmaxf(Elem<T>::load(m + Z + c), -30.f), 20.f);
+        latent[i] = scale * (mean + expf(0.5f * lv) * (eps ? eps[i] : 0.f));
+    }
+}
+
+static inline int grid_n(long n, int cap = 8192) {
+    long b = (n + 255) / 256;
+    return (int)(b < 1 ? 1 : (b > cap ? cap : b));
+}
+
+}  // namespace rbvae
+
+using namespace rbvae;
+
+#define DISPATCH_T(dtype, CALL_F32, CALL_BF16, name)                       \
+    if ((dtype) == RBVAE_F32) { CALL_F32; }                                \
+    else if ((dtype) == RBVAE_BF16) { CALL_BF16; }                         \
+    else return fail(RBVAE_E_INVALID, name ": dtype %d", (dtype));
+
+extern "C" {
+
+int rbvae_groupnorm_swish(int dtype, const void* x, void* y, const float* gamma, const float* beta, float* stats_ws,
+                          int N, int HW, int C, int ldx, int ldy, int groups, float eps, int swish, void* stream) {
+    RBVAE_CHECK_ARG(x && y && gamma && beta && stats_ws && N > 0 && HW > 0 && C > 0, "groupnorm_swish: bad arguments");
+    RBVAE_CHECK_ARG(groups > 0 && C % groups == 0 && ldx >= C && ldy >= C, "groupnorm_swish: C=%d groups=%d", C, groups);
+    hipStream_t st = (hipStream_t)stream;
+    float* mean = stats_ws;
+    float* rstd = stats_ws + (size_t)N * groups;
+    const long rows = (long)N * HW;
+    DISPATCH_T(dtype,
+               hipLaunchKernelGGL(gn_stats_k<float>, dim3(N * groups), dim3(256), 0, st, (const float*)x, HW, C, ldx,
+                                  groups, eps, mean, rstd);
+               hipLaunchKernelGGL(gn_apply_k<float>, dim3(grid_n(rows * C)), dim3(256), 0, st, (const float*)x,
+                                  (float*)y, mean, rstd, gamma, beta, rows, HW, C, ldx, ldy, groups, swish),
+               hipLaunchKernelGGL(gn_stats_k<bf16_t>, dim3(N * groups), dim3(256), 0, st, (const bf16_t*)x, HW, C, ldx,
+                                  groups, eps, mean, rstd);
+               hipLaunchKernelGGL(gn_apply_k<bf16_t>, dim3(grid_n(rows * C)), dim3(256), 0, st, (const bf16_t*)x,
+                                  (bf16_t*)y, mean, rstd, gamma, beta, rows, HW, C, ldx, ldy, groups, swish),
+               "groupnorm_swish")
+    RBVAE_CHECK_LAUNCH("groupnorm_swish");
+    return RBVAE_OK;
+}
+
+int rbvae_softmax_rows(int dtype, const void* x, void* y, long rows, int n, int ld, void* stream) {
+    RBVAE_CHECK_ARG(x && y && rows > 0 && n > 0 && ld >= n, "softmax_rows: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    const int blocks = cdiv(rows, 4);
+    DISPATCH_T(dtype,
+               hipLaunchKernelGGL(softmax_rows_k<float>, dim3(blocks), dim3(256), 0, st, (const float*)x, (float*)y,
+                                  rows, n, ld),
+               hipLaunchKernelGGL(softmax_rows_k<bf16_t>, dim3(blocks), dim3(256), 0, st, (const bf16_t*)x,
+                                  (bf16_t*)y, rows, n, ld),
+               "softmax_rows")
+    RBVAE_CHECK_LAUNCH("softmax_rows");
+    return RBVAE_OK;
+}
+
+int rbvae_transpose2d(int dtype, const void* in, void* out, int R, int C, int ldi, int ldo, void* stream) {
+    RBVAE_CHECK_ARG(in && out && R > 0 && C > 0 && ldi >= C && ldo >= R, "transpose2d: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid(cdiv(C, 32), cdiv(R, 32));
+    DISPATCH_T(dtype,
+               hipLaunchKernelGGL(transpose_k<float>, grid, dim3(256), 0, st, (const float*)in, (float*)out, R, C, ldi,
+                                  ldo),
+               hipLaunchKernelGGL(transpose_k<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)in, (bf16_t*)out, R, C,
+                                  ldi, ldo),
+               "transpose2d")
+    RBVAE_CHECK_LAUNCH("transpose2d");
+    return RBVAE_OK;
+}
+
+int rbvae_posterior_sample(int dtype, const void* moments, int ld, const float* eps, float* latent, int N, int Z,
+                           int HW, float scale, void* stream) {
+    RBVAE_CHECK_ARG(moments && latent && N > 0 && Z > 0 && HW > 0 && ld >= 2 * Z, "posterior_sample: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    const long tot = (long)N * Z * HW;
+    DISPATCH_T(dtype,
+               hipLaunchKernelGGL(posterior_sample_k<float>, dim3(grid_n(tot)), dim3(256), 0, st,
+                                  (const float*)moments, ld, eps, latent, N, Z, HW, scale),
+               hipLaunchKernelGGL(posterior_sample_k<bf16_t>, dim3(grid_n(tot)), dim3(256), 0, st,
+                                  (const bf16_t*)moments, ld, eps, latent, N, Z, HW, scale),
+               "posterior_sample")
+    RBVAE_CHECK_LAUNCH("posterior_sample");
+    return RBVAE_OK;
+}
+
+}  // extern "C"

@@ -327,7 +327,7 @@ class Engine:
             prow = ncls * (-(-(nimg * th * tw) // 128))
             ws = self._buf(("colsum", tag), prow * nout)
             self._jobs.add(JOB_ROWS, ws, bias_grad, (1, 1, nout), (0, 0, 1), nslab=prow, slab=nout)
-        L.call("rbvae_gather_gemm", self.dt, A, W, out, bias, gate, mask, self.zero, nimg, ih, iw, th, tw, sa, oh, ow,
+        L.call("rbvae_gather_gemm", self.dt, A, W, out, bias, gate, mask, None, self.zero, nimg, ih, iw, th, tw, sa, oh, ow,
                so, kc, nout, lda, ldo, taps, ncls, ctypes.addressof(desc), relu, drop_mode, float(drop_p),
                float(scale), int(seed), seed_dev, ws)
 

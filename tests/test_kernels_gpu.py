@@ -37,7 +37,7 @@ def gemm(sfv, dt, A, Wp, out, bias, gate, mask, geom, kc, nout, taps, desc, ncls
          scale=1.0, seed=0):
     zero = torch.zeros(256, dtype=torch.uint8, device="cuda")
     d = (ctypes.c_int * len(desc))(*desc)
-    sfv._lib.call("rbvae_gather_gemm", dt, A, Wp, out, bias, gate, mask, zero, *geom, kc, nout, A.shape[1],
+    sfv._lib.call("rbvae_gather_gemm", dt, A, Wp, out, bias, gate, mask, None, zero, *geom, kc, nout, A.shape[1],
                   out.shape[1], taps, ncls, ctypes.addressof(d), relu, drop_mode, drop_p, scale, seed, None, None)
 
 

@@ -1,0 +1,54 @@
+"""Frozen LDM VAE encoder (cfg 5) on HIP vs the reference Encoder's own outputs."""
+import numpy as np
+import pytest
+import torch
+
+import ldm_oracle as LO
+from _golden import load
+
+pytestmark = pytest.mark.gpu
+
+
+def _model(sfv, g, dtype):
+    torch.manual_seed(int(g["meta/seed"]))
+    m = sfv.LDMEncoder(compute_dtype=dtype)
+    sd = m.state_dict()
+    ref = LO.init_params(int(g["meta/seed"]))
+    assert list(sd.keys()) == list(ref.keys())
+    for k in ref:                                   # same construction order => same initial weights
+        assert torch.equal(sd[k], ref[k]), k
+    return m.cuda()
+
+
+def test_f32_matches_reference_encoder():
+    import sfv_amd as sfv
+    g = load("ldm_encoder")
+    m = _model(sfv, g, "f32")
+    x = torch.from_numpy(g["x"]).cuda()
+    mom = m.moments(x).float().cpu().reshape(2, 8, 8, 8).permute(0, 3, 1, 2)
+    np.testing.assert_allclose(mom.numpy(), g["moments"], atol=2e-4, rtol=1e-4)
+    lat = m.encode(x, eps=torch.from_numpy(g["eps"]).cuda())
+    np.testing.assert_allclose(lat.cpu().numpy(), g["latent"], atol=1e-4, rtol=1e-4)
+    mode = m.encode(x, sample=False)
+    np.testing.assert_allclose(mode.cpu().numpy(), 0.18215 * g["moments"][:, :4], atol=1e-4, rtol=1e-4)
+
+
+def test_bf16_tracks_and_checkpoint_keys():
+    import sfv_amd as sfv
+    g = load("ldm_encoder")
+    m = _model(sfv, g, "bf16")
+    x = torch.from_numpy(g["x"]).cuda()
+    lat = m.encode(x, eps=torch.from_numpy(g["eps"]).cuda()).cpu().numpy()
+    ref = g["latent"]
+    assert np.linalg.norm(lat - ref) / np.linalg.norm(ref) < 5e-2
+    # a Stable-Diffusion style checkpoint (first_stage_model.* keys, extra decoder entries) loads as is
+    sd = {f"first_stage_model.{k}": v + 0.01 for k, v in m.state_dict().items()}
+    sd["first_stage_model.decoder.conv_in.weight"] = torch.zeros(3)
+    m2 = sfv.LDMEncoder(compute_dtype="bf16")
+    m2.load_state_dict(sd)
+    k0 = "encoder.conv_in.weight"
+    assert torch.allclose(m2.state_dict()[k0], m.state_dict()[k0].cpu() + 0.01)
+    with pytest.raises(RuntimeError):
+        m.moments(x.cpu())
+    with pytest.raises(ValueError):
+        m.moments(torch.zeros(1, 3, 60, 64, device="cuda"))

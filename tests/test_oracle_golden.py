@@ -156,3 +156,18 @@ def test_state_consistency_small_table():
     avg, pct = O.state_consistency(codes, labels, 4)
     assert pct == [2 / 3, 1.0, 1.0, 0.0]
     assert abs(avg - (2 + 2 + 1) / 6) < 1e-12
+
+
+def test_ldm_encoder_oracle_vs_reference_fixture():
+    import ldm_oracle as LO
+    g = load("ldm_encoder")
+    p = LO.init_params(int(g["meta/seed"]))
+    for k, v in p.items():
+        cs = g[f"paramsum/{k}"]
+        assert abs(float(v.double().sum()) - cs[0]) <= 1e-9 * max(1.0, cs[1]), k
+    x = torch.from_numpy(g["x"])
+    with torch.no_grad():
+        m = LO.encoder_moments(p, x)
+        lat = LO.posterior_sample(m, torch.from_numpy(g["eps"]))
+    np.testing.assert_allclose(m.numpy(), g["moments"], atol=5e-6)
+    np.testing.assert_allclose(lat.numpy(), g["latent"], atol=5e-6)

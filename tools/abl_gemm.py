@@ -14,7 +14,7 @@ def run(N, mode, taps3=True, iters=30):
     out = torch.empty(N * Ho * Wo, C, device="cuda", dtype=torch.bfloat16)
     desc = E.conv_classes(3) if taps3 else [1, 0, 0, 4, 0, 0]
     d = (ctypes.c_int * len(desc))(*desc)
-    args = (1, A, Wt, out, None, None, None, zero, N, H, W, Ho, Wo, 2, Ho, Wo, 1, C, C, C, C, 9, 1, ctypes.addressof(d), 0, mode, 0.0, 1.0, 0, None, None)
+    args = (1, A, Wt, out, None, None, None, None, zero, N, H, W, Ho, Wo, 2, Ho, Wo, 1, C, C, C, C, 9, 1, ctypes.addressof(d), 0, mode, 0.0, 1.0, 0, None, None)
     for _ in range(3):
         L.call("rbvae_gather_gemm", *args)
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -30,27 +30,5 @@ while time.time() - t0 < 0.2:
     for _ in range(20): y = x @ x
     torch.cuda.synchronize()
 
-ctr = torch.zeros(1, dtype=torch.int64, device="cuda")
-def t_ctr(iters=50):
-    for _ in range(3): L.call("rbvae_counter_add", ctr, 1)
-    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    a.record()
-    for _ in range(iters): L.call("rbvae_counter_add", ctr, 1)
-    b.record(); torch.cuda.synchronize()
-    return a.elapsed_time(b) / iters * 1e3
-print("empty kernel back-to-back", t_ctr())
-def run_k(N, Kc, iters=30):
-    A = torch.randn(N * 64, Kc, device="cuda").bfloat16()
-    Wt = torch.randn(256, 1, Kc, device="cuda").bfloat16()
-    out = torch.empty(N * 64, 256, device="cuda", dtype=torch.bfloat16)
-    desc = [1, 0, 0, 0, 0, 0]
-    d = (ctypes.c_int * len(desc))(*desc)
-    args = (1, A, Wt, out, None, None, None, zero, N * 64, 1, 1, 1, 1, 1, 1, 1, 1, Kc, 256, Kc, 256, 1, 1, ctypes.addressof(d), 0, 0, 0.0, 1.0, 0, None, None)
-    for _ in range(3): L.call("rbvae_gather_gemm", *args)
-    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    a.record()
-    for _ in range(iters): L.call("rbvae_gather_gemm", *args)
-    b.record(); torch.cuda.synchronize()
-    return a.elapsed_time(b) / iters * 1e3
-for N in (16, 256, 1024):
-    print(f"N={N} (blocks {N}): Kc=64 {run_k(N,64):6.1f}  Kc=256 {run_k(N,256):6.1f}  Kc=1024 {run_k(N,1024):6.1f}  Kc=4096 {run_k(N,4096):6.1f} us")
+for N in (256, 512):
+    print(f"dbg={os.environ.get('RBVAE_GG_DBG','0')} N={N:5d} 9taps {run(N,0):7.1f} us")

@@ -411,7 +411,53 @@ def main():
     model_case("contrastive_native_eval", "contrastive", cm, ct, 3, 32, 1, 2, (256, 256), 18, 0.7, 0.1,
                full_grads=False, **common)
     simple_case(sm, st)
+    ldm_case()
+
+
+
+
+def ldm_case():
+    """G7: the reference's own LDM Encoder class (random init) at [1,3,64,64] + restated quant_conv/posterior."""
+    sdroot = os.path.join(REF, "src", "stable-diffusion")
+    if sdroot not in sys.path:
+        sys.path.insert(0, sdroot)
+    import importlib
+    mdl = importlib.import_module("ldm.modules.diffusionmodules.model")
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import ldm_oracle as LO
+    seed = 31
+    cfg = LO.DDCONFIG
+    torch.manual_seed(seed)
+    enc = mdl.Encoder(ch=cfg["ch"], out_ch=3, ch_mult=cfg["ch_mult"], num_res_blocks=cfg["num_res_blocks"],
+                      attn_resolutions=[], dropout=0.0, in_channels=3, resolution=256, z_channels=4, double_z=True)
+    quant = nn.Conv2d(8, 8, 1)
+    mine = LO.init_params(seed)
+    sd = {f"encoder.{k}": v for k, v in enc.state_dict().items()}
+    sd.update({f"quant_conv.{k}": v for k, v in quant.state_dict().items()})
+    assert list(sd.keys()) == list(mine.keys()), "construction order drifted"
+    for k in sd:
+        assert torch.equal(sd[k], mine[k]), k
+    enc.eval()
+    g = torch.Generator().manual_seed(seed + 1)
+    x = torch.rand((2, 3, 64, 64), generator=g) * 2 - 1
+    eps = torch.randn((2, 4, 8, 8), generator=g)
+    with torch.no_grad():
+        hs = enc(x)
+        moments = quant(hs)
+    mean, logvar = torch.chunk(moments, 2, dim=1)
+    latent = 0.18215 * (mean + torch.exp(0.5 * torch.clamp(logvar, -30.0, 20.0)) * eps)
+    out = {"meta/seed": seed, "x": x.numpy(), "eps": eps.numpy(), "encoder_out": hs.numpy(),
+           "moments": moments.numpy(), "latent": latent.numpy()}
+    for k, v in sd.items():
+        out[f"paramsum/{k}"] = np.array([float(v.double().sum()), float(v.double().abs().sum())])
+    np.savez_compressed(os.path.join(OUT, "ldm_encoder.npz"), **out)
+    print(f"ldm_encoder: {len(sd)} tensors bit-identical to the reference Encoder; moments {tuple(moments.shape)}")
 
 
 if __name__ == "__main__":
-    main()
+    if "--ldm-only" in sys.argv:
+        assert os.path.isdir(REF), "run in the dev container (needs /root/reference)"
+        _stub_imports()
+        ldm_case()
+    else:
+        main()
