@@ -140,9 +140,16 @@ def main():
     from importlib import import_module
     ddp = import_module("symbols-from-video_amd.ddp")
     trainer_mod = import_module("symbols-from-video_amd.trainer")
-    rank, world, local = ddp.init_from_env("nccl")
+    # RCCL ("nccl") is the backend of record; RBVAE_DIST_BACKEND=gloo lets the N > 1 code path be rehearsed
+    # with several ranks sharing one GPU (RCCL refuses duplicate devices)
+    backend = os.environ.get("RBVAE_DIST_BACKEND", "nccl")
+    ndev = max(torch.cuda.device_count(), 1)
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")) % ndev)
+    rank, world, local = ddp.init_from_env(backend)
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    local = local % ndev
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
@@ -176,8 +183,9 @@ def main():
 
     roof = None
     cpu = None
+    # every rank runs the instrumented leg (its steps contain the gradient all-reduce: a collective)
+    ms, launches, flops = roofline_leg(tr, item, min(args.steps, 20))
     if rank == 0:
-        ms, launches, flops = roofline_leg(tr, item, min(args.steps, 20))
         achieved = flops / (ms * 1e-3) / 1e12
         roof = {"bound": "mfma", "kernel": "gather_gemm_k<%s, NT=4, WAVES=8, NS=3>" % ("unsigned short" if args.dtype == "bf16" else "float"),
                 "achieved": round(achieved, 2), "peak": MFMA_BF16_PEAK_TFLOPS if args.dtype == "bf16" else 157.3,
