@@ -196,11 +196,16 @@ int rbvae_lstm_wgrad(const float* dG, const float* hs_all, const float* hprev, f
                      int layers, int accumulate, void* stream);
 
 /* torch.optim.Adam defaults (percep_RBVAE_train.py:753,553) on a flat f32 buffer; g is scaled by gscale
- * first.  The step number comes from `step` or, when step_dev != NULL, from a device counter (then
- * hyper_ws, 2 floats, receives the bias-correction terms): graph-replay safe. */
+ * first.  The step number comes from `step` or, when step_dev != NULL, from a device counter that the call
+ * first ADVANCES by one (then hyper_ws, 2 floats, receives the bias-correction terms): graph-replay safe. */
 int rbvae_adam_step(float* w, const float* g, float* m, float* v, long n, double lr, double beta1, double beta2,
-                    double eps, int step, float gscale, const unsigned long long* step_dev, float* hyper_ws,
+                    double eps, int step, float gscale, unsigned long long* step_dev, float* hyper_ws,
                     void* stream);
+/* The trainer's scalar bookkeeping in one launch (percep_RBVAE_train.py:531-549):
+ * out4 = [recon + beta*kl + alpha*pair, recon, kl, pair]; recon from `recon` or, when sse_ws != NULL,
+ * finished here as inv_n * sum(sse_ws[0..nparts)) (the col2im kernel's partial sums). */
+int rbvae_combine_losses(const float* sse_ws, int nparts, float inv_n, const float* recon, const float* kl,
+                         const float* pair, float beta, float alpha, float* out4, void* stream);
 
 /* ---- frozen LDM / Stable-Diffusion VAE encoder (cfg 5: on-the-fly latents) ------------------------
  * The convolutions, 1x1 projections and both attention products run on rbvae_gather_gemm (stride-1 and

@@ -406,6 +406,38 @@ int rbvae_col2im_sigmoid(int dtype, const void* Y, int ldy, const float* bias, i
     return RBVAE_OK;
 }
 
+// total = recon + beta*kl + alpha*pair, with recon finished from the col2im kernel's partial sums
+__global__ __launch_bounds__(1024) void combine_losses_k(const float* __restrict__ sse_ws, int nparts, float inv_n,
+                                                         const float* __restrict__ recon_in,
+                                                         const float* __restrict__ kl, const float* __restrict__ pair,
+                                                         float beta, float alpha, float* __restrict__ out4) {
+    __shared__ float red[16];
+    float recon;
+    if (sse_ws) {
+        float a = 0.f;
+        for (int i = threadIdx.x; i < nparts; i += 1024) a += sse_ws[i];
+        recon = block_sum(a, red) * inv_n;
+    } else {
+        recon = recon_in[0];
+    }
+    if (threadIdx.x == 0) {
+        const float k = kl[0], pr = pair[0];
+        out4[0] = recon + beta * k + alpha * pr;
+        out4[1] = recon;
+        out4[2] = k;
+        out4[3] = pr;
+    }
+}
+
+int rbvae_combine_losses(const float* sse_ws, int nparts, float inv_n, const float* recon, const float* kl,
+                         const float* pair, float beta, float alpha, float* out4, void* stream) {
+    RBVAE_CHECK_ARG(kl && pair && out4 && (sse_ws || recon), "combine_losses: bad arguments");
+    hipLaunchKernelGGL(combine_losses_k, dim3(1), dim3(1024), 0, (hipStream_t)stream, sse_ws, nparts, inv_n, recon, kl,
+                       pair, beta, alpha, out4);
+    RBVAE_CHECK_LAUNCH("combine_losses");
+    return RBVAE_OK;
+}
+
 int rbvae_sigmoid_bwd_nhwc(const float* g_nchw, const float* xr_nchw, float* dpre_nhwc, int N, int C, int H, int W,
                            void* stream) {
     RBVAE_CHECK_ARG(g_nchw && xr_nchw && dpre_nhwc && N > 0 && C > 0 && H > 0 && W > 0, "sigmoid_bwd_nhwc: bad arguments");
@@ -437,16 +469,19 @@ int rbvae_skinny_linear(int dtype, const void* A, const void* B, const float* bi
     return RBVAE_OK;
 }
 
-// hyper[0] = lr / (1 - b1^step), hyper[1] = sqrt(1 - b2^step) from a DEVICE step counter
-__global__ void adam_hyper_k(const unsigned long long* __restrict__ step_dev, double lr, double b1, double b2,
+// hyper[0] = lr / (1 - b1^step), hyper[1] = sqrt(1 - b2^step) from a DEVICE step counter, which this
+// kernel advances first (so a graph-replayed step needs no separate counter launch)
+__global__ void adam_hyper_k(unsigned long long* __restrict__ step_dev, double lr, double b1, double b2,
                              float* __restrict__ hyper) {
-    const double st = (double)step_dev[0];
+    const unsigned long long s1 = step_dev[0] + 1;
+    step_dev[0] = s1;
+    const double st = (double)s1;
     hyper[0] = (float)(lr / (1.0 - pow(b1, st)));
     hyper[1] = (float)sqrt(1.0 - pow(b2, st));
 }
 
 int rbvae_adam_step(float* w, const float* g, float* m, float* v, long n, double lr, double beta1, double beta2,
-                    double eps, int step, float gscale, const unsigned long long* step_dev, float* hyper_ws,
+                    double eps, int step, float gscale, unsigned long long* step_dev, float* hyper_ws,
                     void* stream) {
     RBVAE_CHECK_ARG(w && g && m && v && n > 0, "adam_step: bad arguments");
     RBVAE_CHECK_ARG(step_dev ? hyper_ws != nullptr : step >= 1, "adam_step: needs step >= 1 or step_dev + hyper_ws");

@@ -47,6 +47,7 @@ class FusedTrainer:
         self.step_dev = torch.zeros(1, dtype=torch.int64, device=dev)       # device step counter
         self.hyper = torch.zeros(2, device=dev)
         self.losses = torch.zeros(4, device=dev)                               # total, recon, kl, pair
+        self._pair = torch.zeros(1, device=dev)
         self.steps = 0
         self._graphs: Dict = {}
         self._static: Dict = {}
@@ -56,7 +57,6 @@ class FusedTrainer:
     # ---- the two halves of a step (plain launches; captured below) ------------------
     def _fwd_bwd(self, x, U, tau, B, T):
         eng, model = self.eng, self.model
-        L.call("rbvae_counter_add", self.step_dev, 1)
         numel = x.numel()
         # dropout follows the module's mode like the reference (model.train() in train_one_epoch, :501)
         out = eng.forward(model._flat, x, U, tau, False, self.r, bool(model.training), None, seed=0, need_grad=True,
@@ -64,7 +64,7 @@ class FusedTrainer:
         hs = out["hs"]                       # [2B, T, L]
         Ld = hs.shape[-1]
         h0, h1 = hs[:B], hs[B:]
-        pair = self.losses[3:4]
+        pair = self._pair
         g_hs = torch.empty_like(hs)
         if self.model.variant == "triplet":
             L.call("rbvae_triplet_term_fwd", h0, h1, B, T, Ld, float(self.margin), pair)
@@ -74,10 +74,8 @@ class FusedTrainer:
             L.call("rbvae_contrast_term_fwd", h0, h1, B, T, Ld, pair)
             L.call("rbvae_contrast_term_bwd", h0, h1, B, T, Ld, float(self.alpha), None, g_hs[:B], g_hs[B:])
         eng.backward(model._flat, self.gflat, out["saved"], None, g_hs, None, kl_weight=self.beta_kl, kl_p=self.p)
-        self.losses[1:2].copy_(out["mse"])
-        self.losses[2:3].copy_(out["kl"])
-        torch.add(out["mse"], out["kl"], alpha=self.beta_kl, out=self.losses[0:1])
-        self.losses[0:1].add_(pair, alpha=self.alpha)
+        L.call("rbvae_combine_losses", None, 0, 0.0, out["mse"], out["kl"], self._pair, float(self.beta_kl),
+               float(self.alpha), self.losses)
 
     def _update(self):
         b1, b2 = self.betas
