@@ -10,5 +10,7 @@ from . import _lib  # noqa: F401
 from .engine import VARIANTS, Engine, ParamLayout  # noqa: F401
 from .losses import (contrast_loss, contrast_term, kl_binary_concrete, kl_binary_concrete_simple,  # noqa: F401
                      l1_loss, recon_loss, triplet_loss, triplet_term)
+from .data import (DeviceStatePairDataset, assign_label, build_pairs, consistency_from_codes,  # noqa: F401
+                   split_indices, state_consistency)
 from .ldm import LDMEncoder  # noqa: F401
 from .model import Seq2SeqBinaryVAE, binary_concrete_logits  # noqa: F401

@@ -356,7 +356,7 @@ def trainer_cases(pt):
     out["label/idx"] = idx
     out["label/out"] = np.array([pt.assign_label(int(i), flags) for i in idx])
     segs = [(0, 37), (45, 100), (110, 111), (120, 180)]
-    emb = {f"{i:010d}.jpg": np.full((1, 1, 2, 2), float(i), dtype=np.float32) for i in range(200)}
+    emb = {f"{i:010d}.jpg": np.full((1, 3, 2, 2), float(i), dtype=np.float32) for i in range(200)}
     for mode in ("train", "val", "test"):
         ds = pt.ShuffledStatePairDataset(emb, segs, test_pct=0.1, val_pct=0.15, mode="train")
         for si in range(len(segs)):
@@ -365,6 +365,15 @@ def trainer_cases(pt):
             out[f"split/{si}/val"] = np.array(ds.val_indices_per_state[si], dtype=np.int64)
     out["split/segs"] = np.array(segs)
     out["split/pcts"] = np.array([0.1, 0.15])
+    import random
+    for mode in ("train", "val"):
+        random.seed(77)
+        ds = pt.ShuffledStatePairDataset(emb, segs, test_pct=0.1, val_pct=0.15, mode=mode)
+        for si, pairs in enumerate(ds.pairs_per_state):
+            out[f"pairs/{mode}/{si}"] = np.array(pairs, dtype=np.int64).reshape(-1, 2)
+        out[f"pairs/{mode}/len"] = len(ds)
+        if mode == "train":
+            out[f"pairs/{mode}/item3"] = ds[3].numpy()
     np.savez_compressed(os.path.join(OUT, "trainer.npz"), **out)
     print("trainer: temperature/labels/splits")
 
