@@ -314,7 +314,8 @@ int rbvae_cast_pad(int dtype, const float* in, void* out, int rows, int L, int L
     return RBVAE_OK;
 }
 
-static inline int colsum_rpb(int P) { return max(64, ((cdiv(P, 256) + 63) / 64) * 64); }
+// rows per block: at most 256 row blocks, at least 16 rows each (short tensors still fan out over the chip)
+static inline int colsum_rpb(int P) { return max(16, ((cdiv(P, 256) + 15) / 16) * 16); }
 size_t rbvae_colsum_ws_floats(int P, int C) { return (size_t)cdiv(P, colsum_rpb(P)) * C; }
 
 int rbvae_colsum(int dtype, const void* X, int P, int C, int ld, float* out, float* ws, float scale, int accumulate,

@@ -67,7 +67,8 @@ __global__ __launch_bounds__(512, 1) void wgrad_gemm_k(const WgArgs p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     int* s_idx = (int*)(smem + WG_NS * STAGE);            // [WG_MAXP]
 
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);     // provably uniform: scalar LDS addressing
     const int co0 = blockIdx.x * BM, ci0 = blockIdx.y * BN;
     const int tap = blockIdx.z / p.ksplit, ks = blockIdx.z - tap * p.ksplit;
     const int pbeg = ks * p.Pper;
@@ -107,15 +108,26 @@ __global__ __launch_bounds__(512, 1) void wgrad_gemm_k(const WgArgs p) {
         b_coff[i] = c * 16;
         b_cval[i] = b_wave && ci0 + c * (16 / ES) < p.Ci;
     }
+    // producer state: A rows advance by a constant stride per K step (one 64-bit add each); B rows are
+    // gathered through the index table in LDS
+    const size_t a_stride = (size_t)WG_BK * p.ldy * ES;
+    const unsigned char* acur[A_INSTR];
+#pragma unroll
+    for (int i = 0; i < A_INSTR; ++i)
+        acur[i] = p.Dy + ((size_t)(pbeg + a_row[i]) * p.ldy + co0) * ES + a_coff[i];
+    const size_t ldi_b = (size_t)p.ldi * ES;
+    const unsigned char* bbase[B_INSTR];
+#pragma unroll
+    for (int i = 0; i < B_INSTR; ++i) bbase[i] = p.In + (size_t)ci0 * ES + b_coff[i];
     int pstep = 0, pbuf = 0;
     auto stage_next = [&]() {
         unsigned char* la = smem + pbuf * STAGE + (w * A_INSTR) * 1024;
         const int base = pstep * WG_BK;
 #pragma unroll
         for (int i = 0; i < A_INSTR; ++i) {
-            const int pp = base + a_row[i];
-            const bool v = a_cval[i] && pp < npix;
-            glds16w(v ? p.Dy + ((size_t)(pbeg + pp) * p.ldy + co0) * ES + a_coff[i] : p.zero, la + i * 1024);
+            const bool v = a_cval[i] && base + a_row[i] < npix;
+            glds16w(v ? acur[i] : p.zero, la + i * 1024);
+            acur[i] += a_stride;
         }
         if (b_wave) {
             unsigned char* lb = smem + pbuf * STAGE + A_BYTES + (w * B_INSTR) * 1024;
@@ -123,7 +135,7 @@ __global__ __launch_bounds__(512, 1) void wgrad_gemm_k(const WgArgs p) {
             for (int i = 0; i < B_INSTR; ++i) {
                 const int src = s_idx[base + b_row[i]];
                 const bool v = b_cval[i] && src >= 0;
-                glds16w(v ? p.In + ((size_t)src * p.ldi + ci0) * ES + b_coff[i] : p.zero, lb + i * 1024);
+                glds16w(v ? bbase[i] + (size_t)src * ldi_b : p.zero, lb + i * 1024);
             }
         }
         ++pstep;
@@ -162,37 +174,74 @@ __global__ __launch_bounds__(512, 1) void wgrad_gemm_k(const WgArgs p) {
         for (int nt = 0; nt < NT; ++nt) offB[nt] = A_BYTES + fg * RBB + ((wc * NT + nt) * 16 + fi) * 4;
     }
 
-    auto multiply = [&](const unsigned char* lb) {
-        if constexpr (ES == 2) {
-            bf16x8_t fa[WG_BK / 32][MT], fb[WG_BK / 32][NT];
-#pragma unroll
-            for (int ksub = 0; ksub < WG_BK / 32; ++ksub) {
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt) {
-                    const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                        (__attribute__((address_space(3))) s16x4_t*)(lb + offA[mt] + ksub * 32 * RBA));
-                    const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                        (__attribute__((address_space(3))) s16x4_t*)(lb + offA[mt] + ksub * 32 * RBA + 4 * RBA));
-                    fa[ksub][mt] = bf16x8_t{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-                }
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) {
-                    const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                        (__attribute__((address_space(3))) s16x4_t*)(lb + offB[nt] + ksub * 32 * RBB));
-                    const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                        (__attribute__((address_space(3))) s16x4_t*)(lb + offB[nt] + ksub * 32 * RBB + 4 * RBB));
-                    fb[ksub][nt] = bf16x8_t{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-                }
-            }
-            __builtin_amdgcn_sched_barrier(0);      // all transposed reads in flight before the first MFMA
-#pragma unroll
-            for (int ksub = 0; ksub < WG_BK / 32; ++ksub)
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-                    for (int mt = 0; mt < MT; ++mt)
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[ksub][nt], fa[ksub][mt], acc[mt][nt], 0, 0, 0);
+    // this wave's LDS-DMA count per stage (waves that stage no B rows issue fewer)
+    const int my_loads = A_INSTR + (b_wave ? B_INSTR : 0);
+    auto wait_stage = [&](int younger_ok) {
+        if (younger_ok) {
+            // WG_NS-2 younger stages stay in flight; the immediate must match this wave's own load count
+            if (my_loads == A_INSTR + B_INSTR) wg_wait_barrier<(WG_NS - 2) * (A_INSTR + B_INSTR)>();
+            else wg_wait_barrier<(WG_NS - 2) * A_INSTR>();
         } else {
+            wg_wait_barrier<0>();       // tail: drain (conservative)
+        }
+    };
+    if constexpr (ES == 2) {
+        // one 32-pixel half of a K step: its transposed fragment reads / its MFMAs
+        auto read_half = [&](const unsigned char* lb, int ksub, bf16x8_t (&fa)[MT], bf16x8_t (&fb)[NT]) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                    (__attribute__((address_space(3))) s16x4_t*)(lb + offA[mt] + ksub * 32 * RBA));
+                const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                    (__attribute__((address_space(3))) s16x4_t*)(lb + offA[mt] + ksub * 32 * RBA + 4 * RBA));
+                fa[mt] = bf16x8_t{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            }
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                    (__attribute__((address_space(3))) s16x4_t*)(lb + offB[nt] + ksub * 32 * RBB));
+                const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                    (__attribute__((address_space(3))) s16x4_t*)(lb + offB[nt] + ksub * 32 * RBB + 4 * RBB));
+                fb[nt] = bf16x8_t{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            }
+        };
+        auto mma_half = [&](const bf16x8_t (&fa)[MT], const bf16x8_t (&fb)[NT]) {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[nt], fa[mt], acc[mt][nt], 0, 0, 0);
+        };
+        // software pipeline over the two 32-pixel halves (same structure as gather_gemm_k): the LDS serves one
+        // half while the matrix pipe works on the other; the stage barrier sits between two MFMA groups.
+        bf16x8_t fa0[MT], fb0[NT], fa1[MT], fb1[NT];
+        if (nsteps > 0) {
+#pragma unroll
+            for (int i = 0; i < WG_NS - 1; ++i)
+                if (i < nsteps) stage_next();
+            wait_stage(nsteps >= WG_NS - 1);
+            if (WG_NS - 1 < nsteps) stage_next();
+            int cbuf = 0;
+            read_half(smem, 0, fa0, fb0);
+            for (int s = 0; s < nsteps; ++s) {
+                const unsigned char* lcur = smem + cbuf * STAGE;
+                cbuf = (cbuf + 1 == WG_NS) ? 0 : cbuf + 1;
+                read_half(lcur, 1, fa1, fb1);
+                __builtin_amdgcn_sched_barrier(0);
+                mma_half(fa0, fb0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (s + 1 < nsteps) {
+                    wait_stage(nsteps - s - 2 >= WG_NS - 2);
+                    if (s + WG_NS < nsteps) stage_next();
+                    read_half(smem + cbuf * STAGE, 0, fa0, fb0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                mma_half(fa1, fb1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    } else {
+        auto multiply = [&](const unsigned char* lb) {
 #pragma unroll
             for (int sub = 0; sub < WG_BK / 4; ++sub) {
                 float fa[MT], fb[NT];
@@ -206,26 +255,17 @@ __global__ __launch_bounds__(512, 1) void wgrad_gemm_k(const WgArgs p) {
                     for (int nt = 0; nt < NT; ++nt)
                         acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(fb[nt], fa[mt], acc[mt][nt], 0, 0, 0);
             }
-        }
-    };
-
-    // this wave's LDS-DMA count per stage (waves that stage no B rows issue fewer)
-    const int my_loads = A_INSTR + (b_wave ? B_INSTR : 0);
+        };
 #pragma unroll
-    for (int i = 0; i < WG_NS - 1; ++i)
-        if (i < nsteps) stage_next();
-    int cbuf = 0;
-    for (int s = 0; s < nsteps; ++s) {
-        if (nsteps - s - 1 >= WG_NS - 2) {
-            // WG_NS-2 younger stages stay in flight; the immediate must match this wave's own load count
-            if (my_loads == A_INSTR + B_INSTR) wg_wait_barrier<(WG_NS - 2) * (A_INSTR + B_INSTR)>();
-            else wg_wait_barrier<(WG_NS - 2) * A_INSTR>();
-        } else {
-            wg_wait_barrier<0>();       // tail: drain (conservative)
+        for (int i = 0; i < WG_NS - 1; ++i)
+            if (i < nsteps) stage_next();
+        int cbuf = 0;
+        for (int s = 0; s < nsteps; ++s) {
+            wait_stage(nsteps - s - 1 >= WG_NS - 2);
+            if (s + WG_NS - 1 < nsteps) stage_next();
+            multiply(smem + cbuf * STAGE);
+            cbuf = (cbuf + 1 == WG_NS) ? 0 : cbuf + 1;
         }
-        if (s + WG_NS - 1 < nsteps) stage_next();
-        multiply(smem + cbuf * STAGE);
-        cbuf = (cbuf + 1 == WG_NS) ? 0 : cbuf + 1;
     }
 
     // D[row = ci 4g+r][col = co i]: lane owns 4 consecutive ci of one co -> one 16-B store
