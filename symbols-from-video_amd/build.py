@@ -32,8 +32,27 @@ def _compile(src):
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed on {src}:\n{r.stdout}\n{r.stderr}")
+        if src == "wgrad_gemm.hip":
+            _check_wgrad_isa(src)
         return obj, True
     return obj, False
+
+
+def _check_wgrad_isa(src):
+    """wgrad_gemm_k hides its transposed LDS reads from the compiler (inline asm); prove on the ISA that no
+    fragment register is touched before the wait that covers it (isa_check.py)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("rbvae_isa_check", os.path.join(HERE, "isa_check.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    asm = os.path.join(OBJ, src[:-4] + ".s")
+    cmd = [HIPCC] + FLAGS + ["-S", "--cuda-device-only", os.path.join(CSRC, src), "-o", asm]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"hipcc -S failed on {src}:\n{r.stderr}")
+    bad = mod.tr_asm_hazards(open(asm).read())
+    if bad:
+        raise RuntimeError("wgrad_gemm ISA check failed (fragment register touched before its wait):\n" + "\n".join(bad[:20]))
 
 
 def build(verbose=False):

@@ -413,12 +413,13 @@ template <typename T>
 static int dispatch_gg(const GgArgs& a, hipStream_t st, int max_steps) {
     const long blocks = (long)cdiv(a.Nimg * a.TH * a.TW, GG_BM) * cdiv(a.Nout, a.Nout > 64 ? 128 : 64) * a.nclass;
     static const int force = getenv("RBVAE_GG_NS") ? atoi(getenv("RBVAE_GG_NS")) : 0;
+    static const int dbg = getenv("RBVAE_GG_DBG") ? atoi(getenv("RBVAE_GG_DBG")) : 0;
     int ns = max_steps <= 2 ? 1 : (blocks > 256 ? 2 : 3);
     if (force) ns = force;
     if (a.Nout <= 64) return ns == 1 ? launch_gg<T, 2, 4, 1>(a, st) : launch_gg<T, 2, 4, 2>(a, st);
     if (ns == 1) return launch_gg<T, 4, 4, 1>(a, st);
+    if (ns >= 2 && (dbg == 5 || dbg == 6)) return dbg == 5 ? launch_gg<T, 2, 4, 3>(a, st) : launch_gg<T, 2, 4, 2>(a, st);
     if (ns == 2) return launch_gg<T, 4, 8, 2>(a, st);
-    static const int dbg = getenv("RBVAE_GG_DBG") ? atoi(getenv("RBVAE_GG_DBG")) : 0;
     if (dbg == 4) return launch_gg<T, 4, 4, 3>(a, st);       // 4 waves, 64x64 wave tiles (less LDS traffic)
     if (dbg == 1) return launch_gg<T, 4, 8, 3, 1>(a, st);
     if (dbg == 2) return launch_gg<T, 4, 8, 3, 2>(a, st);

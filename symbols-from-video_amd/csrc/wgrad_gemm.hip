@@ -14,6 +14,8 @@
 // K-slice writes its own f32 slab (summed later in a fixed order by
 // rbvae_permute_reduce, so gradients are bitwise reproducible -- no float atomics).
 #include "common.h"
+#include <stdlib.h>
+#include <type_traits>
 
 namespace rbvae {
 
@@ -43,7 +45,6 @@ template <int RB> __device__ __forceinline__ int tr_swz(int row) {
 }
 
 constexpr int WG_BM = 128;      // co per workgroup
-constexpr int WG_NS = 3;        // LDS ring depth (two K steps in flight behind the one being multiplied)
 constexpr int WG_MAXP = 4096;   // pixels of one K-slice (their gather indices live in LDS)
 
 template <int N> __device__ __forceinline__ void wg_wait_barrier() {
@@ -51,8 +52,15 @@ template <int N> __device__ __forceinline__ void wg_wait_barrier() {
 }
 
 // 8 waves as 2 (co) x 4 (ci); a wave owns 64 co x 16*NT ci; BN = 64*NT ci per workgroup.
-template <typename T, int NT>
-__global__ __launch_bounds__(512, 1) void wgrad_gemm_k(const WgArgs p) {
+// WG_NS = LDS ring depth.  3: two K steps in flight behind the one being multiplied, one workgroup per CU;
+// 2: double buffer, two workgroups per CU (grids of more than 256 workgroups).
+//
+// Workgroup order: the grid is one-dimensional and the K-slice index is the fastest digit of the workgroup
+// id.  Workgroups are dealt to the 8 XCDs round-robin by id, so with ksplit a multiple of 8 every workgroup
+// of one XCD works on the same pixel slices: all taps and channel tiles of a slice re-read its Dy / In rows
+// from that XCD's own L2 instead of from the Infinity Cache.
+template <typename T, int NT, int WG_NS>
+__global__ __launch_bounds__(512, WG_NS == 2 ? 2 : 1) void wgrad_gemm_k(const WgArgs p) {
     constexpr int ES = sizeof(T);
     constexpr int WG_BK = (ES == 2) ? 64 : 32;            // pixels per K step (one or two 32-pixel MFMA steps)
     constexpr int MT = 4;
@@ -69,8 +77,13 @@ __global__ __launch_bounds__(512, 1) void wgrad_gemm_k(const WgArgs p) {
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);     // provably uniform: scalar LDS addressing
-    const int co0 = blockIdx.x * BM, ci0 = blockIdx.y * BN;
-    const int tap = blockIdx.z / p.ksplit, ks = blockIdx.z - tap * p.ksplit;
+    int wg = blockIdx.x;
+    const int ks = wg % p.ksplit; wg /= p.ksplit;
+    const int gx = (p.Co + BM - 1) / BM, gy = (p.Ci + BN - 1) / BN;
+    const int bx = wg % gx; wg /= gx;
+    const int by = wg % gy;
+    const int tap = wg / gy;
+    const int co0 = bx * BM, ci0 = by * BN;
     const int pbeg = ks * p.Pper;
     const int pend = min(p.P, pbeg + p.Pper);
     const int npix = max(pend - pbeg, 0);
@@ -186,24 +199,50 @@ __global__ __launch_bounds__(512, 1) void wgrad_gemm_k(const WgArgs p) {
         }
     };
     if constexpr (ES == 2) {
-        // one 32-pixel half of a K step: its transposed fragment reads / its MFMAs
-        auto read_half = [&](const unsigned char* lb, int ksub, bf16x8_t (&fa)[MT], bf16x8_t (&fb)[NT]) {
+        // Transposed fragment reads are issued as inline asm: behind the ds_read_tr16 builtin the compiler
+        // conservatively drains ALL LDS-DMA (s_waitcnt vmcnt(0)) before the first read that follows a
+        // global_load_lds, which serialises the ring (measured: 1.1 us per K step instead of 0.55).  The asm
+        // reads are invisible to its wait-count pass, so each group is followed by an explicit counted
+        // s_waitcnt lgkmcnt that is tied ("+v") to the fragment registers it guards; only values that have
+        // passed such a wait are packed and handed to the MFMAs.
+        const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
+        constexpr int RPH = 2 * (MT + NT);          // LDS reads of one 32-pixel half
+        static_assert(RPH <= 15, "lgkmcnt is a 4-bit counter");
+        auto read_half = [&](unsigned lb, int ksub, s16x4_t (&alo)[MT], s16x4_t (&ahi)[MT], s16x4_t (&blo)[NT],
+                             s16x4_t (&bhi)[NT]) {
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
-                const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                    (__attribute__((address_space(3))) s16x4_t*)(lb + offA[mt] + ksub * 32 * RBA));
-                const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                    (__attribute__((address_space(3))) s16x4_t*)(lb + offA[mt] + ksub * 32 * RBA + 4 * RBA));
-                fa[mt] = bf16x8_t{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                const unsigned ad = lb + offA[mt] + ksub * 32 * RBA;
+                asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(alo[mt]) : "v"(ad));
+                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(ahi[mt]) : "v"(ad), "n"(4 * RBA));
             }
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
-                const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                    (__attribute__((address_space(3))) s16x4_t*)(lb + offB[nt] + ksub * 32 * RBB));
-                const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                    (__attribute__((address_space(3))) s16x4_t*)(lb + offB[nt] + ksub * 32 * RBB + 4 * RBB));
-                fb[nt] = bf16x8_t{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                const unsigned ad = lb + offB[nt] + ksub * 32 * RBB;
+                asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(blo[nt]) : "v"(ad));
+                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(bhi[nt]) : "v"(ad), "n"(4 * RBB));
             }
+        };
+        // wait until at most `younger` LDS reads are outstanding; returns the guarded fragments as MFMA operands
+        auto landed = [&](auto younger_tag, s16x4_t (&alo)[MT], s16x4_t (&ahi)[MT], s16x4_t (&blo)[NT],
+                          s16x4_t (&bhi)[NT], bf16x8_t (&fa)[MT], bf16x8_t (&fb)[NT]) {
+            constexpr int YOUNGER = decltype(younger_tag)::value;
+            if constexpr (NT == 2)
+                asm volatile("s_waitcnt lgkmcnt(%12)"
+                             : "+v"(alo[0]), "+v"(ahi[0]), "+v"(alo[1]), "+v"(ahi[1]), "+v"(alo[2]), "+v"(ahi[2]),
+                               "+v"(alo[3]), "+v"(ahi[3]), "+v"(blo[0]), "+v"(bhi[0]), "+v"(blo[NT - 1]), "+v"(bhi[NT - 1])
+                             : "n"(YOUNGER));
+            else
+                asm volatile("s_waitcnt lgkmcnt(%10)"
+                             : "+v"(alo[0]), "+v"(ahi[0]), "+v"(alo[1]), "+v"(ahi[1]), "+v"(alo[2]), "+v"(ahi[2]),
+                               "+v"(alo[3]), "+v"(ahi[3]), "+v"(blo[0]), "+v"(bhi[0])
+                             : "n"(YOUNGER));
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+                fa[mt] = bf16x8_t{alo[mt][0], alo[mt][1], alo[mt][2], alo[mt][3], ahi[mt][0], ahi[mt][1], ahi[mt][2], ahi[mt][3]};
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+                fb[nt] = bf16x8_t{blo[nt][0], blo[nt][1], blo[nt][2], blo[nt][3], bhi[nt][0], bhi[nt][1], bhi[nt][2], bhi[nt][3]};
         };
         auto mma_half = [&](const bf16x8_t (&fa)[MT], const bf16x8_t (&fb)[NT]) {
 #pragma unroll
@@ -214,7 +253,10 @@ __global__ __launch_bounds__(512, 1) void wgrad_gemm_k(const WgArgs p) {
         };
         // software pipeline over the two 32-pixel halves (same structure as gather_gemm_k): the LDS serves one
         // half while the matrix pipe works on the other; the stage barrier sits between two MFMA groups.
-        bf16x8_t fa0[MT], fb0[NT], fa1[MT], fb1[NT];
+        s16x4_t a0l[MT], a0h[MT], b0l[NT], b0h[NT], a1l[MT], a1h[MT], b1l[NT], b1h[NT];
+        bf16x8_t fa[MT], fb[NT];
+        using Younger = std::integral_constant<int, RPH>;
+        using None = std::integral_constant<int, 0>;
         if (nsteps > 0) {
 #pragma unroll
             for (int i = 0; i < WG_NS - 1; ++i)
@@ -222,23 +264,25 @@ __global__ __launch_bounds__(512, 1) void wgrad_gemm_k(const WgArgs p) {
             wait_stage(nsteps >= WG_NS - 1);
             if (WG_NS - 1 < nsteps) stage_next();
             int cbuf = 0;
-            read_half(smem, 0, fa0, fb0);
+            read_half(lds0, 0, a0l, a0h, b0l, b0h);
             for (int s = 0; s < nsteps; ++s) {
-                const unsigned char* lcur = smem + cbuf * STAGE;
+                const unsigned lcur = lds0 + cbuf * STAGE;
                 cbuf = (cbuf + 1 == WG_NS) ? 0 : cbuf + 1;
-                read_half(lcur, 1, fa1, fb1);
-                __builtin_amdgcn_sched_barrier(0);
-                mma_half(fa0, fb0);
-                __builtin_amdgcn_sched_barrier(0);
+                read_half(lcur, 1, a1l, a1h, b1l, b1h);
+                landed(Younger{}, a0l, a0h, b0l, b0h, fa, fb);        // half 0 landed, half 1 in flight
+                mma_half(fa, fb);
+                // half 1 landed (its reads were issued a whole MFMA group ago).  One wait site per register
+                // set keeps the compiler from merging two tied asm statements through register copies that
+                // would read a fragment before its wait.
+                landed(None{}, a1l, a1h, b1l, b1h, fa, fb);
                 if (s + 1 < nsteps) {
                     wait_stage(nsteps - s - 2 >= WG_NS - 2);
                     if (s + WG_NS < nsteps) stage_next();
-                    read_half(smem + cbuf * STAGE, 0, fa0, fb0);
+                    read_half(lds0 + cbuf * STAGE, 0, a0l, a0h, b0l, b0h);
                 }
-                __builtin_amdgcn_sched_barrier(0);
-                mma_half(fa1, fb1);
-                __builtin_amdgcn_sched_barrier(0);
+                mma_half(fa, fb);
             }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // nothing is in flight here; keeps the ISA check linear
         }
     } else {
         auto multiply = [&](const unsigned char* lb) {
@@ -297,20 +341,37 @@ __global__ void conv_gather_index_k(int* __restrict__ idx, int Nimg, int IH, int
     idx[i] = (ih >= 0 && ih < IH && iw >= 0 && iw < IW) ? (n * IH + ih) * IW + iw : -1;
 }
 
+template <typename T, int NT, int NS>
+static int launch_wg_ns(const WgArgs& a, hipStream_t st) {
+    constexpr int ES = sizeof(T);
+    constexpr int BK = (ES == 2) ? 64 : 32;
+    constexpr size_t ring = (size_t)NS * BK * (WG_BM + 64 * NT) * ES;
+    const size_t lds = ring + (size_t)a.Pper * sizeof(int);            // + this launch's index table
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute((const void*)wgrad_gemm_k<T, NT, NS>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)(ring + WG_MAXP * sizeof(int)));
+        attr_set = true;
+    }
+    const long blocks = (long)cdiv(a.Co, WG_BM) * cdiv(a.Ci, 64 * NT) * a.taps * a.ksplit;
+    hipLaunchKernelGGL((wgrad_gemm_k<T, NT, NS>), dim3((unsigned)blocks), dim3(512), lds, st, a);
+    RBVAE_CHECK_LAUNCH("wgrad_gemm");
+    return RBVAE_OK;
+}
+
 template <typename T, int NT>
 static int launch_wg(const WgArgs& a, hipStream_t st) {
     constexpr int ES = sizeof(T);
     constexpr int BK = (ES == 2) ? 64 : 32;
-    const size_t lds = (size_t)WG_NS * BK * (WG_BM + 64 * NT) * ES + WG_MAXP * sizeof(int);
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipFuncSetAttribute((const void*)wgrad_gemm_k<T, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
+    // more workgroups than CUs: two per CU (double buffer) when two rings + index tables fit the 160 KB LDS
+    const long blocks = (long)cdiv(a.Co, WG_BM) * cdiv(a.Ci, 64 * NT) * a.taps * a.ksplit;
+    const size_t lds2 = (size_t)2 * BK * (WG_BM + 64 * NT) * ES + (size_t)a.Pper * sizeof(int);
+    static const int force = getenv("RBVAE_WG_NS") ? atoi(getenv("RBVAE_WG_NS")) : 0;
+    const bool two = force ? force == 2 : (blocks > 256 && 2 * lds2 <= 160 * 1024);
+    if constexpr (ES == 2) {
+        if (force == 4 && a.Pper <= 2560) return launch_wg_ns<T, NT, 4>(a, st);
     }
-    dim3 grid(cdiv(a.Co, WG_BM), cdiv(a.Ci, 64 * NT), a.taps * a.ksplit);
-    hipLaunchKernelGGL((wgrad_gemm_k<T, NT>), grid, dim3(512), lds, st, a);
-    RBVAE_CHECK_LAUNCH("wgrad_gemm");
-    return RBVAE_OK;
+    return two ? launch_wg_ns<T, NT, 2>(a, st) : launch_wg_ns<T, NT, 3>(a, st);
 }
 
 }  // namespace rbvae
@@ -343,7 +404,6 @@ int rbvae_wgrad_gemm(int dtype, const void* Dy, const void* In, float* dW_slabs,
                     "wgrad_gemm: leading dimensions ldy=%d ldi=%d", ldy, ldi);
     RBVAE_CHECK_ARG(((uintptr_t)Dy | (uintptr_t)In | (uintptr_t)dW_slabs | (uintptr_t)zero_page) % 16 == 0,
                     "wgrad_gemm: pointers must be 16-byte aligned");
-    RBVAE_CHECK_ARG(taps * ksplit <= 65535, "wgrad_gemm: taps*ksplit=%d exceeds the grid limit", taps * ksplit);
     WgArgs a;
     a.Dy = (const unsigned char*)Dy; a.In = (const unsigned char*)In; a.dW = dW_slabs; a.idx = idx;
     a.zero = (const unsigned char*)zero_page;

@@ -348,6 +348,8 @@ class Engine:
         ks = max(1, min(256, 512 // max(blocks, 1), P // 256 if P >= 256 else 1,
                         max(1, (4 << 20) // (Co * taps * Ci))))
         ks = max(ks, -(-P // 4096))            # the kernel keeps a K-slice's gather indices in LDS (<= 4096)
+        if 256 < blocks * ks < 512:
+            ks = max(1, 256 // blocks)         # one round of workgroups on the 256 CUs, not one and a bit
         slabs = self._buf(("slabs", tag), ks * Co * taps * Ci)
         side = self._side_begin()
         L.call("rbvae_wgrad_gemm", self.dt, Dy, In, slabs, idx, self.zero, P, Co, Ci, ldy, ldi, taps, ks)
