@@ -32,14 +32,21 @@ def _compile(src):
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed on {src}:\n{r.stdout}\n{r.stderr}")
-        if src == "wgrad_gemm.hip":
-            _check_wgrad_isa(src)
+        if src in ISA_CHECKED:
+            _check_asm_reads(src)
         return obj, True
     return obj, False
 
 
-def _check_wgrad_isa(src):
-    """wgrad_gemm_k hides its transposed LDS reads from the compiler (inline asm); prove on the ISA that no
+# kernels whose LDS fragment reads are inline asm: (mangled-name prefix, read opcodes)
+ISA_CHECKED = {
+    "wgrad_gemm.hip": ("_ZN5rbvae12wgrad_gemm_k", ("ds_read_b64_tr_b16",)),
+    "gather_gemm.hip": ("_ZN5rbvae13gather_gemm_k", ("ds_read_b128",)),
+}
+
+
+def _check_asm_reads(src):
+    """The GEMM kernels hide their LDS fragment reads from the compiler (inline asm); prove on the ISA that no
     fragment register is touched before the wait that covers it (isa_check.py)."""
     import importlib.util
     spec = importlib.util.spec_from_file_location("rbvae_isa_check", os.path.join(HERE, "isa_check.py"))
@@ -50,9 +57,10 @@ def _check_wgrad_isa(src):
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"hipcc -S failed on {src}:\n{r.stderr}")
-    bad = mod.tr_asm_hazards(open(asm).read())
+    prefix, ops = ISA_CHECKED[src]
+    bad = mod.tr_asm_hazards(open(asm).read(), prefix, ops)
     if bad:
-        raise RuntimeError("wgrad_gemm ISA check failed (fragment register touched before its wait):\n" + "\n".join(bad[:20]))
+        raise RuntimeError(src + " ISA check failed (fragment register touched before its wait):\n" + "\n".join(bad[:20]))
 
 
 def build(verbose=False):

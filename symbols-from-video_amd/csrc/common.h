@@ -77,4 +77,28 @@ __device__ __forceinline__ unsigned hash_u32(unsigned long long seed, unsigned l
     return (unsigned)x;
 }
 
+// Dropout keep-mask bits: 32 uniform bits per element from a per-launch key and the element's index.
+// The 64-bit hash above costs ~230 cycles per wave-instruction-element (three 64-bit multiplies at quarter
+// rate) and, evaluated once per activation element, WAS the conv1 forward kernel's run time; this is the
+// two-round 32-bit finaliser "lowbias32" (two quarter-rate multiplies) keyed by a 64-bit mix of the seed
+// that is computed once per thread.
+struct DropKey { unsigned k0, k1; };
+__device__ __forceinline__ DropKey drop_key(unsigned long long seed) {
+    unsigned long long x = seed * 0x9E3779B97F4A7C15ull + 0xD6E8FEB86659FD93ull;
+    x ^= x >> 32; x *= 0xD6E8FEB86659FD93ull;
+    x ^= x >> 32;
+    return DropKey{(unsigned)x, (unsigned)(x >> 32)};
+}
+// start of a run of consecutive elements: fold the key and the high index bits in once
+__device__ __forceinline__ unsigned drop_run(DropKey k, unsigned long long idx) {
+    return (unsigned)idx + k.k0 + (unsigned)(idx >> 32) * k.k1;
+}
+__device__ __forceinline__ unsigned drop_bits(unsigned run, int e) {
+    unsigned x = run + (unsigned)e;
+    x ^= x >> 16; x *= 0x7feb352du;
+    x ^= x >> 15; x *= 0x846ca68bu;
+    x ^= x >> 16;
+    return x;
+}
+
 }  // namespace rbvae

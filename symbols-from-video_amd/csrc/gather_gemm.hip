@@ -23,6 +23,7 @@
 // LDS once more and leaves as whole 16-B chunks of NHWC rows.
 #include "common.h"
 #include <stdlib.h>
+#include <type_traits>
 
 namespace rbvae {
 
@@ -58,6 +59,7 @@ struct GgArgs {
     const unsigned long long* seed_dev;   // optional device step counter mixed into seed
     float* colsum_ws;          // optional [nclass * m-tiles][Nout]: per-tile column sums of the stored values
     int nclass;
+    int dephase;               // 8-wave kernels: the two waves of a SIMD stage at different points of the step
     TapClass cls[4];
 };
 
@@ -103,7 +105,7 @@ template <int N> __device__ __forceinline__ void wait_vmcnt_barrier() {
 // GG_NS = LDS ring depth.  3: two K-slices in flight behind the one being multiplied (one workgroup per
 // CU, deep K); 2: classic double buffer, two workgroups per CU; 1: single buffer for 1-2 slice problems
 // where four workgroups per CU overlap each other's load / store latencies instead.
-template <typename T, int NT, int WAVES, int GG_NS, int DBG = 0>
+template <typename T, int NT, int WAVES, int GG_NS>
 __global__ __launch_bounds__(WAVES * 64, 1) void gather_gemm_k(const GgArgs p) {
     constexpr int THREADS = WAVES * 64;
     constexpr int BN = NT * 32;
@@ -237,12 +239,39 @@ __global__ __launch_bounds__(WAVES * 64, 1) void gather_gemm_k(const GgArgs p) {
 #pragma unroll
         for (int nt = 0; nt < NTW; ++nt) acc[mt][nt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-    // one 32-k half of a slice: its MT + NTW fragment reads, and its MT x NTW MFMAs
-    auto read_half = [&](const unsigned char* lbase, int kk, u32x4_t (&fa)[MT], u32x4_t (&fb)[NTW]) {
+    // One 32-k half of a slice: its MT + NTW fragment reads, and its MT x NTW MFMAs.
+    //
+    // The fragment reads are inline asm with explicit counted waits.  Left to the compiler, the loop got an
+    // s_waitcnt lgkmcnt(0) in front of every MFMA group -- it waited for the reads of the NEXT half it had
+    // just issued, so the LDS and the matrix pipe took turns (measured 1130 cycles per slice against 512 of
+    // MFMA).  The asm reads are invisible to its wait-count pass; each group is guarded by a "+v"-tied
+    // s_waitcnt, and tools/check_tr_asm.py proves on the ISA that nothing touches a fragment register
+    // between a read and its wait.
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
+    constexpr int RPH = MT + NTW;                 // LDS reads of one half
+    static_assert(RPH <= 15, "lgkmcnt is a 4-bit counter");
+    auto read_half = [&](unsigned lbase, int kk, u32x4_t (&fa)[MT], u32x4_t (&fb)[NTW]) {
+        const unsigned aa_ = lbase + offA[kk], ab_ = lbase + offB[kk];
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) fa[mt] = *(const u32x4_t*)(lbase + offA[kk] + mt * 2048);
+        for (int mt = 0; mt < MT; ++mt)
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fa[mt]) : "v"(aa_), "n"(mt * 2048));
 #pragma unroll
-        for (int nt = 0; nt < NTW; ++nt) fb[nt] = *(const u32x4_t*)(lbase + offB[kk] + nt * 2048);
+        for (int nt = 0; nt < NTW; ++nt)
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fb[nt]) : "v"(ab_), "n"(nt * 2048));
+    };
+    // wait until at most YOUNGER LDS reads are outstanding (in-order return): the guarded fragments landed
+    auto landed = [&](auto younger_tag, u32x4_t (&fa)[MT], u32x4_t (&fb)[NTW]) {
+        constexpr int YOUNGER = decltype(younger_tag)::value;
+        static_assert(MT == 4 && (NTW == 2 || NTW == 4), "operand list below");
+        if constexpr (NTW == 2)
+            asm volatile("s_waitcnt lgkmcnt(%6)"
+                         : "+v"(fa[0]), "+v"(fa[1]), "+v"(fa[2]), "+v"(fa[3]), "+v"(fb[0]), "+v"(fb[1])
+                         : "n"(YOUNGER));
+        else
+            asm volatile("s_waitcnt lgkmcnt(%8)"
+                         : "+v"(fa[0]), "+v"(fa[1]), "+v"(fa[2]), "+v"(fa[3]), "+v"(fb[0]), "+v"(fb[1]),
+                           "+v"(fb[2]), "+v"(fb[NTW - 1])
+                         : "n"(YOUNGER));
     };
     auto mma_half = [&](const u32x4_t (&fa)[MT], const u32x4_t (&fb)[NTW]) {
 #pragma unroll
@@ -250,48 +279,60 @@ __global__ __launch_bounds__(WAVES * 64, 1) void gather_gemm_k(const GgArgs p) {
 #pragma unroll
             for (int nt = 0; nt < NTW; ++nt) Mma<T>::run(acc[mt][nt], fb[nt], fa[mt]);
     };
+    using Younger = std::integral_constant<int, RPH>;
+    using None = std::integral_constant<int, 0>;
     u32x4_t fa0[MT], fb0[NTW], fa1[MT], fb1[NTW];
     if constexpr (GG_NS == 1) {
         for (int s = 0; s < nsteps; ++s) {
             if (s > 0) __syncthreads();              // everyone is done reading the single buffer
             stage_next();
             wait_vmcnt_barrier<0>();
-            read_half(smem, 0, fa0, fb0);
-            read_half(smem, 1, fa1, fb1);
+            read_half(lds0, 0, fa0, fb0);
+            read_half(lds0, 1, fa1, fb1);
+            landed(Younger{}, fa0, fb0);
             mma_half(fa0, fb0);
+            landed(None{}, fa1, fb1);
             mma_half(fa1, fb1);
         }
     } else {
-        // Software pipeline over the 32-k halves: while the matrix pipe works on one half the LDS serves
-        // the next one, and the slice barrier sits between two MFMA groups whose operands are already in
+        // Software pipeline over the 32-k halves: while the matrix pipe works on one half the LDS serves the
+        // next one, and the slice barrier sits between two MFMA groups whose operands are already in
         // registers.  Ring: slice s is being read, slices s+1 .. s+GG_NS-1 are landed or in flight.
 #pragma unroll
         for (int i = 0; i < GG_NS - 1; ++i)
-            if (i < nsteps && DBG != 1) stage_next();
+            if (i < nsteps) stage_next();
         if (nsteps > GG_NS - 1 && GG_NS > 2) wait_vmcnt_barrier<(GG_NS > 2 ? GG_NS - 2 : 0) * LOADS>();
         else wait_vmcnt_barrier<0>();
-        if (GG_NS - 1 < nsteps && DBG != 1) stage_next();
+        if (GG_NS - 1 < nsteps) stage_next();
         int cbuf = 0;
-        read_half(smem, 0, fa0, fb0);
+        read_half(lds0, 0, fa0, fb0);
+        // Waves w and w+4 share a SIMD and leave every barrier together.  Issuing an LDS-DMA piece holds a
+        // wave for ~60-180 cycles, so the two take turns: the low wave stages the next slice right after the
+        // barrier while its partner multiplies, the high wave stages after that MFMA group.
+        const bool late = WAVES == 8 && w >= 4 && p.dephase;
         for (int s = 0; s < nsteps; ++s) {
-            const unsigned char* lcur = smem + cbuf * STAGE;
+            const unsigned lcur = lds0 + cbuf * STAGE;
             cbuf = (cbuf + 1 == GG_NS) ? 0 : cbuf + 1;
             read_half(lcur, 1, fa1, fb1);
+            landed(Younger{}, fa0, fb0);                 // half 0 landed, half 1 in flight
             __builtin_amdgcn_sched_barrier(0);
-            if (DBG != 2) mma_half(fa0, fb0);
+            mma_half(fa0, fb0);
             __builtin_amdgcn_sched_barrier(0);
+            landed(None{}, fa1, fb1);                    // issued a whole MFMA group ago (one wait site per set)
             if (s + 1 < nsteps) {
                 // slice s+1 landed (GG_NS-2 younger ones may stay in flight); after the barrier every wave
                 // holds both halves of slice s in registers, so its buffer can be refilled
                 if (GG_NS > 2 && nsteps - s - 2 >= GG_NS - 2) wait_vmcnt_barrier<(GG_NS > 2 ? GG_NS - 2 : 0) * LOADS>();
                 else wait_vmcnt_barrier<0>();
-                if (s + GG_NS < nsteps && DBG != 1) stage_next();
-                read_half(smem + cbuf * STAGE, 0, fa0, fb0);
+                if (!late && s + GG_NS < nsteps) stage_next();
+                read_half(lds0 + cbuf * STAGE, 0, fa0, fb0);
             }
             __builtin_amdgcn_sched_barrier(0);
-            if (DBG != 2) mma_half(fa1, fb1);
+            mma_half(fa1, fb1);
             __builtin_amdgcn_sched_barrier(0);
+            if (late && s + GG_NS < nsteps) stage_next();
         }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // nothing is in flight here; keeps the ISA check linear
     }
     __syncthreads();
 
@@ -334,6 +375,8 @@ __global__ __launch_bounds__(WAVES * 64, 1) void gather_gemm_k(const GgArgs p) {
     float csum[EC];
 #pragma unroll
     for (int e = 0; e < EC; ++e) csum[e] = 0.f;
+    DropKey dkey{0u, 0u};
+    if (p.drop_mode == 1) dkey = drop_key(p.seed + (p.seed_dev ? p.seed_dev[0] * 0x9E3779B97F4A7C15ull : 0ull));
     for (int idx = tid; idx < GG_BM * CPR; idx += THREADS) {
         const int row = idx / CPR, ch = idx - row * CPR;     // ch == tid % CPR on every pass
         const int orow = s_orow[row];
@@ -342,11 +385,10 @@ __global__ __launch_bounds__(WAVES * 64, 1) void gather_gemm_k(const GgArgs p) {
         u32x4_t val = *(const u32x4_t*)(tile + row * PITCH + ch * 16);
         T* ev = (T*)&val;
         if (p.drop_mode == 1) {
-            const unsigned long long sd = p.seed + (p.seed_dev ? p.seed_dev[0] * 0x9E3779B97F4A7C15ull : 0ull);
-            const unsigned long long base = (unsigned long long)orow * p.Nout + col;
+            const unsigned run = drop_run(dkey, (unsigned long long)orow * p.Nout + col);
 #pragma unroll
             for (int e = 0; e < EC; ++e)
-                if (hash_u32(sd, base + e) < p.drop_thresh) ev[e] = 0;
+                if (drop_bits(run, e) < p.drop_thresh) ev[e] = 0;
         } else if (p.drop_mode == 2) {
             const unsigned char* mk = p.mask + (size_t)orow * p.Nout + col;
 #pragma unroll
@@ -389,7 +431,7 @@ __global__ __launch_bounds__(WAVES * 64, 1) void gather_gemm_k(const GgArgs p) {
     }
 }
 
-template <typename T, int NT, int WAVES, int NS, int DBG = 0>
+template <typename T, int NT, int WAVES, int NS>
 static int launch_gg(const GgArgs& a, hipStream_t st) {
     constexpr int BN = NT * 32;
     constexpr int ES = sizeof(T);
@@ -399,12 +441,12 @@ static int launch_gg(const GgArgs& a, hipStream_t st) {
     const size_t lds = (ring > tile ? ring : tile) + GG_BM * sizeof(int) + 64 * sizeof(int);
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute((const void*)gather_gemm_k<T, NT, WAVES, NS, DBG>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        hipFuncSetAttribute((const void*)gather_gemm_k<T, NT, WAVES, NS>, hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)lds);
         attr_set = true;
     }
     dim3 grid(cdiv(Mc, GG_BM), cdiv(a.Nout, BN), a.nclass);
-    hipLaunchKernelGGL((gather_gemm_k<T, NT, WAVES, NS, DBG>), grid, dim3(WAVES * 64), lds, st, a);
+    hipLaunchKernelGGL((gather_gemm_k<T, NT, WAVES, NS>), grid, dim3(WAVES * 64), lds, st, a);
     RBVAE_CHECK_LAUNCH("gather_gemm");
     return RBVAE_OK;
 }
@@ -421,8 +463,6 @@ static int dispatch_gg(const GgArgs& a, hipStream_t st, int max_steps) {
     if (ns >= 2 && (dbg == 5 || dbg == 6)) return dbg == 5 ? launch_gg<T, 2, 4, 3>(a, st) : launch_gg<T, 2, 4, 2>(a, st);
     if (ns == 2) return launch_gg<T, 4, 8, 2>(a, st);
     if (dbg == 4) return launch_gg<T, 4, 4, 3>(a, st);       // 4 waves, 64x64 wave tiles (less LDS traffic)
-    if (dbg == 1) return launch_gg<T, 4, 8, 3, 1>(a, st);
-    if (dbg == 2) return launch_gg<T, 4, 8, 3, 2>(a, st);
     if (ns >= 4) return launch_gg<T, 4, 8, 4>(a, st);
     return launch_gg<T, 4, 8, 3>(a, st);
 }
@@ -461,6 +501,8 @@ extern "C" int rbvae_gather_gemm(int dtype, const void* A, const void* W, void* 
     a.relu = relu; a.drop_mode = drop_mode; a.scale = scale; a.seed = seed; a.seed_dev = seed_dev; a.colsum_ws = colsum_ws;
     a.drop_thresh = (unsigned)((double)drop_p * 4294967296.0);
     a.nclass = nclass;
+    static const int dephase = getenv("RBVAE_GG_DEPHASE") ? atoi(getenv("RBVAE_GG_DEPHASE")) : 1;
+    a.dephase = dephase;
     // class_desc (host ints): per class [ntaps, oh0, ow0, then ntaps x (widx, dh, dw)], classes back to back
     const int* d = class_desc;
     for (int c = 0; c < nclass; ++c) {

@@ -1,46 +1,98 @@
-"""Build-time check of the wgrad kernels' ISA.
+"""Build-time check of the GEMM kernels' ISA.
 
-wgrad_gemm_k issues its transposed LDS reads (ds_read_b64_tr_b16) as inline asm so that the compiler's
-wait-count pass does not drain the LDS-DMA ring in front of them; the price is that the compiler no longer
-knows those registers are filled asynchronously.  The source guards every group with a tied s_waitcnt; this
-check proves it on the generated code: between such a read and the wait that covers it no instruction may
-touch a register the read is still filling (the hardware does not interlock them)."""
+gather_gemm_k and wgrad_gemm_k issue their LDS fragment reads (ds_read_b128 / ds_read_b64_tr_b16) as inline
+asm so that the compiler's wait-count pass neither drains the LDS-DMA ring nor the LDS queue in front of
+them; the price is that the compiler no longer knows those registers are filled asynchronously.  The source
+guards every group with a tied s_waitcnt; this check proves it on the generated code: on every path of the
+kernel's control-flow graph, between such a read and the wait that covers it no instruction may touch a
+register the read is still filling (the hardware does not interlock them)."""
 import re
 
+_BR = re.compile(r"^(s_cbranch_\w+|s_branch)\s+(\S+)")
 
-def tr_asm_hazards(asm_text, kernel_prefix="_ZN5rbvae12wgrad_gemm_k"):
-    """Returns a list of 'kernel: message' strings (empty = clean).  Linear scan in text order, which is
-    conservative for this kernel: every loop exit passes a full s_waitcnt lgkmcnt(0)."""
+
+def _blocks(body):
+    """Split a kernel's text into basic blocks: {label: (instructions, successors)}; entry label is '^'."""
+    blocks, order, cur, name = {}, [], [], "^"
+    for raw in body.splitlines()[1:]:
+        ln = raw.split(";")[0].strip()
+        if not ln:
+            continue
+        if ln.endswith(":") and not ln.startswith("s_") and " " not in ln:
+            blocks[name] = cur; order.append(name)
+            name, cur = ln[:-1], []
+            continue
+        if ln.startswith("."):
+            continue
+        cur.append(ln)
+        if _BR.match(ln) or ln.startswith("s_endpgm") or ln.startswith("s_setpc"):
+            blocks[name] = cur; order.append(name)
+            name, cur = f"{name}+{len(order)}", []
+    blocks[name] = cur; order.append(name)
+    succ = {}
+    for i, n in enumerate(order):
+        ins = blocks[n]
+        nxt = order[i + 1] if i + 1 < len(order) else None
+        last = ins[-1] if ins else ""
+        m = _BR.match(last)
+        if last.startswith("s_endpgm"):
+            succ[n] = []
+        elif m and m.group(1) == "s_branch":
+            succ[n] = [m.group(2)]
+        elif m:
+            succ[n] = [m.group(2)] + ([nxt] if nxt else [])
+        else:
+            succ[n] = [nxt] if nxt else []
+    return blocks, succ
+
+
+def _regs(text):
+    used = set()
+    for a, b in re.findall(r"\bv\[(\d+):(\d+)\]", text):
+        used |= set(range(int(a), int(b) + 1))
+    used |= set(int(x) for x in re.findall(r"\bv(\d+)\b", text))
+    return used
+
+
+def tr_asm_hazards(asm_text, kernel_prefix="_ZN5rbvae12wgrad_gemm_k", read_ops=("ds_read_b64_tr_b16",)):
+    """Returns a list of 'kernel: message' strings (empty = clean).  Forward data flow over the kernel's CFG;
+    the state is the in-order queue of in-flight reads (each a set of destination registers), one visit per
+    (block, state)."""
     out = []
     for m in re.finditer(r"^(" + re.escape(kernel_prefix) + r"\w+):.*?s_endpgm", asm_text, re.S | re.M):
-        reads = []          # in-flight transposed reads, oldest first (each: set of destination registers)
-        for ln in m.group(0).splitlines():
-            ln = ln.split(";")[0].strip()
-            if not ln or ln.endswith(":") or ln.startswith("."):
+        blocks, succ = _blocks(m.group(0))
+        seen, work, msgs = set(), [("^", ())], set()
+        while work:
+            name, state = work.pop()
+            if (name, state) in seen or name not in blocks:
                 continue
-            op, _, rest = ln.partition(" ")
-            if op == "ds_read_b64_tr_b16":
-                d = re.match(r"\s*v\[(\d+):(\d+)\]", rest)
-                regs = set(range(int(d.group(1)), int(d.group(2)) + 1))
-                uses = set(int(x) for x in re.findall(r"\bv(\d+)\b", rest.split(",", 1)[1]))
-                pending = set().union(*reads) if reads else set()
-                if uses & pending:
-                    out.append(f"{m.group(1)}: in-flight register used as address: {ln}")
-                reads.append(regs)
-                continue
-            if op == "s_waitcnt" and "lgkmcnt" in rest:
-                n = int(re.search(r"lgkmcnt\((\d+)\)", rest).group(1))
-                # LDS returns in order: at most the n youngest operations are still outstanding (other LGKM
-                # operations in between only make this more conservative)
-                reads = reads[len(reads) - n:] if n else []
-                continue
-            if not reads:
-                continue
-            pending = set().union(*reads)
-            used = set()
-            for a, b in re.findall(r"v\[(\d+):(\d+)\]", rest):
-                used |= set(range(int(a), int(b) + 1))
-            used |= set(int(x) for x in re.findall(r"\bv(\d+)\b", rest))
-            if used & pending:
-                out.append(f"{m.group(1)}: touches in-flight v{sorted(used & pending)}: {ln}")
+            seen.add((name, state))
+            if len(seen) > 200000:
+                msgs.add("state explosion: check aborted"); break
+            reads = list(state)
+            for ln in blocks[name]:
+                op, _, rest = ln.partition(" ")
+                if op in read_ops:
+                    dst, _, addr = rest.partition(",")
+                    pending = set().union(*reads) if reads else set()
+                    if _regs(addr) & pending:
+                        msgs.add(f"in-flight register used as address: {ln}")
+                    if _regs(dst) & pending:
+                        msgs.add(f"in-flight register overwritten by a second read: {ln}")
+                    reads.append(frozenset(_regs(dst)))
+                    reads = reads[-15:]
+                    continue
+                if op == "s_waitcnt" and "lgkmcnt" in rest:
+                    n = int(re.search(r"lgkmcnt\((\d+)\)", rest).group(1))
+                    # LDS returns in order: at most the n youngest operations are still outstanding (other
+                    # LGKM operations in between only make this more conservative)
+                    reads = reads[len(reads) - n:] if n else []
+                    continue
+                if reads:
+                    hit = _regs(rest) & set().union(*reads)
+                    if hit:
+                        msgs.add(f"touches in-flight v{sorted(hit)}: {ln}")
+            for nx in succ[name]:
+                work.append((nx, tuple(reads)))
+        out += [f"{m.group(1)}: {x}" for x in sorted(msgs)]
     return out

@@ -1,0 +1,99 @@
+"""The build-time ISA check (symbols-from-video_amd/isa_check.py) on hand-written instruction streams:
+it must accept the guarded pattern the GEMM kernels use and reject every way a fragment register can be
+touched before the wait that covers its asynchronous LDS read."""
+import importlib.util
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+spec = importlib.util.spec_from_file_location("isa_check", os.path.join(HERE, "..", "symbols-from-video_amd", "isa_check.py"))
+isa_check = importlib.util.module_from_spec(spec)
+spec.loader.exec_module(isa_check)
+
+PFX = "_ZN5rbvae12wgrad_gemm_k"
+
+
+def kernel(body):
+    return f"{PFX}ItLi2ELi3EEEvNS_6WgArgsE:\n" + body + "\n\ts_endpgm\n"
+
+
+def check(body):
+    return isa_check.tr_asm_hazards(kernel(body), PFX, ("ds_read_b64_tr_b16",))
+
+
+def test_guarded_pipeline_is_clean():
+    body = """
+	ds_read_b64_tr_b16 v[0:1], v40
+	ds_read_b64_tr_b16 v[2:3], v40 offset:1024
+.LBB0_1:
+	ds_read_b64_tr_b16 v[4:5], v41
+	ds_read_b64_tr_b16 v[6:7], v41 offset:1024
+	s_waitcnt lgkmcnt(2)
+	v_mfma_f32_16x16x32_bf16 v[20:23], v[0:3], v[0:3], v[20:23]
+	s_waitcnt lgkmcnt(0)
+	s_cbranch_scc1 .LBB0_3
+	s_barrier
+	ds_read_b64_tr_b16 v[0:1], v40
+	ds_read_b64_tr_b16 v[2:3], v40 offset:1024
+.LBB0_3:
+	v_mfma_f32_16x16x32_bf16 v[20:23], v[4:7], v[4:7], v[20:23]
+	s_cbranch_scc0 .LBB0_1
+	s_waitcnt lgkmcnt(0)
+	global_store_dwordx4 v[30:31], v[20:23], off
+"""
+    assert check(body) == []
+
+
+def test_copy_before_wait_is_flagged():
+    body = """
+	ds_read_b64_tr_b16 v[0:1], v40
+	v_mov_b64_e32 v[8:9], v[0:1]
+	s_waitcnt lgkmcnt(0)
+"""
+    bad = check(body)
+    assert len(bad) == 1 and "touches in-flight" in bad[0]
+
+
+def test_counted_wait_releases_only_the_oldest():
+    body = """
+	ds_read_b64_tr_b16 v[0:1], v40
+	ds_read_b64_tr_b16 v[2:3], v40 offset:1024
+	s_waitcnt lgkmcnt(1)
+	v_mov_b32_e32 v9, v0
+	v_mov_b32_e32 v10, v2
+	s_waitcnt lgkmcnt(0)
+"""
+    bad = check(body)
+    assert len(bad) == 1 and "v[2]" in bad[0]
+
+
+def test_hazard_through_the_loop_back_edge():
+    # the read at the bottom of the loop is still in flight when the top of the next iteration uses v0
+    body = """
+.LBB0_1:
+	v_add_u32_e32 v9, v0, v9
+	ds_read_b64_tr_b16 v[0:1], v40
+	s_cbranch_scc0 .LBB0_1
+	s_waitcnt lgkmcnt(0)
+"""
+    bad = check(body)
+    assert any("touches in-flight v[0]" in b for b in bad)
+
+
+def test_in_flight_register_as_address_or_second_destination():
+    body = """
+	ds_read_b64_tr_b16 v[0:1], v40
+	ds_read_b64_tr_b16 v[2:3], v1
+	ds_read_b64_tr_b16 v[0:1], v41
+	s_waitcnt lgkmcnt(0)
+"""
+    bad = check(body)
+    assert any("used as address" in b for b in bad) and any("second read" in b for b in bad)
+
+
+def test_built_kernels_are_clean_when_the_listing_exists():
+    # build() writes the listings next to the objects; absent on a checkout that has not been built
+    for src, (prefix, ops) in (("wgrad_gemm", (PFX, ("ds_read_b64_tr_b16",))),
+                               ("gather_gemm", ("_ZN5rbvae13gather_gemm_k", ("ds_read_b128",)))):
+        path = os.path.join(HERE, "..", "symbols-from-video_amd", "build", src + ".s")
+        if os.path.exists(path):
+            assert isa_check.tr_asm_hazards(open(path).read(), prefix, ops) == []

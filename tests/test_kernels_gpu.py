@@ -99,6 +99,36 @@ def test_dropout_modes(sfv, dtype):
     assert torch.equal(out, out2)                                       # same seed -> same mask, bitwise
 
 
+def test_hash_dropout_statistics(sfv):
+    """Counter-hash keep-masks (drop_mode 1): Bernoulli(0.8) per element, no row / column / neighbour
+    structure, and unrelated masks for different seeds (nn.Dropout(0.2), percep_RBVAE_model.py:53)."""
+    g = torch.Generator().manual_seed(5)
+    M, K, Nout = 4096, 64, 256
+    A = (torch.rand(M, K, generator=g) + 0.5).bfloat16()
+    Wt = (torch.rand(Nout, K, generator=g) + 0.5).bfloat16()         # positive products: no accidental zeros
+    masks = []
+    for seed in (11, 12):
+        out = torch.empty(M, Nout, dtype=torch.bfloat16, device="cuda")
+        gemm(sfv, DT["bf16"][0], A.cuda(), Wt.cuda(), out, None, None, None, (M, 1, 1, 1, 1, 1, 1, 1, 1), K, Nout, 1,
+             [1, 0, 0, 0, 0, 0], 1, drop_mode=1, drop_p=0.2, scale=1.25, seed=seed)
+        masks.append((out.float().cpu() != 0))
+    k0, k1 = masks[0].float(), masks[1].float()
+    n = k0.numel()
+    sig = (0.16 / n) ** 0.5
+    assert abs(k0.mean().item() - 0.8) < 5 * sig and abs(k1.mean().item() - 0.8) < 5 * sig
+    # rows (256 draws each) and columns (4096 draws each): worst deviation stays within ~5 sigma of its own scale
+    assert (k0.mean(1) - 0.8).abs().max().item() < 5.5 * (0.16 / Nout) ** 0.5
+    assert (k0.mean(0) - 0.8).abs().max().item() < 5.5 * (0.16 / M) ** 0.5
+    # neighbours along a row, along a column, and the same element under another seed are uncorrelated
+    def corr(a, b):
+        a, b = a.flatten() - a.mean(), b.flatten() - b.mean()
+        return (a * b).mean().item() / 0.16
+    assert abs(corr(k0[:, :-1], k0[:, 1:])) < 0.01
+    assert abs(corr(k0[:-1, :], k0[1:, :])) < 0.01
+    assert abs(corr(k0[:, :-8], k0[:, 8:])) < 0.01                    # across 16-byte store chunks
+    assert abs(corr(k0, k1)) < 0.01
+
+
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
 @pytest.mark.parametrize("k,C,Co,N,H,W,ks", [(3, 64, 64, 3, 16, 24, 1), (3, 256, 256, 2, 8, 8, 2), (4, 64, 128, 2, 16, 16, 3),
                                               (3, 128, 72, 5, 10, 6, 1)])

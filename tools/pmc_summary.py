@@ -2,7 +2,8 @@
 """Per-kernel averages of rocprofv3 --pmc counters (counter_collection.csv)."""
 import csv, glob, sys, collections
 d = sys.argv[1]
-f = glob.glob(f"{d}/**/*counter_collection.csv", recursive=True)[0]
+import os
+f = max(glob.glob(f"{d}/**/*counter_collection.csv", recursive=True), key=os.path.getmtime)
 rows = list(csv.DictReader(open(f)))
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for r in rows:

@@ -6,11 +6,16 @@ import sys
 import collections
 
 d = sys.argv[1]
-f = glob.glob(f"{d}/**/*_kernel_trace.csv", recursive=True)[0]
+import os
+f = max(glob.glob(f"{d}/**/*_kernel_trace.csv", recursive=True), key=os.path.getmtime)
 rows = list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 names = [r["Kernel_Name"] for r in rows]
 marks = [i for i, n in enumerate(names) if "counter_add" in n]
+if len(marks) < 12:
+    marks = [i for i, n in enumerate(names) if "pack3" in n or "cast_pad_k" in n and False]
+if len(marks) < 12:
+    marks = [i for i, n in enumerate(names) if "adam_k" in n]
 a, b = marks[-12], marks[-2]          # 10 steps
 steps = 10
 agg = collections.OrderedDict()
