@@ -6,7 +6,8 @@ namespace rbvae {
 
 // 16 x int64 per job
 struct Job {
-    long type;        // 0 pack3 (f32 -> T, strided scatter), 1 permute_reduce (thread per output), 2 reduce_rows (wave per output)
+    long type;        // 0 pack3 (f32 -> T, strided scatter), 1 permute_reduce (thread per output), 2 reduce_rows (wave per
+                      // output), 3 conv weight [co][ci][kk] f32 -> both GEMM orders [co][t][ci] (dst) and [ci][t][co] (dst2)
     const float* src;
     void* dst;
     long d0, d1, d2;  // logical extents [d0][d1][d2] (the contiguous side is laid out in this order)
@@ -16,12 +17,62 @@ struct Job {
     long accumulate;
     float scale;
     int fast;         // which logical index consecutive threads walk (the one whose strided-side stride is 1)
-    long pad1, pad2;
+    long inner;       // types 0/1 with fast == 1: a thread walks the whole (short) last index itself
+    void* dst2;       // type 3: the second destination
 };
 static_assert(sizeof(Job) == 16 * 8, "job table stride");
 
+// Type 3: one read of a conv / conv-transpose weight [co][ci][kk] (contiguous f32 rows of TCI*kk values)
+// through an LDS tile, written out in both orders the GEMMs use -- [co][t][ci] for the forward GEMM and
+// [ci][t][co] for the backward-data GEMM -- as 64- to 128-byte runs on both sides.
+constexpr int CP_TCO = 16;                             // co per tile: 128 tiles for a 256 x 256 weight
+constexpr int CP_LDSF = CP_TCO * (32 * 9 + 1);        // floats: 32 ci x 9 taps, or 16 ci x 16 taps, +1 pad
+template <typename T, unsigned KK>      // KK = taps as a compile-time constant (index math by constant), 0 = runtime
+__device__ __forceinline__ void conv_pack_tile(const Job& j, float* tile) {
+    const unsigned Co = (unsigned)j.d0, Ci = (unsigned)j.d1, kk = KK ? KK : (unsigned)j.d2;
+    const unsigned TCI = kk <= 9 ? 32u : 16u;
+    const unsigned row = TCI * kk, pitch = row + 1;
+    const unsigned tco = (Co + CP_TCO - 1) / CP_TCO, tci = (Ci + TCI - 1) / TCI;
+    T* wf = (T*)j.dst;
+    T* wd = (T*)j.dst2;
+    for (unsigned t = blockIdx.x; t < tco * tci; t += gridDim.x) {
+        const unsigned co0 = (t / tci) * CP_TCO, ci0 = (t % tci) * TCI;
+        __syncthreads();
+        for (unsigned i = threadIdx.x; i < CP_TCO * row; i += 256) {
+            const unsigned r = i / row, e = i - r * row;
+            const unsigned c = e / kk;
+            float v = 0.f;
+            if (co0 + r < Co && ci0 + c < Ci) v = j.src[((size_t)(co0 + r) * Ci + ci0) * kk + e];
+            tile[r * pitch + e] = v;
+        }
+        __syncthreads();
+        for (unsigned i = threadIdx.x; i < CP_TCO * row; i += 256) {
+            // [co][t][ci]: ci fastest
+            const unsigned c = i % TCI, q = i / TCI;
+            const unsigned tp = q % kk, r = q / kk;
+            if (co0 + r < Co && ci0 + c < Ci)
+                Elem<T>::store(wf + ((size_t)(co0 + r) * kk + tp) * Ci + ci0 + c, tile[r * pitch + c * kk + tp]);
+        }
+        for (unsigned i = threadIdx.x; i < CP_TCO * row; i += 256) {
+            // [ci][t][co]: co fastest
+            const unsigned r = i % CP_TCO, q = i / CP_TCO;
+            const unsigned tp = q % kk, c = q / kk;
+            if (co0 + r < Co && ci0 + c < Ci)
+                Elem<T>::store(wd + ((size_t)(ci0 + c) * kk + tp) * Co + co0 + r, tile[r * pitch + c * kk + tp]);
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void run_jobs_k(const Job* __restrict__ jobs) {
+    __shared__ float cp_tile[CP_LDSF];
     const Job j = jobs[blockIdx.y];
+    if (j.type == 3) {
+        const bool f32 = j.dtype == RBVAE_F32;
+        if (j.d2 == 9) { if (f32) conv_pack_tile<float, 9>(j, cp_tile); else conv_pack_tile<bf16_t, 9>(j, cp_tile); }
+        else if (j.d2 == 16) { if (f32) conv_pack_tile<float, 16>(j, cp_tile); else conv_pack_tile<bf16_t, 16>(j, cp_tile); }
+        else { if (f32) conv_pack_tile<float, 0>(j, cp_tile); else conv_pack_tile<bf16_t, 0>(j, cp_tile); }
+        return;
+    }
     const unsigned d0 = (unsigned)j.d0, d1 = (unsigned)j.d1, d2 = (unsigned)j.d2;
     const unsigned n = d0 * d1 * d2;
     // this job may need fewer blocks than the launch provides
@@ -37,6 +88,42 @@ __global__ __launch_bounds__(256) void run_jobs_k(const Job* __restrict__ jobs) 
             for (unsigned k = lane; k < ns; k += 64) a += j.src[(size_t)k * slab + c];
             a = wave_sum(a) * j.scale;
             if (lane == 0) out[c] = j.accumulate ? out[c] + a : a;
+        }
+        return;
+    }
+    if (j.inner) {
+        // fast == 1 with a short last index (conv weights: [co][ci][kk] on the contiguous side, ci-major rows on
+        // the strided side): a thread owns (i0, i1) and walks i2 itself, so the strided side is read / written
+        // as whole rows of consecutive i1 and the contiguous side as d2-element runs per thread
+        const unsigned ns = (unsigned)j.nslab;
+        for (unsigned i = blockIdx.x * 256 + threadIdx.x; i < d0 * d1; i += gridDim.x * 256) {
+            const unsigned i1 = i % d1, i0 = i / d1;
+            const size_t lin0 = (size_t)i * d2;
+            const size_t so0 = i0 * (size_t)j.s0 + i1 * (size_t)j.s1;
+            if (j.type == 0) {
+                for (unsigned i2 = 0; i2 < d2; ++i2) {
+                    const size_t so = so0 + i2 * (size_t)j.s2;
+                    if (j.dtype == RBVAE_F32) ((float*)j.dst)[so] = j.src[lin0 + i2];
+                    else ((bf16_t*)j.dst)[so] = f32_to_bf16(j.src[lin0 + i2]);
+                }
+            } else {
+                // all d2 (<= 16) loads of a slab are independent and in flight together; slabs in fixed order
+                float a[16];
+#pragma unroll
+                for (int i2 = 0; i2 < 16; ++i2) a[i2] = 0.f;
+                const float* p = j.src + so0;
+                for (unsigned k = 0; k < ns; ++k, p += j.slab) {
+                    float v[16];
+#pragma unroll
+                    for (int i2 = 0; i2 < 16; ++i2) v[i2] = (unsigned)i2 < d2 ? p[(size_t)i2 * j.s2] : 0.f;
+#pragma unroll
+                    for (int i2 = 0; i2 < 16; ++i2) a[i2] += v[i2];
+                }
+                float* out = (float*)j.dst + lin0;
+#pragma unroll
+                for (int i2 = 0; i2 < 16; ++i2)
+                    if ((unsigned)i2 < d2) out[i2] = j.accumulate ? out[i2] + a[i2] * j.scale : a[i2] * j.scale;
+            }
         }
         return;
     }

@@ -138,7 +138,7 @@ def dgrad_classes(k: int) -> Tuple[List[int], int]:
 
 ONE_TAP = [1, 0, 0, 0, 0, 0]
 
-JOB_PACK, JOB_PERMUTE, JOB_ROWS = 0, 1, 2
+JOB_PACK, JOB_PERMUTE, JOB_ROWS, JOB_CONV_PACK = 0, 1, 2, 3
 
 
 class JobList:
@@ -158,9 +158,20 @@ class JobList:
             if strides[ax] == 1 and dims[ax] > 1:
                 fast = ax
                 break
+        # ... unless that index is the middle one of a long row with a short last index (conv weights): then a
+        # thread walks the last index itself and both sides move in runs
+        inner = int(kind in (JOB_PACK, JOB_PERMUTE) and fast == 1 and dims[2] <= 16 and dims[1] >= 64)
         self.rows.append([kind, src.data_ptr(), dst.data_ptr(), dims[0], dims[1], dims[2], strides[0], strides[1],
-                          strides[2], nslab, slab, dtype, int(accumulate), bits | (fast << 32), 0, 0])
+                          strides[2], nslab, slab, dtype, int(accumulate), bits | (fast << 32), inner, 0])
         self.keep += [src, dst]
+
+    def add_conv_pack(self, src, wf, wd, co, ci, kk, dtype):
+        """f32 weight [co][ci][kk] -> [co][t][ci] (wf) and [ci][t][co] (wd) in one pass."""
+        if kk > 16:
+            raise ValueError("conv weight pack supports kernels up to 4x4")
+        self.rows.append([JOB_CONV_PACK, src.data_ptr(), wf.data_ptr(), co, ci, kk, 0, 0, 0, 1, 0, dtype, 0, 0, 0,
+                          wd.data_ptr()])
+        self.keep += [src, wf, wd]
 
     def upload(self, device):
         return torch.tensor(self.rows, dtype=torch.int64).to(device)
@@ -272,8 +283,7 @@ class Engine:
                                      (f"decoder_cnn.deconv.{i0}.weight", self.V1f, self.V1d, c3, c2),
                                      (f"decoder_cnn.deconv.{i1}.weight", self.V2f, self.V2d, c2, c1)):
             w = P(name)                                               # [co][ci][kk]
-            pk(w, wf, (co, ci, kk), (kk * ci, 1, ci))                 # [co][t][ci]
-            pk(w, wd, (co, ci, kk), (1, kk * co, co))                 # [ci][t][co]
+            jl.add_conv_pack(w, wf, wd, co, ci, kk, dt)               # [co][t][ci] and [ci][t][co]
         v3 = P(f"decoder_cnn.deconv.{i2}.weight")                     # [c1][out][kk]
         pk(v3, self.V3p, (c1, self.out_ch, kk), (1, c1, self.out_ch * c1))       # [(t*out+co)][c1]
         pk(v3, self.V3f, (c1, self.out_ch, kk), (self.K3, 1, self.out_ch))       # [c1][t*out+co]
@@ -343,13 +353,11 @@ class Engine:
     def _wgrad(self, Dy, In, idx, P, Co, Ci, ldy, ldi, taps, out, dims, strides, tag=None):
         """wgrad GEMM into K-slice slabs; their fixed-order reduction into the torch layout is a job."""
         blocks = -(-Co // 128) * -(-Ci // (128 if Ci > 64 else 64)) * taps
-        # K-slices: enough workgroups to cover the chip (~2 per CU), each with >= 256 pixels, and at most
-        # ~16 MB of f32 slabs to reduce afterwards
-        ks = max(1, min(256, 512 // max(blocks, 1), P // 256 if P >= 256 else 1,
+        # K-slices: one round of workgroups on the 256 CUs, each with >= 256 pixels, and at most ~16 MB of f32
+        # slabs to reduce afterwards
+        ks = max(1, min(256 // max(blocks, 1), P // 256 if P >= 256 else 1,
                         max(1, (4 << 20) // (Co * taps * Ci))))
         ks = max(ks, -(-P // 4096))            # the kernel keeps a K-slice's gather indices in LDS (<= 4096)
-        if 256 < blocks * ks < 512:
-            ks = max(1, 256 // blocks)         # one round of workgroups on the 256 CUs, not one and a bit
         slabs = self._buf(("slabs", tag), ks * Co * taps * Ci)
         side = self._side_begin()
         L.call("rbvae_wgrad_gemm", self.dt, Dy, In, slabs, idx, self.zero, P, Co, Ci, ldy, ldi, taps, ks)

@@ -1,0 +1,37 @@
+"""Per-row timing of the two batched job launches (weight pack, gradient reduce) of the bench workload."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import sfv_amd as sfv
+from importlib import import_module
+trainer_mod = import_module("symbols-from-video_amd.trainer")
+L = sfv._lib
+dev = torch.device("cuda", 0)
+torch.manual_seed(1234)
+model = sfv.Seq2SeqBinaryVAE(4, 4, 32, 32, variant="percep", input_hw=(32, 32), compute_dtype="bf16").to(dev).train()
+item = torch.randn(16, 2, 8, 4, 32, 32, device=dev)
+tr = trainer_mod.FusedTrainer(model, lr=1e-3, alpha=1.0, beta_kl=1.0, bernoulli_p=0.1, noise_ratio=0.1,
+                              device_noise=True, use_graph=False)
+for _ in range(3):
+    tr.step(item, 0.7)
+torch.cuda.synchronize()
+eng = list(model._engines.values())[0]
+names = {0: "pack", 1: "permute_reduce", 2: "reduce_rows", 3: "conv_pack"}
+def time_tab(label, tab, n, jl):
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    def t(ptr, cnt):
+        for _ in range(3):
+            L.call("rbvae_run_jobs", ptr, cnt, 256)
+        a.record()
+        for _ in range(20):
+            L.call("rbvae_run_jobs", ptr, cnt, 256)
+        b.record(); torch.cuda.synchronize()
+        return a.elapsed_time(b) / 20 * 1e3
+    print(f"{label}: {n} jobs, all together {t(tab, n):.1f} us")
+    for i, r in enumerate(jl.rows):
+        us = t(tab[i:], 1)
+        print(f"  job {i:2d} {names[r[0]]:15s} dims=({r[3]},{r[4]},{r[5]}) strides=({r[6]},{r[7]},{r[8]}) nslab={r[9]} fast={r[13] >> 32} inner={r[14]}: {us:6.1f} us")
+for key, (tab, n, jl) in eng._pack_tab.items():
+    time_tab("pack", tab, n, jl)
+for sig, (tab, n, jl) in eng._bwd_tab.items():
+    time_tab("bwd reduce", tab, n, jl)
