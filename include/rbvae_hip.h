@@ -198,6 +198,10 @@ int rbvae_lstm_bwd(const float* wblk, const float* acts, const float* cs, const 
                    int S, int T, int L, int layers, void* stream);
 int rbvae_lstm_wgrad(const float* dG, const float* hs_all, const float* hprev, float* gblk, int S, int T, int L,
                      int layers, int accumulate, void* stream);
+/* the same for two stacks of equal shape (the encoder and decoder LSTMs) in one launch */
+int rbvae_lstm_wgrad_pair(const float* dG_a, const float* hs_a, const float* hprev_a, float* gblk_a, const float* dG_b,
+                          const float* hs_b, const float* hprev_b, float* gblk_b, int S, int T, int L, int layers,
+                          int accumulate, void* stream);
 
 /* torch.optim.Adam defaults (percep_RBVAE_train.py:753,553) on a flat f32 buffer; g is scaled by gscale
  * first.  The step number comes from `step` or, when step_dev != NULL, from a device counter that the call

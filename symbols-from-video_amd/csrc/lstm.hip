@@ -420,11 +420,17 @@ constexpr int LW_JT = 8;
 template <int LW_KMAX>          // ceil((L + 1) / 32): 2 for L <= 32, 3 for L <= 64, 5 for L <= 128
 __global__ __launch_bounds__(256) void lstm_wgrad_tiled_k(const float* __restrict__ dG, const float* __restrict__ hs_all,
                                                           const float* __restrict__ hprev, float* __restrict__ gblk,
-                                                          int S, int T, int L, int accumulate) {
+                                                          const float* __restrict__ dG2, const float* __restrict__ hs_all2,
+                                                          const float* __restrict__ hprev2, float* __restrict__ gblk2,
+                                                          int S, int T, int L, int layers, int accumulate) {
     extern __shared__ float sm[];
     float* sg = sm;                         // [LW_ROWS][LW_JT gate rows]
     float* sx = sg + LW_ROWS * LW_JT;       // [LW_ROWS][L + 1]   (column L holds 1.0: the bias column)
-    const int l = blockIdx.z, hh = blockIdx.y, j0 = blockIdx.x * LW_JT;
+    // grid.z = layers of the first stack, then (optionally) layers of a second one: encoder and decoder
+    // stacks share one launch
+    int l = blockIdx.z;
+    if (l >= layers) { l -= layers; dG = dG2; hs_all = hs_all2; hprev = hprev2; gblk = gblk2; }
+    const int hh = blockIdx.y, j0 = blockIdx.x * LW_JT;
     const int jj = threadIdx.x & (LW_JT - 1), kq = threadIdx.x / LW_JT;     // kq in [0, 32)
     const int R = S * T, LP = L + 1;
     const float* g = dG + (long)l * R * 4 * L;
@@ -540,23 +546,38 @@ int rbvae_lstm_bwd(const float* wblk, const float* acts, const float* cs, const 
     return RBVAE_OK;
 }
 
-int rbvae_lstm_wgrad(const float* dG, const float* hs_all, const float* hprev, float* gblk, int S, int T, int L,
-                     int layers, int accumulate, void* stream) {
-    RBVAE_CHECK_ARG(dG && hs_all && hprev && gblk && S > 0 && T > 0 && L > 0 && layers > 0, "lstm_wgrad: bad arguments");
-    dim3 grid(cdiv(4 * L, LW_JT), 2, layers);
+static int launch_lstm_wgrad(const float* dG, const float* hs_all, const float* hprev, float* gblk, const float* dG2,
+                             const float* hs_all2, const float* hprev2, float* gblk2, int S, int T, int L, int layers,
+                             int accumulate, void* stream) {
+    dim3 grid(cdiv(4 * L, LW_JT), 2, dG2 ? 2 * layers : layers);
     const size_t lds = (size_t)(LW_ROWS * LW_JT + LW_ROWS * (L + 1)) * sizeof(float);
     RBVAE_CHECK_ARG(lds <= 64 * 1024, "lstm_wgrad: L=%d too large", L);
     if (L <= 32)
-        hipLaunchKernelGGL(lstm_wgrad_tiled_k<2>, grid, dim3(256), lds, (hipStream_t)stream, dG, hs_all, hprev, gblk, S,
-                           T, L, accumulate);
+        hipLaunchKernelGGL(lstm_wgrad_tiled_k<2>, grid, dim3(256), lds, (hipStream_t)stream, dG, hs_all, hprev, gblk, dG2,
+                           hs_all2, hprev2, gblk2, S, T, L, layers, accumulate);
     else if (L <= 64)
-        hipLaunchKernelGGL(lstm_wgrad_tiled_k<3>, grid, dim3(256), lds, (hipStream_t)stream, dG, hs_all, hprev, gblk, S,
-                           T, L, accumulate);
+        hipLaunchKernelGGL(lstm_wgrad_tiled_k<3>, grid, dim3(256), lds, (hipStream_t)stream, dG, hs_all, hprev, gblk, dG2,
+                           hs_all2, hprev2, gblk2, S, T, L, layers, accumulate);
     else
-        hipLaunchKernelGGL(lstm_wgrad_tiled_k<5>, grid, dim3(256), lds, (hipStream_t)stream, dG, hs_all, hprev, gblk, S,
-                           T, L, accumulate);
+        hipLaunchKernelGGL(lstm_wgrad_tiled_k<5>, grid, dim3(256), lds, (hipStream_t)stream, dG, hs_all, hprev, gblk, dG2,
+                           hs_all2, hprev2, gblk2, S, T, L, layers, accumulate);
     RBVAE_CHECK_LAUNCH("lstm_wgrad");
     return RBVAE_OK;
+}
+
+int rbvae_lstm_wgrad(const float* dG, const float* hs_all, const float* hprev, float* gblk, int S, int T, int L,
+                     int layers, int accumulate, void* stream) {
+    RBVAE_CHECK_ARG(dG && hs_all && hprev && gblk && S > 0 && T > 0 && L > 0 && layers > 0, "lstm_wgrad: bad arguments");
+    return launch_lstm_wgrad(dG, hs_all, hprev, gblk, nullptr, nullptr, nullptr, nullptr, S, T, L, layers, accumulate,
+                             stream);
+}
+
+int rbvae_lstm_wgrad_pair(const float* dG_a, const float* hs_a, const float* hprev_a, float* gblk_a, const float* dG_b,
+                          const float* hs_b, const float* hprev_b, float* gblk_b, int S, int T, int L, int layers,
+                          int accumulate, void* stream) {
+    RBVAE_CHECK_ARG(dG_a && hs_a && hprev_a && gblk_a && dG_b && hs_b && hprev_b && gblk_b && S > 0 && T > 0 && L > 0 &&
+                        layers > 0, "lstm_wgrad_pair: bad arguments");
+    return launch_lstm_wgrad(dG_a, hs_a, hprev_a, gblk_a, dG_b, hs_b, hprev_b, gblk_b, S, T, L, layers, accumulate, stream);
 }
 
 }  // extern "C"

@@ -600,9 +600,6 @@ class Engine:
         dGe = tmp("dG_enc", nl, S, T, 4 * Ld, dtype=f32)
         d_in_dec = tmp("d_in_dec", N, Ld, dtype=f32)
         L.call("rbvae_lstm_bwd", wdec, sv.acts_dec, sv.cs_dec, dds, dG, d_in_dec, S, T, Ld, nl)
-        side = self._side_begin()
-        L.call("rbvae_lstm_wgrad", dG, sv.hs_dec, sv.hp_dec, G("decoder_rnn.lstm.weight_ih_l0"), S, T, Ld, nl, 0)
-        self._side_end(side)
         de = tmp("de", N, Ld, dtype=f32)
         if not v.simple_order:
             # z -> binarise backward (+ fused KL) -> gradient of h_seq
@@ -616,14 +613,16 @@ class Engine:
                 dh = dh + g_hs.reshape(N, Ld)
             L.call("rbvae_lstm_bwd", wenc, sv.acts_enc, sv.cs_enc, dh, dGe, de, S, T, Ld, nl)
             side = self._side_begin()
-            L.call("rbvae_lstm_wgrad", dGe, sv.hs_enc, sv.hp_enc, G("encoder_rnn.lstm.weight_ih_l0"), S, T, Ld, nl, 0)
+            L.call("rbvae_lstm_wgrad_pair", dG, sv.hs_dec, sv.hp_dec, G("decoder_rnn.lstm.weight_ih_l0"),
+                   dGe, sv.hs_enc, sv.hp_enc, G("encoder_rnn.lstm.weight_ih_l0"), S, T, Ld, nl, 0)
             self._side_end(side)
         else:
             # decoder stack input = encoder stack output
             dz = tmp("dz", N, Ld, dtype=f32)
             L.call("rbvae_lstm_bwd", wenc, sv.acts_enc, sv.cs_enc, d_in_dec, dGe, dz, S, T, Ld, nl)
             side = self._side_begin()
-            L.call("rbvae_lstm_wgrad", dGe, sv.hs_enc, sv.hp_enc, G("encoder_rnn.lstm.weight_ih_l0"), S, T, Ld, nl, 0)
+            L.call("rbvae_lstm_wgrad_pair", dG, sv.hs_dec, sv.hp_dec, G("decoder_rnn.lstm.weight_ih_l0"),
+                   dGe, sv.hs_enc, sv.hp_enc, G("encoder_rnn.lstm.weight_ih_l0"), S, T, Ld, nl, 0)
             self._side_end(side)
             L.call("rbvae_binarize_kl_bwd", dz, sv.y, sv.z, de, 0, N, Ld, float(sv.tau), 0.0, None, 0.5, 1e-10, 0)
             if g_e is not None:

@@ -200,6 +200,12 @@ def test_lstm_forward_backward(sfv, L, layers, S, T):
     sfv._lib.call("rbvae_lstm_wgrad", dG, hs, hp, gb, S, T, L, layers, 0)
     ref = torch.cat([p[n].grad.reshape(-1) for n in names])
     assert rel(gb.cpu(), ref) < 1e-5
+    # the two-stack launch (encoder + decoder LSTMs of one step) computes each stack exactly as the single one
+    dG2, hs2, hp2 = dG.flip(1).contiguous(), hs.flip(1).contiguous(), hp.flip(1).contiguous()
+    gb2, ga, gbb = torch.empty_like(wblk), torch.empty_like(wblk), torch.empty_like(wblk)
+    sfv._lib.call("rbvae_lstm_wgrad", dG2, hs2, hp2, gb2, S, T, L, layers, 0)
+    sfv._lib.call("rbvae_lstm_wgrad_pair", dG, hs, hp, ga, dG2, hs2, hp2, gbb, S, T, L, layers, 0)
+    assert torch.equal(ga, gb) and torch.equal(gbb, gb2)
 
 
 def test_im2col_col2im(sfv):
