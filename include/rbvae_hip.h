@@ -59,6 +59,14 @@ int rbvae_binarize_kl_fwd(const float* h, const float* U, float* y_soft, float* 
                           int rows, int L, float tau, float noise_ratio, float noise_eps, int hard,
                           float kl_p, float kl_eps, int kl_clamp, unsigned long long seed,
                           const unsigned long long* seed_dev, void* stream);
+/* The same over many workgroups (256 elements each): kl_parts[b] = sum over block b of the per-element KL terms,
+ * b < rbvae_binarize_kl_nparts(rows, L); kl_mean = sum(kl_parts) / rows is left to rbvae_combine_losses.  The
+ * one-workgroup form above is ALU-latency bound at the trainer's 256 x 32 logits; this one is not. */
+int rbvae_binarize_kl_nparts(int rows, int L);
+int rbvae_binarize_kl_fwd_parts(const float* h, const float* U, float* y_soft, float* z, float* kl_parts,
+                                int rows, int L, float tau, float noise_ratio, float noise_eps, int hard,
+                                float kl_p, float kl_eps, int kl_clamp, unsigned long long seed,
+                                const unsigned long long* seed_dev, void* stream);
 /* dh (+)= (g_z + kl_weight * gscale * dKL/dz) * y_soft*(1-y_soft)/tau (straight-through when hard).
  * g_z may be NULL; gscale_dev (device scalar, may be NULL = 1) multiplies kl_weight. */
 int rbvae_binarize_kl_bwd(const float* g_z, const float* y_soft, const float* z, float* dh, int accumulate,
@@ -174,8 +182,11 @@ int rbvae_im2col(int dtype, const float* src, long sn, long sc, long sh, long sw
 /* Last ConvTranspose2d + Sigmoid (percep_RBVAE_model.py:82-83) fused with recon_loss
  * (percep_RBVAE_train.py:32-33): Y[(n,a,b)][t*Cout+co] = per-tap products; gathers them (col2im),
  * adds bias, applies sigmoid, writes x_recon NCHW f32; with target: sse_mean[0] = mse and
- * dpre[n][oh][ow][co] = gscale*gscale_dev*(xr-x)*xr*(1-xr).  ws >= col2im_ws_floats floats. */
+ * dpre[n][oh][ow][co] = gscale*gscale_dev*(xr-x)*xr*(1-xr).  ws >= col2im_ws_floats floats.
+ * sse_mean == NULL with ws and target given: the rbvae_col2im_nparts(N*OH*OW*Cout) per-block partial sums of
+ * squared error stay in ws for rbvae_combine_losses to finish (one launch fewer per training step). */
 size_t rbvae_col2im_ws_floats(void);
+int rbvae_col2im_nparts(long n_out);
 int rbvae_col2im_sigmoid(int dtype, const void* Y, int ldy, const float* bias, int N, int IH, int IW, int OH,
                          int OW, int Cout, int KH, int KW, int pad, float* xr, const float* target,
                          float* sse_mean, float* ws, float* dpre, float gscale, const float* gscale_dev,
@@ -205,15 +216,21 @@ int rbvae_lstm_wgrad_pair(const float* dG_a, const float* hs_a, const float* hpr
 
 /* torch.optim.Adam defaults (percep_RBVAE_train.py:753,553) on a flat f32 buffer; g is scaled by gscale
  * first.  The step number comes from `step` or, when step_dev != NULL, from a device counter that the call
- * first ADVANCES by one (then hyper_ws, 2 floats, receives the bias-correction terms): graph-replay safe. */
+ * first ADVANCES by one (then hyper_ws, 2 floats, receives the bias-correction terms): graph-replay safe.
+ * step_dev == NULL with hyper_ws != NULL: hyper_ws already holds the terms (rbvae_combine_losses prepared them). */
 int rbvae_adam_step(float* w, const float* g, float* m, float* v, long n, double lr, double beta1, double beta2,
                     double eps, int step, float gscale, unsigned long long* step_dev, float* hyper_ws,
                     void* stream);
 /* The trainer's scalar bookkeeping in one launch (percep_RBVAE_train.py:531-549):
  * out4 = [recon + beta*kl + alpha*pair, recon, kl, pair]; recon from `recon` or, when sse_ws != NULL,
- * finished here as inv_n * sum(sse_ws[0..nparts)) (the col2im kernel's partial sums). */
+ * finished here as inv_n * sum(sse_ws[0..nparts)) (the col2im kernel's partial sums); kl = kl[0] or, when
+ * kl_parts > 0, kl_scale * sum(kl[0..kl_parts)) (rbvae_binarize_kl_fwd_parts' per-block sums).
+ * step_dev != NULL: also advances the device step counter and leaves Adam's bias-correction terms for that step
+ * in hyper_ws (2 floats); rbvae_adam_step(step_dev = NULL, hyper_ws) then uses them without a launch of its own. */
 int rbvae_combine_losses(const float* sse_ws, int nparts, float inv_n, const float* recon, const float* kl,
-                         const float* pair, float beta, float alpha, float* out4, void* stream);
+                         int kl_parts, float kl_scale, const float* pair, float beta, float alpha, float* out4,
+                         unsigned long long* step_dev, double lr, double beta1, double beta2, float* hyper_ws,
+                         void* stream);
 
 /* ---- frozen LDM / Stable-Diffusion VAE encoder (cfg 5: on-the-fly latents) ------------------------
  * The convolutions, 1x1 projections and both attention products run on rbvae_gather_gemm (stride-1 and

@@ -262,8 +262,12 @@ __global__ __launch_bounds__(WAVES * 64, 1) void gather_gemm_k(const GgArgs p) {
     // wait until at most YOUNGER LDS reads are outstanding (in-order return): the guarded fragments landed
     auto landed = [&](auto younger_tag, u32x4_t (&fa)[MT], u32x4_t (&fb)[NTW]) {
         constexpr int YOUNGER = decltype(younger_tag)::value;
-        static_assert(MT == 4 && (NTW == 2 || NTW == 4), "operand list below");
-        if constexpr (NTW == 2)
+        static_assert(MT == 4 && (NTW == 1 || NTW == 2 || NTW == 4), "operand list below");
+        if constexpr (NTW == 1)
+            asm volatile("s_waitcnt lgkmcnt(%5)"
+                         : "+v"(fa[0]), "+v"(fa[1]), "+v"(fa[2]), "+v"(fa[3]), "+v"(fb[0])
+                         : "n"(YOUNGER));
+        else if constexpr (NTW == 2)
             asm volatile("s_waitcnt lgkmcnt(%6)"
                          : "+v"(fa[0]), "+v"(fa[1]), "+v"(fa[2]), "+v"(fa[3]), "+v"(fb[0]), "+v"(fb[1])
                          : "n"(YOUNGER));
@@ -459,6 +463,12 @@ static int dispatch_gg(const GgArgs& a, hipStream_t st, int max_steps) {
     int ns = max_steps <= 2 ? 1 : (blocks > 256 ? 2 : 3);
     if (force) ns = force;
     if (a.Nout <= 64) return ns == 1 ? launch_gg<T, 2, 4, 1>(a, st) : launch_gg<T, 2, 4, 2>(a, st);
+    // deep-K problems with too few 128x128 tiles for the 256 CUs: narrower tiles (more workgroups, shorter steps)
+    static const int small = getenv("RBVAE_GG_SMALL") ? atoi(getenv("RBVAE_GG_SMALL")) : 2;
+    if (ns == 3 && !force && !dbg && small) {
+        if (small >= 2 && blocks <= 64) return launch_gg<T, 1, 4, 3>(a, st);
+        if (blocks <= 128) return launch_gg<T, 2, 4, 3>(a, st);
+    }
     if (ns == 1) return launch_gg<T, 4, 4, 1>(a, st);
     if (ns >= 2 && (dbg == 5 || dbg == 6)) return dbg == 5 ? launch_gg<T, 2, 4, 3>(a, st) : launch_gg<T, 2, 4, 2>(a, st);
     if (ns == 2) return launch_gg<T, 4, 8, 2>(a, st);

@@ -132,25 +132,71 @@ __global__ void im2col_k(const float* __restrict__ src, long sn, long sc, long s
     }
 }
 
+// 32-bit-index variant for the shapes of this path (the 64-bit divisions and the per-element runtime divisions
+// of the general kernel above made it ALU bound: ~1000 instructions per 16-byte store).  CC / KWC > 0 fix the
+// channel count and kernel width at compile time (divisions become shifts / multiplies); 0 = runtime values.
+template <typename T, int CC, int KWC>
+__global__ __launch_bounds__(256) void im2col_fast_k(const float* __restrict__ src, int sn, int sc, int sh, int sw,
+                                                     int N, int C_, int IH, int IW, int OH, int OW, int KH, int KW_,
+                                                     int stride, int pad, int Kpad, T* __restrict__ col) {
+    const unsigned C = CC > 0 ? CC : C_, KW = KWC > 0 ? KWC : KW_;
+    const unsigned gpr = Kpad >> 3;
+    const unsigned tot = (unsigned)N * OH * OW * gpr;
+    const unsigned kreal = KH * KW * C;
+    const unsigned i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= tot) return;
+    const unsigned pp = i / gpr, kg = i - pp * gpr;
+    const unsigned r = pp / OW, ow = pp - r * OW;
+    const unsigned n = r / OH, oh = r - n * OH;
+    const int ih0 = (int)oh * stride - pad, iw0 = (int)ow * stride - pad;
+    const float* base = src + n * sn;
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const unsigned kx = kg * 8 + e;
+        const unsigned kxc = kx < kreal ? kx : 0;
+        const unsigned t = kxc / C, c = kxc - t * C;
+        const unsigned kh = t / KW, kw = t - kh * KW;
+        const int ih = ih0 + (int)kh, iw = iw0 + (int)kw;
+        const bool ok = kx < kreal && ih >= 0 && ih < IH && iw >= 0 && iw < IW;
+        const int ihc = min(max(ih, 0), IH - 1), iwc = min(max(iw, 0), IW - 1);
+        const float x = base[(int)c * sc + ihc * sh + iwc * sw];      // unconditional load, the select zeroes padding
+        v[e] = ok ? x : 0.f;
+    }
+    T* dst = col + (size_t)pp * Kpad + kg * 8;
+    if constexpr (sizeof(T) == 2) {
+        uint4 pk;
+        pk.x = (unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16);
+        pk.y = (unsigned)f32_to_bf16(v[2]) | ((unsigned)f32_to_bf16(v[3]) << 16);
+        pk.z = (unsigned)f32_to_bf16(v[4]) | ((unsigned)f32_to_bf16(v[5]) << 16);
+        pk.w = (unsigned)f32_to_bf16(v[6]) | ((unsigned)f32_to_bf16(v[7]) << 16);
+        *(uint4*)dst = pk;
+    } else {
+        *(float4*)dst = make_float4(v[0], v[1], v[2], v[3]);
+        *(float4*)(dst + 4) = make_float4(v[4], v[5], v[6], v[7]);
+    }
+}
+
 // ---- last ConvTranspose2d: col2im gather + bias + sigmoid (+ MSE, + d(loss)/d(pre)) ----
 // Y[(n,a,b)][t*Cout + co] holds each input pixel's contribution to every tap.
-template <typename T>
+// IDX = unsigned for outputs below 2^31 elements (64-bit divisions cost ~100 instructions each), else long
+template <typename T, typename IDX>
 __global__ __launch_bounds__(256) void col2im_sigmoid_k(
     const T* __restrict__ Y, int ldy, const float* __restrict__ bias, int N, int IH, int IW, int OH, int OW,
     int Cout, int KH, int KW, int pad, float* __restrict__ xr, const float* __restrict__ target,
     float* __restrict__ sse_ws, float* __restrict__ dpre, float gscale, const float* __restrict__ gs_dev) {
     __shared__ float red[4];
-    const long tot = (long)N * OH * OW * Cout;
+    const IDX tot = (IDX)N * OH * OW * Cout;
     float sse = 0.f;
     float gsc = gscale;
     if (gs_dev) gsc *= gs_dev[0];
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < tot; i += (long)gridDim.x * blockDim.x) {
+    for (IDX i = (IDX)blockIdx.x * blockDim.x + threadIdx.x; i < tot; i += (IDX)gridDim.x * blockDim.x) {
         // i enumerates the NCHW output: (n, co, oh, ow), ow fastest -> coalesced xr/target accesses
-        const int ow = (int)(i % OW);
-        long r = i / OW;
-        const int oh = (int)(r % OH);
-        r /= OH;
-        const int co = (int)(r % Cout), n = (int)(r / Cout);
+        IDX r = i / (IDX)OW;
+        const int ow = (int)(i - r * (IDX)OW);
+        IDX r2 = r / (IDX)OH;
+        const int oh = (int)(r - r2 * (IDX)OH);
+        const int n = (int)(r2 / (IDX)Cout), co = (int)(r2 - (IDX)n * (IDX)Cout);
         float v = bias ? bias[co] : 0.f;
         for (int kh = (oh + pad) & 1; kh < KH; kh += 2) {
             const int a = (oh + pad - kh) >> 1;
@@ -216,15 +262,28 @@ __global__ __launch_bounds__(512) void skinny_linear_k(const T* __restrict__ A, 
     const T* bp = B + (long)(nv ? n : 0) * ldb + g * EC;
     f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
     const u32x4_t z = {0u, 0u, 0u, 0u};
-    for (int k = w * KS; k < K; k += 8 * KS) {
-        const u32x4_t a = mv ? *(const u32x4_t*)(ap + k) : z;
-        const u32x4_t b = nv ? *(const u32x4_t*)(bp + k) : z;
-        if constexpr (ES == 2) {
-            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8_t*)&a, *(const bf16x8_t*)&b, acc, 0, 0, 0);
-        } else {
-            const f32x4_t af = *(const f32x4_t*)&a, bf = *(const f32x4_t*)&b;
+    // batches of UB K-steps: all 2*UB operand loads are in flight before the first MFMA (one step per iteration
+    // paid a memory round trip per step: 16 of them at K = 4096)
+    constexpr int UB = 8;
+    for (int k0 = w * KS; k0 < K; k0 += UB * 8 * KS) {
+        u32x4_t a[UB], b[UB];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[q], bf[q], acc, 0, 0, 0);
+        for (int u = 0; u < UB; ++u) {
+            const int k = k0 + u * 8 * KS;
+            const bool kv = k < K;
+            a[u] = (mv && kv) ? *(const u32x4_t*)(ap + k) : z;
+            b[u] = (nv && kv) ? *(const u32x4_t*)(bp + k) : z;
+        }
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+            if (k0 + u * 8 * KS >= K) break;
+            if constexpr (ES == 2) {
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8_t*)&a[u], *(const bf16x8_t*)&b[u], acc, 0, 0, 0);
+            } else {
+                const f32x4_t af = *(const f32x4_t*)&a[u], bf = *(const f32x4_t*)&b[u];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[q], bf[q], acc, 0, 0, 0);
+            }
         }
     }
     // D[row = m-local 4g+r][col = n-local i]
@@ -367,19 +426,39 @@ int rbvae_im2col(int dtype, const float* src, long sn, long sc, long sh, long sw
     RBVAE_CHECK_ARG(src && col && N > 0 && C > 0 && Kpad >= KH * KW * C, "im2col: bad arguments");
     RBVAE_CHECK_ARG(Kpad % 8 == 0 && (uintptr_t)col % 16 == 0, "im2col: Kpad=%d must be a multiple of 8, col 16-byte aligned", Kpad);
     const long tot = (long)N * OH * OW * (Kpad / 8);
-    if (dtype == RBVAE_F32)
-        hipLaunchKernelGGL(im2col_k<float>, dim3(grid_for(tot, 256, 8192)), dim3(256), 0, (hipStream_t)stream, src,
+    RBVAE_CHECK_ARG(dtype == RBVAE_F32 || dtype == RBVAE_BF16, "im2col: dtype %d", dtype);
+    hipStream_t st = (hipStream_t)stream;
+    // largest source offset the kernel forms (all strides non-negative in this library's callers)
+    const long span = (long)(N - 1) * sn + (long)(C - 1) * sc + (long)(IH - 1) * sh + (long)(IW - 1) * sw;
+    const bool fast = tot < (1l << 31) - 256 && span < (1l << 31) && (long)N * OH * OW * Kpad < (1l << 40) &&
+                      sn >= 0 && sc >= 0 && sh >= 0 && sw >= 0;
+    if (fast) {
+        const dim3 grid(cdiv(tot, 256));
+#define RBVAE_IM2COL(TT, CC, KK)                                                                                      \
+    hipLaunchKernelGGL((im2col_fast_k<TT, CC, KK>), grid, dim3(256), 0, st, src, (int)sn, (int)sc, (int)sh, (int)sw, N, \
+                       C, IH, IW, OH, OW, KH, KW, stride, pad, Kpad, (TT*)col)
+        if (dtype == RBVAE_F32) {
+            if (C == 4 && KW == 3) RBVAE_IM2COL(float, 4, 3);
+            else if (C == 3 && KW == 3) RBVAE_IM2COL(float, 3, 3);
+            else RBVAE_IM2COL(float, 0, 0);
+        } else {
+            if (C == 4 && KW == 3) RBVAE_IM2COL(bf16_t, 4, 3);
+            else if (C == 3 && KW == 3) RBVAE_IM2COL(bf16_t, 3, 3);
+            else RBVAE_IM2COL(bf16_t, 0, 0);
+        }
+#undef RBVAE_IM2COL
+    } else if (dtype == RBVAE_F32)
+        hipLaunchKernelGGL(im2col_k<float>, dim3(grid_for(tot, 256, 8192)), dim3(256), 0, st, src,
                            sn, sc, sh, sw, N, C, IH, IW, OH, OW, KH, KW, stride, pad, Kpad, (float*)col);
-    else if (dtype == RBVAE_BF16)
-        hipLaunchKernelGGL(im2col_k<bf16_t>, dim3(grid_for(tot, 256, 8192)), dim3(256), 0, (hipStream_t)stream, src,
-                           sn, sc, sh, sw, N, C, IH, IW, OH, OW, KH, KW, stride, pad, Kpad, (bf16_t*)col);
     else
-        return fail(RBVAE_E_INVALID, "im2col: dtype %d", dtype);
+        hipLaunchKernelGGL(im2col_k<bf16_t>, dim3(grid_for(tot, 256, 8192)), dim3(256), 0, st, src,
+                           sn, sc, sh, sw, N, C, IH, IW, OH, OW, KH, KW, stride, pad, Kpad, (bf16_t*)col);
     RBVAE_CHECK_LAUNCH("im2col");
     return RBVAE_OK;
 }
 
-size_t rbvae_col2im_ws_floats(void) { return 1024; }
+size_t rbvae_col2im_ws_floats(void) { return 4096; }
+int rbvae_col2im_nparts(long n_out) { return grid_for(n_out, 256, 4096); }
 
 int rbvae_col2im_sigmoid(int dtype, const void* Y, int ldy, const float* bias, int N, int IH, int IW, int OH,
                          int OW, int Cout, int KH, int KW, int pad, float* xr, const float* target,
@@ -389,20 +468,20 @@ int rbvae_col2im_sigmoid(int dtype, const void* Y, int ldy, const float* bias, i
     RBVAE_CHECK_ARG(!sse_mean || (target && ws), "col2im_sigmoid: sse_mean needs target and ws");
     RBVAE_CHECK_ARG(!dpre || target, "col2im_sigmoid: dpre needs target");
     const long tot = (long)N * OH * OW * Cout;
-    const int nb = grid_for(tot, 256, 1024);
-    float* sws = sse_mean ? ws : nullptr;
-    if (dtype == RBVAE_F32)
-        hipLaunchKernelGGL(col2im_sigmoid_k<float>, dim3(nb), dim3(256), 0, (hipStream_t)stream, (const float*)Y, ldy,
-                           bias, N, IH, IW, OH, OW, Cout, KH, KW, pad, xr, target, sws, dpre, gscale, gscale_dev);
-    else if (dtype == RBVAE_BF16)
-        hipLaunchKernelGGL(col2im_sigmoid_k<bf16_t>, dim3(nb), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)Y,
-                           ldy, bias, N, IH, IW, OH, OW, Cout, KH, KW, pad, xr, target, sws, dpre, gscale,
-                           gscale_dev);
-    else
-        return fail(RBVAE_E_INVALID, "col2im_sigmoid: dtype %d", dtype);
+    RBVAE_CHECK_ARG(dtype == RBVAE_F32 || dtype == RBVAE_BF16, "col2im_sigmoid: dtype %d", dtype);
+    const int nb = grid_for(tot, 256, 4096);
+    // sse_mean == NULL with ws given: leave the nb per-block partial sums in ws (rbvae_combine_losses finishes them)
+    float* sws = (sse_mean || ws) && target ? ws : nullptr;
+    hipStream_t st = (hipStream_t)stream;
+    const bool small = tot < (1l << 31) - (1l << 20) && (long)N * IH * IW * ldy < (1l << 31);
+#define RBVAE_COL2IM(TT, II)                                                                                       \
+    hipLaunchKernelGGL((col2im_sigmoid_k<TT, II>), dim3(nb), dim3(256), 0, st, (const TT*)Y, ldy, bias, N, IH, IW, OH, \
+                       OW, Cout, KH, KW, pad, xr, target, sws, dpre, gscale, gscale_dev)
+    if (dtype == RBVAE_F32) { if (small) RBVAE_COL2IM(float, unsigned); else RBVAE_COL2IM(float, long); }
+    else { if (small) RBVAE_COL2IM(bf16_t, unsigned); else RBVAE_COL2IM(bf16_t, long); }
+#undef RBVAE_COL2IM
     if (sse_mean)
-        hipLaunchKernelGGL(sum_partials_k, dim3(1), dim3(1024), 0, (hipStream_t)stream, ws, nb, 1.0f / (float)tot,
-                           sse_mean, 0);
+        hipLaunchKernelGGL(sum_partials_k, dim3(1), dim3(1024), 0, st, ws, nb, 1.0f / (float)tot, sse_mean, 0);
     RBVAE_CHECK_LAUNCH("col2im_sigmoid");
     return RBVAE_OK;
 }
@@ -410,9 +489,20 @@ int rbvae_col2im_sigmoid(int dtype, const void* Y, int ldy, const float* bias, i
 // total = recon + beta*kl + alpha*pair, with recon finished from the col2im kernel's partial sums
 __global__ __launch_bounds__(1024) void combine_losses_k(const float* __restrict__ sse_ws, int nparts, float inv_n,
                                                          const float* __restrict__ recon_in,
-                                                         const float* __restrict__ kl, const float* __restrict__ pair,
-                                                         float beta, float alpha, float* __restrict__ out4) {
+                                                         const float* __restrict__ kl, int kl_parts, float kl_scale,
+                                                         const float* __restrict__ pair,
+                                                         float beta, float alpha, float* __restrict__ out4,
+                                                         unsigned long long* __restrict__ step_dev, double lr,
+                                                         double b1, double b2, float* __restrict__ hyper) {
     __shared__ float red[16];
+    if (step_dev && threadIdx.x == 64) {
+        // the optimiser's bias corrections for the step that follows (what adam_hyper_k does as its own launch)
+        const unsigned long long s1 = step_dev[0] + 1;
+        step_dev[0] = s1;
+        const double st = (double)s1;
+        hyper[0] = (float)(lr / (1.0 - pow(b1, st)));
+        hyper[1] = (float)sqrt(1.0 - pow(b2, st));
+    }
     float recon;
     if (sse_ws) {
         float a = 0.f;
@@ -421,8 +511,16 @@ __global__ __launch_bounds__(1024) void combine_losses_k(const float* __restrict
     } else {
         recon = recon_in[0];
     }
+    float k;
+    if (kl_parts > 0) {
+        float a = 0.f;
+        for (int i = threadIdx.x; i < kl_parts; i += 1024) a += kl[i];
+        k = block_sum(a, red) * kl_scale;
+    } else {
+        k = kl[0];
+    }
     if (threadIdx.x == 0) {
-        const float k = kl[0], pr = pair[0];
+        const float pr = pair[0];
         out4[0] = recon + beta * k + alpha * pr;
         out4[1] = recon;
         out4[2] = k;
@@ -431,10 +529,13 @@ __global__ __launch_bounds__(1024) void combine_losses_k(const float* __restrict
 }
 
 int rbvae_combine_losses(const float* sse_ws, int nparts, float inv_n, const float* recon, const float* kl,
-                         const float* pair, float beta, float alpha, float* out4, void* stream) {
-    RBVAE_CHECK_ARG(kl && pair && out4 && (sse_ws || recon), "combine_losses: bad arguments");
+                         int kl_parts, float kl_scale, const float* pair, float beta, float alpha, float* out4,
+                         unsigned long long* step_dev, double lr, double beta1, double beta2, float* hyper_ws,
+                         void* stream) {
+    RBVAE_CHECK_ARG(kl && pair && out4 && (sse_ws || recon) && kl_parts >= 0, "combine_losses: bad arguments");
+    RBVAE_CHECK_ARG(!step_dev || hyper_ws, "combine_losses: step_dev needs hyper_ws");
     hipLaunchKernelGGL(combine_losses_k, dim3(1), dim3(1024), 0, (hipStream_t)stream, sse_ws, nparts, inv_n, recon, kl,
-                       pair, beta, alpha, out4);
+                       kl_parts, kl_scale, pair, beta, alpha, out4, step_dev, lr, beta1, beta2, hyper_ws);
     RBVAE_CHECK_LAUNCH("combine_losses");
     return RBVAE_OK;
 }
@@ -485,9 +586,12 @@ int rbvae_adam_step(float* w, const float* g, float* m, float* v, long n, double
                     double eps, int step, float gscale, unsigned long long* step_dev, float* hyper_ws,
                     void* stream) {
     RBVAE_CHECK_ARG(w && g && m && v && n > 0, "adam_step: bad arguments");
-    RBVAE_CHECK_ARG(step_dev ? hyper_ws != nullptr : step >= 1, "adam_step: needs step >= 1 or step_dev + hyper_ws");
+    RBVAE_CHECK_ARG(step_dev ? hyper_ws != nullptr : (step >= 1 || hyper_ws),
+                    "adam_step: needs step >= 1, or step_dev + hyper_ws, or a prepared hyper_ws");
     double bc1 = 1.0, bc2 = 1.0;
-    if (step_dev) {
+    if (!step_dev && hyper_ws) {
+        // hyper_ws was prepared by rbvae_combine_losses (device step counter already advanced)
+    } else if (step_dev) {
         hipLaunchKernelGGL(adam_hyper_k, dim3(1), dim3(1), 0, (hipStream_t)stream, step_dev, lr, beta1, beta2,
                            hyper_ws);
     } else {
@@ -496,7 +600,7 @@ int rbvae_adam_step(float* w, const float* g, float* m, float* v, long n, double
     }
     hipLaunchKernelGGL(adam_k, dim3(grid_for(n, 256, 2048)), dim3(256), 0, (hipStream_t)stream, w, g, m, v, n,
                        (float)(lr / bc1), (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps,
-                       (float)sqrt(bc2), gscale, step_dev ? hyper_ws : (const float*)nullptr);
+                       (float)sqrt(bc2), gscale, hyper_ws ? hyper_ws : (const float*)nullptr);
     RBVAE_CHECK_LAUNCH("adam_step");
     return RBVAE_OK;
 }

@@ -46,19 +46,59 @@ __global__ __launch_bounds__(RED_THREADS) void binarize_kl_fwd_k(
     const int n = rows * L;
     float acc = 0.f;
     if (seed_dev) seed += seed_dev[0] * 0x9E3779B97F4A7C15ull;
-    for (int i = threadIdx.x; i < n; i += RED_THREADS) {
-        // U == null: 24-bit uniform in [0,1) from the counter hash (device-side noise)
+    // batches of UB elements per thread: every global load of a batch is in flight before the first use (the
+    // one-element-per-iteration loop paid a memory round trip per element: 8 of them at 256 x 32)
+    constexpr int UB = 8;
+    for (int base = threadIdx.x; base < n; base += UB * RED_THREADS) {
+        float hv[UB], uv[UB];
+#pragma unroll
+        for (int b = 0; b < UB; ++b) {
+            const int i = base + b * RED_THREADS, ic = i < n ? i : n - 1;
+            hv[b] = h[ic];
+            // U == null: 24-bit uniform in [0,1) from the counter hash (device-side noise)
+            uv[b] = U ? U[ic] : (float)(hash_u32(seed, (unsigned long long)ic) >> 8) * (1.0f / 16777216.0f);
+        }
+#pragma unroll
+        for (int b = 0; b < UB; ++b) {
+            const int i = base + b * RED_THREADS;
+            if (i >= n) break;
+            const float u = uv[b];
+            const float noise = ratio * (logf(u + neps) - logf(1.0f - u + neps));
+            const float y = sigmoidf_((hv[b] + noise) / tau);
+            const float zz = hard ? (y > 0.5f ? 1.0f : 0.0f) : y;
+            y_soft[i] = y;
+            z[i] = zz;
+            if (kl_mean) acc += kl_elem(zz, lp, l1p, keps, clamp);
+        }
+    }
+    if (kl_mean) {
+        const float tot = block_sum(acc, red);
+        if (threadIdx.x == 0) kl_mean[0] = tot / (float)rows;
+    }
+}
+
+// many-workgroup form: one element per thread, per-block partial KL sums (fixed order inside the block)
+__global__ __launch_bounds__(256) void binarize_kl_fwd_parts_k(
+    const float* __restrict__ h, const float* __restrict__ U, float* __restrict__ y_soft,
+    float* __restrict__ z, float* __restrict__ kl_parts, int n, float tau, float ratio,
+    float neps, int hard, float lp, float l1p, float keps, int clamp, unsigned long long seed,
+    const unsigned long long* __restrict__ seed_dev) {
+    __shared__ float red[4];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    float acc = 0.f;
+    if (i < n) {
+        if (seed_dev) seed += seed_dev[0] * 0x9E3779B97F4A7C15ull;
         const float u = U ? U[i] : (float)(hash_u32(seed, (unsigned long long)i) >> 8) * (1.0f / 16777216.0f);
         const float noise = ratio * (logf(u + neps) - logf(1.0f - u + neps));
         const float y = sigmoidf_((h[i] + noise) / tau);
         const float zz = hard ? (y > 0.5f ? 1.0f : 0.0f) : y;
         y_soft[i] = y;
         z[i] = zz;
-        if (kl_mean) acc += kl_elem(zz, lp, l1p, keps, clamp);
+        if (kl_parts) acc = kl_elem(zz, lp, l1p, keps, clamp);
     }
-    if (kl_mean) {
+    if (kl_parts) {
         const float tot = block_sum(acc, red);
-        if (threadIdx.x == 0) kl_mean[0] = tot / (float)rows;
+        if (threadIdx.x == 0) kl_parts[blockIdx.x] = tot;
     }
 }
 
@@ -375,6 +415,23 @@ int rbvae_binarize_kl_fwd(const float* h, const float* U, float* y_soft, float* 
                        kl_mean, rows, L, tau, noise_ratio, noise_eps, hard, logf(kl_p), logf(1.0f - kl_p),
                        kl_eps, kl_clamp, seed, seed_dev);
     RBVAE_CHECK_LAUNCH("binarize_kl_fwd");
+    return RBVAE_OK;
+}
+
+int rbvae_binarize_kl_nparts(int rows, int L) { return cdiv((long)rows * L, 256); }
+
+int rbvae_binarize_kl_fwd_parts(const float* h, const float* U, float* y_soft, float* z, float* kl_parts, int rows,
+                                int L, float tau, float noise_ratio, float noise_eps, int hard, float kl_p,
+                                float kl_eps, int kl_clamp, unsigned long long seed,
+                                const unsigned long long* seed_dev, void* stream) {
+    RBVAE_CHECK_ARG(h && y_soft && z, "binarize_kl_fwd_parts: null pointer");
+    RBVAE_CHECK_ARG(rows > 0 && L > 0 && tau > 0.f, "binarize_kl_fwd_parts: rows=%d L=%d tau=%g", rows, L, tau);
+    RBVAE_CHECK_ARG(!kl_parts || (kl_p > 0.f && kl_p < 1.f), "binarize_kl_fwd_parts: kl_p=%g outside (0,1)", kl_p);
+    const int n = rows * L;
+    hipLaunchKernelGGL(binarize_kl_fwd_parts_k, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, h, U, y_soft, z,
+                       kl_parts, n, tau, noise_ratio, noise_eps, hard, logf(kl_p), logf(1.0f - kl_p), kl_eps,
+                       kl_clamp, seed, seed_dev);
+    RBVAE_CHECK_LAUNCH("binarize_kl_fwd_parts");
     return RBVAE_OK;
 }
 

@@ -228,12 +228,13 @@ __device__ __forceinline__ void lds_barrier() {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-template <int LMAX, bool VEC>
+template <int LMAX, bool VEC, bool EXACT>       // EXACT: L == LMAX (every bound check folds away)
 __global__ __launch_bounds__(1024) void lstm_fwd_wave_k(const float* __restrict__ wblk, const float* __restrict__ wT,
                                                         float* __restrict__ hs_all,
                                                         float* __restrict__ hprev, float* __restrict__ acts,
-                                                        float* __restrict__ cs, int S, int T, int L, int layers,
+                                                        float* __restrict__ cs, int S, int T, int L_, int layers,
                                                         int G) {
+    const int L = EXACT ? LMAX : L_;
     extern __shared__ __attribute__((aligned(16))) float sm[];
     float* hbuf = sm;                               // [layers+1][T][L]
     float* gates = hbuf + (layers + 1) * T * L;     // [layers][4L]  ACTIVATED gates i, f, g, o
@@ -314,11 +315,12 @@ __global__ __launch_bounds__(1024) void lstm_fwd_wave_k(const float* __restrict_
     }
 }
 
-template <int LMAX>
+template <int LMAX, bool EXACT>
 __global__ __launch_bounds__(1024) void lstm_bwd_wave_k(const float* __restrict__ wblk, const float* __restrict__ acts,
                                                         const float* __restrict__ cs, const float* __restrict__ g_top,
                                                         float* __restrict__ dG, float* __restrict__ dx, int S, int T,
-                                                        int L, int layers, int G) {
+                                                        int L_, int layers, int G) {
+    const int L = EXACT ? LMAX : L_;
     extern __shared__ float sm[];
     float* gtop = sm;                              // [T][L]
     float* sacts = gtop + T * L;                   // [layers][T][4L]
@@ -329,11 +331,30 @@ __global__ __launch_bounds__(1024) void lstm_bwd_wave_k(const float* __restrict_
     const int s = blockIdx.x;
     const bool row = j < 4 * L;
     const int kcol = j % L, prt = j / L;
-    for (int i = threadIdx.x; i < T * L; i += blockDim.x) gtop[i] = g_top[((long)s * T) * L + i];
-    for (int ll = 0; ll < layers; ++ll) {
-        const long o = ((long)ll * S + s) * T;
-        for (int i = threadIdx.x; i < T * 4 * L; i += blockDim.x) sacts[ll * T * 4 * L + i] = acts[o * 4 * L + i];
-        for (int i = threadIdx.x; i < T * L; i += blockDim.x) scs[ll * T * L + i] = cs[o * L + i];
+    {
+        // Stage g_top, the saved gates and cell states of this sequence: gtop | sacts | scs are consecutive in LDS,
+        // so one flat index covers all three.  Every load of a batch is issued before the first LDS store (a plain
+        // "dst[i] = src[i]" loop per tensor waited for each load in turn: 13 memory round trips in this prologue).
+        constexpr int U = 12;
+        const int n0 = T * L, na = T * 4 * L, n1 = n0 + layers * na, ntot = n1 + layers * n0;
+        for (int base = threadIdx.x; base < ntot; base += U * blockDim.x) {
+            float v[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                int i = base + u * blockDim.x;
+                i = i < ntot ? i : ntot - 1;
+                const float* src;
+                if (i < n0) src = g_top + ((long)s * T) * L + i;
+                else if (i < n1) { const int ll = (i - n0) / na, r = (i - n0) - ll * na; src = acts + (((long)ll * S + s) * T) * 4 * L + r; }
+                else { const int ll = (i - n1) / n0, r = (i - n1) - ll * n0; src = cs + (((long)ll * S + s) * T) * L + r; }
+                v[u] = *src;
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int i = base + u * blockDim.x;
+                if (i < ntot) sm[i] = v[u];
+            }
+        }
     }
     const float* wl = wblk + l * lstm_layer_floats(L);
     float wic[LMAX], whc[LMAX];
@@ -501,12 +522,15 @@ int rbvae_lstm_fwd(const float* wblk, const float* wT, float* hs_all, float* hpr
     // wavefront kernel: one thread group per layer (weights in registers, L <= 32)
     const size_t wlds = (size_t)((layers + 1) * T * L + layers * 4 * L) * sizeof(float);
     if (L <= 32 && layers * threads <= 1024 && wlds <= 64 * 1024) {
-        if (L % 4 == 0)
-            hipLaunchKernelGGL((lstm_fwd_wave_k<32, true>), dim3(S), dim3(layers * threads), wlds, st, wblk, wT, hs_all,
-                               hprev, acts, cs, S, T, L, layers, threads);
+        if (L == 32)
+            hipLaunchKernelGGL((lstm_fwd_wave_k<32, true, true>), dim3(S), dim3(layers * threads), wlds, st, wblk, wT,
+                               hs_all, hprev, acts, cs, S, T, L, layers, threads);
+        else if (L % 4 == 0)
+            hipLaunchKernelGGL((lstm_fwd_wave_k<32, true, false>), dim3(S), dim3(layers * threads), wlds, st, wblk, wT,
+                               hs_all, hprev, acts, cs, S, T, L, layers, threads);
         else
-            hipLaunchKernelGGL((lstm_fwd_wave_k<32, false>), dim3(S), dim3(layers * threads), wlds, st, wblk, wT, hs_all,
-                               hprev, acts, cs, S, T, L, layers, threads);
+            hipLaunchKernelGGL((lstm_fwd_wave_k<32, false, false>), dim3(S), dim3(layers * threads), wlds, st, wblk, wT,
+                               hs_all, hprev, acts, cs, S, T, L, layers, threads);
         RBVAE_CHECK_LAUNCH("lstm_fwd_wave");
         return RBVAE_OK;
     }
@@ -531,8 +555,12 @@ int rbvae_lstm_bwd(const float* wblk, const float* acts, const float* cs, const 
     hipStream_t st = (hipStream_t)stream;
     const size_t wlds = (size_t)(T * L + layers * T * 5 * L + layers * 12 * L) * sizeof(float);
     if (L <= 32 && layers * threads <= 1024 && wlds <= 64 * 1024) {
-        hipLaunchKernelGGL(lstm_bwd_wave_k<32>, dim3(S), dim3(layers * threads), wlds, st, wblk, acts, cs, g_top, dG,
-                           dx, S, T, L, layers, threads);
+        if (L == 32)
+            hipLaunchKernelGGL((lstm_bwd_wave_k<32, true>), dim3(S), dim3(layers * threads), wlds, st, wblk, acts, cs,
+                               g_top, dG, dx, S, T, L, layers, threads);
+        else
+            hipLaunchKernelGGL((lstm_bwd_wave_k<32, false>), dim3(S), dim3(layers * threads), wlds, st, wblk, acts, cs,
+                               g_top, dG, dx, S, T, L, layers, threads);
         RBVAE_CHECK_LAUNCH("lstm_bwd_wave");
         return RBVAE_OK;
     }

@@ -230,10 +230,10 @@ class Engine:
         self._bwd_tab: Dict = {}       # uploaded reduce-job tables, keyed by their signature
         self._jobs: Optional[JobList] = None
         self._side: Optional[torch.cuda.Stream] = None
-        # run wgrad / bias-grad kernels on a side stream beside the dgrad chain (measured slower on MI355X at
-        # the bench shapes: every kernel already spans all CUs, so the fork only adds dependency edges)
+        # weight-gradient work of the decoder runs on a side stream beside the LSTM backward chain (RBVAE_OVERLAP=0:
+        # everything in issue order on one stream)
         import os
-        self.overlap = os.environ.get("RBVAE_OVERLAP", "0") == "1"
+        self.overlap = os.environ.get("RBVAE_OVERLAP", "1") == "1"
         self._alloc_packed()
 
     # ---- packed weights -------------------------------------------------------
@@ -264,8 +264,30 @@ class Engine:
         if tab is None:
             jl = self._pack_jobs(flat)
             tab = (jl.upload(self.device), len(jl.rows), jl)
-            self._pack_tab = {key: tab}
+            self._pack_tab[key] = tab
         L.call("rbvae_run_jobs", tab[0], tab[1], 256)
+
+    def pack_begin(self, flat: torch.Tensor):
+        """pack() split for the fused step: the first conv's weights on the current stream, every other packed
+        copy on the side stream beside the step's first kernels; pack_end() joins before they are needed."""
+        key = ("split", flat.data_ptr())
+        tab = self._pack_tab.get(key)
+        if tab is None:
+            jl = self._pack_jobs(flat)
+            first, rest = JobList(), JobList()
+            first.rows, rest.rows = jl.rows[:1], jl.rows[1:]
+            first.keep = rest.keep = jl.keep
+            tab = (first.upload(self.device), 1, rest.upload(self.device), len(rest.rows), jl)
+            self._pack_tab[key] = tab
+        if self._fork():
+            with self._on_side():
+                L.call("rbvae_run_jobs", tab[2], tab[3], 256)
+        else:
+            L.call("rbvae_run_jobs", tab[2], tab[3], 256)
+        L.call("rbvae_run_jobs", tab[0], tab[1], 256)
+
+    def pack_end(self):
+        self._join()
 
     def _pack_jobs(self, flat: torch.Tensor) -> JobList:
         lay, dt = self.layout, self.dt
@@ -359,39 +381,37 @@ class Engine:
                         max(1, (4 << 20) // (Co * taps * Ci))))
         ks = max(ks, -(-P // 4096))            # the kernel keeps a K-slice's gather indices in LDS (<= 4096)
         slabs = self._buf(("slabs", tag), ks * Co * taps * Ci)
-        side = self._side_begin()
         L.call("rbvae_wgrad_gemm", self.dt, Dy, In, slabs, idx, self.zero, P, Co, Ci, ldy, ldi, taps, ks)
-        self._side_end(side)
         self._jobs.add(JOB_PERMUTE, slabs, out, dims, strides, nslab=ks, slab=Co * taps * Ci)
 
     def _colsum(self, dt, X, P, C, ld, out, tag=None):
         """Column sums of a tensor no GEMM epilogue produced: partial kernel now, final reduction as a job."""
         nf = L.query("rbvae_colsum_ws_floats", P, C)
         ws = self._buf(("cs", tag), nf)
-        side = self._side_begin()
         L.call("rbvae_colsum_partial", dt, X, P, C, ld, ws)
-        self._side_end(side)
         self._jobs.add(JOB_ROWS, ws, out, (1, 1, C), (0, 0, 1), nslab=nf // C, slab=C)
 
-    # ---- side stream: weight-gradient work runs beside the data-gradient chain -------------------
-    def _side_begin(self):
-        """Fork: work issued until _side_end() runs on the side stream, after everything already queued
-        on the main stream.  (Inside HIP-graph capture this becomes a fork edge of the graph.)"""
+    # ---- side stream ------------------------------------------------------------------
+    # The LSTM chains occupy 2B workgroups for ~25 us per stack; weight-gradient GEMMs that do not feed them are
+    # issued on a side stream over exactly those windows (graph capture turns the fork/join into graph edges).
+    def _fork(self):
+        """Side stream picks up after everything queued so far on the current stream."""
         if not self.overlap:
-            return None
+            return False
         if self._side is None:
             self._side = torch.cuda.Stream(device=self.device)
-        main = torch.cuda.current_stream()
-        self._side.wait_stream(main)
-        ctx = torch.cuda.stream(self._side)
-        ctx.__enter__()
-        return ctx
+        self._side.wait_stream(torch.cuda.current_stream())
+        return True
 
-    def _side_end(self, ctx):
-        if ctx is not None:
-            ctx.__exit__(None, None, None)
+    def _on_side(self):
+        import contextlib
+        return torch.cuda.stream(self._side) if self.overlap else contextlib.nullcontext()
 
-    def _side_join(self):
+    def _side_wait_main(self):
+        if self.overlap:
+            self._side.wait_stream(torch.cuda.current_stream())
+
+    def _join(self):
         if self.overlap and self._side is not None:
             torch.cuda.current_stream().wait_stream(self._side)
 
@@ -411,10 +431,16 @@ class Engine:
     def forward(self, flat: torch.Tensor, x: torch.Tensor, U: torch.Tensor, tau: float, hard: bool,
                 noise_ratio: float, train: bool, masks: Optional[Sequence[torch.Tensor]] = None,
                 seed: int = 0, need_grad: bool = True, encode_only: bool = False,
-                target: Optional[torch.Tensor] = None, recon_gscale: float = 0.0, kl_p: Optional[float] = None):
+                target: Optional[torch.Tensor] = None, recon_gscale: float = 0.0, kl_p: Optional[float] = None,
+                after_hs=None, defer_losses: bool = False, repack: bool = False):
         """x: [S,T,C,H,W] f32 NCHW frames; U: [S*T, L] uniform noise.
         masks: explicit dropout keep-masks (u8, NHWC rows) for the 4 dropout sites, else a counter hash.
         target/recon_gscale: fuse recon_loss and its gradient into the last kernel (trainer path).
+        defer_losses: leave recon_loss and the KL mean as per-block partial sums ("sse": (ws, nparts, 1/n),
+        "kl": (parts, nparts, 1/rows)) for rbvae_combine_losses to finish.
+        repack: refresh the packed weight copies from `flat` first (all but the first conv's on the side stream).
+        after_hs: optional callable(h_seq) issued on the side stream as soon as the encoder LSTM is done (the
+        trainer's pairwise term runs there, beside the decoder); backward() joins it.
         Returns dict(xr, hs, z, e, kl, mse, saved)."""
         v = self.v
         S, T, C, H, W = x.shape
@@ -441,6 +467,8 @@ class Engine:
         sv.N, sv.S, sv.T, sv.hw, sv.train, sv.tau, sv.hard = N, S, T, (H, W), train, tau, hard
         sv.gate_scale = dscale
         # encoder CNN
+        if repack:
+            self.pack_begin(flat)
         sv.col1 = self._E(N * h1 * w1, self.K1)
         L.call("rbvae_im2col", self.dt, x, C * H * W, H * W, W, 1, N, C, H, W, h1, w1, k, k, 2, 1, self.K1, sv.col1)
         sv.a1 = self._E(N * h1 * w1, c1)
@@ -448,6 +476,8 @@ class Engine:
         self._gemm(sv.col1, self.W1p, sv.a1, P(f"encoder_cnn.conv.{i0}.bias"), None, mk, N * h1 * w1, 1, 1, 1, 1, 1,
                    1, 1, 1, self.K1, c1, self.K1, c1, 1, "one", relu=1, drop_mode=m, drop_p=drop, scale=dscale,
                    seed=seed * 8 + 1)
+        if repack:
+            self.pack_end()
         sv.a2 = self._E(N * h2 * w2, c2)
         m, mk = dm(1)
         self._gemm(sv.a1, self.W2f, sv.a2, P(f"encoder_cnn.conv.{i1}.bias"), None, mk, N, h1, w1, h2, w2, 2, h2, w2,
@@ -478,9 +508,20 @@ class Engine:
         if not v.simple_order:
             L.call("rbvae_lstm_fwd", wenc, self.wT_enc, sv.hs_enc, sv.hp_enc, sv.acts_enc, sv.cs_enc, S, T, Ld, nl)
             hs = sv.hs_enc[nl]
+            if after_hs is not None:
+                self._fork()
+                with self._on_side():
+                    after_hs(hs)
             sv.z = sv.hs_dec[0].view(N, Ld)
-            L.call("rbvae_binarize_kl_fwd", hs, U, sv.y, sv.z, kl, N, Ld, float(tau), float(r), v.eps, int(hard),
-                   float(kl_p if kl_p is not None else 0.5), 1e-8, 1, int(seed) * 8 + 5, self.seed_dev)
+            if defer_losses and kl_p is not None:
+                nkl = L.query("rbvae_binarize_kl_nparts", N, Ld)
+                parts = self._E(nkl, dtype=torch.float32)
+                L.call("rbvae_binarize_kl_fwd_parts", hs, U, sv.y, sv.z, parts, N, Ld, float(tau), float(r), v.eps,
+                       int(hard), float(kl_p), 1e-8, 1, int(seed) * 8 + 5, self.seed_dev)
+                kl = (parts, nkl, 1.0 / N)
+            else:
+                L.call("rbvae_binarize_kl_fwd", hs, U, sv.y, sv.z, kl, N, Ld, float(tau), float(r), v.eps, int(hard),
+                       float(kl_p if kl_p is not None else 0.5), 1e-8, 1, int(seed) * 8 + 5, self.seed_dev)
             if encode_only:
                 return {"z": sv.z.view(S, T, Ld), "hs": hs, "saved": sv}
             L.call("rbvae_lstm_fwd", wdec, self.wT_dec, sv.hs_dec, sv.hp_dec, sv.acts_dec, sv.cs_dec, S, T, Ld, nl)
@@ -512,10 +553,14 @@ class Engine:
                    self.NY, 1, "one")
         sv.xr = self._E(S, T, self.out_ch, H, W, dtype=torch.float32)
         mse = None
+        sse = None
         sv.dpre3 = None
         if target is not None:
-            mse = self._E(1, dtype=torch.float32)
             ws = self._E(L.query("rbvae_col2im_ws_floats"), dtype=torch.float32)
+            if defer_losses:    # per-block partial sums stay in ws; rbvae_combine_losses finishes the mean
+                sse = (ws, L.query("rbvae_col2im_nparts", sv.xr.numel()), 1.0 / sv.xr.numel())
+            else:
+                mse = self._E(1, dtype=torch.float32)
             if need_grad:
                 sv.dpre3 = self._E(N, H, W, self.out_ch, dtype=torch.float32)
             L.call("rbvae_col2im_sigmoid", self.dt, Y, self.NY, P(f"decoder_cnn.deconv.{i2}.bias"), N, h1, w1, H, W,
@@ -523,17 +568,19 @@ class Engine:
         else:
             L.call("rbvae_col2im_sigmoid", self.dt, Y, self.NY, P(f"decoder_cnn.deconv.{i2}.bias"), N, h1, w1, H, W,
                    self.out_ch, k, k, 1, sv.xr, None, None, None, None, 0.0, None)
-        return {"xr": sv.xr, "hs": hs, "z": sv.z.view(S, T, Ld), "e": sv.e, "kl": kl, "mse": mse, "saved": sv}
+        return {"xr": sv.xr, "hs": hs, "z": sv.z.view(S, T, Ld), "e": sv.e, "kl": kl, "mse": mse, "sse": sse, "saved": sv}
 
     # ---- backward --------------------------------------------------------------
     def backward(self, flat: torch.Tensor, gflat: torch.Tensor, sv: Saved, g_xr: Optional[torch.Tensor],
                  g_hs: Optional[torch.Tensor], g_z: Optional[torch.Tensor], g_e: Optional[torch.Tensor] = None,
-                 kl_weight: float = 0.0, kl_p: float = 0.5):
+                 kl_weight: float = 0.0, kl_p: float = 0.5, g_hs_inplace: bool = False):
         """Writes every parameter gradient into gflat (same layout as flat).
         g_xr: [S,T,C,H,W] upstream gradient of x_recon (None: use the fused dpre3 of forward()).
         g_hs / g_z: [S,T,L] upstream gradients of h_seq / z_seq (None = 0).
         g_e: upstream gradient of the conv logits (simple variant's second output).
-        kl_weight: d(loss)/d(kl_mean) when the KL term was fused into forward()."""
+        kl_weight: d(loss)/d(kl_mean) when the KL term was fused into forward().
+        g_hs_inplace: the caller gives g_hs away (the binarise backward accumulates into it)."""
+        self._join()                       # side-stream work of forward() (after_hs)
         v = self.v
         N, S, T = sv.N, sv.S, sv.T
         H, W = sv.hw
@@ -555,7 +602,7 @@ class Engine:
             n = math.prod(shape)
             return self._buf((N, tag), n, dtype or self.tdt).view(*shape)
 
-        # --- last deconv
+        # --- decoder CNN, data-gradient chain first (main stream) ...
         if g_xr is not None:
             dpre3 = tmp("dpre3", N, H, W, oc, dtype=f32)
             L.call("rbvae_sigmoid_bwd_nhwc", g_xr.contiguous(), sv.xr, dpre3, N, oc, H, W)
@@ -563,35 +610,44 @@ class Engine:
             dpre3 = sv.dpre3
             if dpre3 is None:
                 raise RuntimeError("backward without g_xr needs forward(target=..., need_grad=True)")
-        self._colsum(F32, dpre3, N * H * W, oc, oc, G(f"decoder_cnn.deconv.{i2}.bias"), tag=(N, "b3"))
         col3 = tmp("col3", P1, self.K3)
         L.call("rbvae_im2col", self.dt, dpre3, H * W * oc, 1, W * oc, oc, N, oc, H, W, h1, w1, k, k, 2, 1, self.K3, col3)
-        self._wgrad(sv.d2, col3, None, P1, c1, self.K3, c1, self.K3, 1, G(f"decoder_cnn.deconv.{i2}.weight"),
-                    (c1, oc, kk), (self.K3, 1, oc), tag=(N, "V3"))
         dd2 = tmp("dd2", P1, c1)
         self._gemm(col3, self.V3f, dd2, None, sv.d2, None, P1, 1, 1, 1, 1, 1, 1, 1, 1, self.K3, c1, self.K3, c1, 1,
                    "one", scale=gs, bias_grad=G(f"decoder_cnn.deconv.{i1}.bias"), tag=(N, "dd2"))
-        # --- deconv1 (c2 -> c1): input grad = conv forward of dd2 with the same weights
-        self._wgrad(sv.d1, dd2, self._conv_idx(N, h1, w1, h2, w2), P2, c2, c1, c2, c1, kk,
-                    G(f"decoder_cnn.deconv.{i1}.weight"), (c2, c1, kk), (kk * c1, 1, c1), tag=(N, "V2"))
+        # deconv1 (c2 -> c1): input grad = conv forward of dd2 with the same weights
         dd1 = tmp("dd1", P2, c2)
         self._gemm(dd2, self.V2f, dd1, None, sv.d1, None, N, h1, w1, h2, w2, 2, h2, w2, 1, c1, c2, c1, c2, kk, "conv",
                    scale=gs, bias_grad=G(f"decoder_cnn.deconv.{i0}.bias"), tag=(N, "dd1"))
-        # --- deconv0 (c3 -> c2)
-        self._wgrad(sv.f, dd1, self._conv_idx(N, h2, w2, h3, w3), P3, c3, c2, c3, c2, kk,
-                    G(f"decoder_cnn.deconv.{i0}.weight"), (c3, c2, kk), (kk * c2, 1, c2), tag=(N, "V1"))
+        # deconv0 (c3 -> c2)
         df = tmp("df", P3, c3)
         self._gemm(dd1, self.V1f, df, None, None, None, N, h2, w2, h3, w3, 2, h3, w3, 1, c2, c3, c2, c3, kk, "conv")
-        # --- decoder fc: bias = per (position, channel) sum over frames, permuted to the torch (c, hw) order
-        nf = L.query("rbvae_colsum_ws_floats", N, self.F3)
-        wsf = self._buf((N, "bdfc"), nf)
-        side = self._side_begin()
-        L.call("rbvae_colsum_partial", self.dt, df, N, self.F3, self.F3, wsf)
-        self._side_end(side)
-        self._jobs.add(JOB_PERMUTE, wsf, G("decoder_cnn.fc.bias"), (c3, g3, 1), (1, c3, 0), nslab=nf // self.F3,
-                       slab=self.F3)
-        self._wgrad(df, sv.ds_pad, None, N, self.F3, self.Lp, self.F3, self.Lp, 1, G("decoder_cnn.fc.weight"),
-                    (c3, g3, Ld), (self.Lp, c3 * self.Lp, 1), tag=(N, "Wdfc"))
+
+        # ... then its weight / bias gradients, beside the LSTM chain when overlap is on
+        def decoder_wgrads():
+            self._colsum(F32, dpre3, N * H * W, oc, oc, G(f"decoder_cnn.deconv.{i2}.bias"), tag=(N, "b3"))
+            self._wgrad(sv.d2, col3, None, P1, c1, self.K3, c1, self.K3, 1, G(f"decoder_cnn.deconv.{i2}.weight"),
+                        (c1, oc, kk), (self.K3, 1, oc), tag=(N, "V3"))
+            self._wgrad(sv.d1, dd2, self._conv_idx(N, h1, w1, h2, w2), P2, c2, c1, c2, c1, kk,
+                        G(f"decoder_cnn.deconv.{i1}.weight"), (c2, c1, kk), (kk * c1, 1, c1), tag=(N, "V2"))
+            self._wgrad(sv.f, dd1, self._conv_idx(N, h2, w2, h3, w3), P3, c3, c2, c3, c2, kk,
+                        G(f"decoder_cnn.deconv.{i0}.weight"), (c3, c2, kk), (kk * c2, 1, c2), tag=(N, "V1"))
+            # decoder fc: bias = per (position, channel) sum over frames, permuted to the torch (c, hw) order
+            nf = L.query("rbvae_colsum_ws_floats", N, self.F3)
+            wsf = self._buf((N, "bdfc"), nf)
+            L.call("rbvae_colsum_partial", self.dt, df, N, self.F3, self.F3, wsf)
+            self._jobs.add(JOB_PERMUTE, wsf, G("decoder_cnn.fc.bias"), (c3, g3, 1), (1, c3, 0), nslab=nf // self.F3,
+                           slab=self.F3)
+            self._wgrad(df, sv.ds_pad, None, N, self.F3, self.Lp, self.F3, self.Lp, 1, G("decoder_cnn.fc.weight"),
+                        (c3, g3, Ld), (self.Lp, c3 * self.Lp, 1), tag=(N, "Wdfc"))
+
+        self._fork()
+        with self._on_side():
+            decoder_wgrads()
+            if self.overlap:
+                # the decoder's slab / partial-sum reductions now, beside the LSTM chain, not at the end of the pass
+                self._run_jobs()
+                self._jobs = JobList()
         dds = tmp("dds", N, Ld, dtype=f32)
         L.call("rbvae_skinny_linear", self.dt, df, self.WdfcT, None, dds, N, Ld, self.F3, self.F3, self.F3, Ld)
         # --- decoder LSTM
@@ -606,29 +662,31 @@ class Engine:
             gz = d_in_dec
             if g_z is not None:
                 gz = gz + g_z.reshape(N, Ld)
-            dh = tmp("dh", N, Ld, dtype=f32)
-            L.call("rbvae_binarize_kl_bwd", gz, sv.y, sv.z, dh, 0, N, Ld, float(sv.tau), float(kl_weight), None,
-                   float(kl_p), 1e-8, 1)
-            if g_hs is not None:
-                dh = dh + g_hs.reshape(N, Ld)
+            if g_hs is not None and g_hs_inplace and g_hs.is_contiguous():
+                dh = g_hs.view(N, Ld)
+                L.call("rbvae_binarize_kl_bwd", gz, sv.y, sv.z, dh, 1, N, Ld, float(sv.tau), float(kl_weight), None,
+                       float(kl_p), 1e-8, 1)
+            else:
+                dh = tmp("dh", N, Ld, dtype=f32)
+                L.call("rbvae_binarize_kl_bwd", gz, sv.y, sv.z, dh, 0, N, Ld, float(sv.tau), float(kl_weight), None,
+                       float(kl_p), 1e-8, 1)
+                if g_hs is not None:
+                    dh = dh + g_hs.reshape(N, Ld)
             L.call("rbvae_lstm_bwd", wenc, sv.acts_enc, sv.cs_enc, dh, dGe, de, S, T, Ld, nl)
-            side = self._side_begin()
-            L.call("rbvae_lstm_wgrad_pair", dG, sv.hs_dec, sv.hp_dec, G("decoder_rnn.lstm.weight_ih_l0"),
-                   dGe, sv.hs_enc, sv.hp_enc, G("encoder_rnn.lstm.weight_ih_l0"), S, T, Ld, nl, 0)
-            self._side_end(side)
         else:
             # decoder stack input = encoder stack output
             dz = tmp("dz", N, Ld, dtype=f32)
             L.call("rbvae_lstm_bwd", wenc, sv.acts_enc, sv.cs_enc, d_in_dec, dGe, dz, S, T, Ld, nl)
-            side = self._side_begin()
-            L.call("rbvae_lstm_wgrad_pair", dG, sv.hs_dec, sv.hp_dec, G("decoder_rnn.lstm.weight_ih_l0"),
-                   dGe, sv.hs_enc, sv.hp_enc, G("encoder_rnn.lstm.weight_ih_l0"), S, T, Ld, nl, 0)
-            self._side_end(side)
             L.call("rbvae_binarize_kl_bwd", dz, sv.y, sv.z, de, 0, N, Ld, float(sv.tau), 0.0, None, 0.5, 1e-10, 0)
             if g_e is not None:
                 de = de + g_e.reshape(N, Ld)
+        # LSTM weight gradients (few workgroups, latency bound) ride the side stream beside the encoder CNN backward
+        self._side_wait_main()
+        with self._on_side():
+            L.call("rbvae_lstm_wgrad_pair", dG, sv.hs_dec, sv.hp_dec, G("decoder_rnn.lstm.weight_ih_l0"),
+                   dGe, sv.hs_enc, sv.hp_enc, G("encoder_rnn.lstm.weight_ih_l0"), S, T, Ld, nl, 0)
+            self._colsum(F32, de, N, Ld, Ld, G("encoder_cnn.fc.bias"), tag=(N, "bfc"))
         # --- encoder fc
-        self._colsum(F32, de, N, Ld, Ld, G("encoder_cnn.fc.bias"), tag=(N, "bfc"))
         de_pad = tmp("de_pad", N, self.Lp)
         L.call("rbvae_cast_pad", self.dt, de, de_pad, N, Ld, self.Lp)
         self._wgrad(de_pad, sv.a3, None, N, self.Lp, self.F3, self.Lp, self.F3, 1, G("encoder_cnn.fc.weight"),
@@ -657,5 +715,5 @@ class Engine:
         self._wgrad(da1, sv.col1, None, P1, c1, self.K1, c1, self.K1, 1, G(f"encoder_cnn.conv.{i0}.weight"),
                     (c1, self.in_ch, kk), (self.K1, 1, self.in_ch), tag=(N, "W1"))
         # every slab / partial-sum reduction of this pass in one launch, once the side stream has caught up
-        self._side_join()
+        self._join()
         self._run_jobs()

@@ -58,30 +58,39 @@ class FusedTrainer:
     def _fwd_bwd(self, x, U, tau, B, T):
         eng, model = self.eng, self.model
         numel = x.numel()
+        Ld = model.latent_dim
+        g_hs = torch.empty(2 * B, T, Ld, device=self.dev)
+        pair = self._pair
+
+        def pair_term(hs):                   # [2B, T, L]; runs beside the decoder (engine side stream)
+            h0, h1 = hs[:B], hs[B:]
+            if self.model.variant == "triplet":
+                L.call("rbvae_triplet_term_fwd", h0, h1, B, T, Ld, float(self.margin), pair)
+                L.call("rbvae_triplet_term_bwd", h0, h1, B, T, Ld, float(self.margin), float(self.alpha), None,
+                       g_hs[:B], g_hs[B:])
+            else:
+                L.call("rbvae_contrast_term_fwd", h0, h1, B, T, Ld, pair)
+                L.call("rbvae_contrast_term_bwd", h0, h1, B, T, Ld, float(self.alpha), None, g_hs[:B], g_hs[B:])
+
         # dropout follows the module's mode like the reference (model.train() in train_one_epoch, :501)
         out = eng.forward(model._flat, x, U, tau, False, self.r, bool(model.training), None, seed=0, need_grad=True,
-                          target=x, recon_gscale=2.0 / numel, kl_p=self.p)
-        hs = out["hs"]                       # [2B, T, L]
-        Ld = hs.shape[-1]
-        h0, h1 = hs[:B], hs[B:]
-        pair = self._pair
-        g_hs = torch.empty_like(hs)
-        if self.model.variant == "triplet":
-            L.call("rbvae_triplet_term_fwd", h0, h1, B, T, Ld, float(self.margin), pair)
-            L.call("rbvae_triplet_term_bwd", h0, h1, B, T, Ld, float(self.margin), float(self.alpha), None,
-                   g_hs[:B], g_hs[B:])
-        else:
-            L.call("rbvae_contrast_term_fwd", h0, h1, B, T, Ld, pair)
-            L.call("rbvae_contrast_term_bwd", h0, h1, B, T, Ld, float(self.alpha), None, g_hs[:B], g_hs[B:])
-        eng.backward(model._flat, self.gflat, out["saved"], None, g_hs, None, kl_weight=self.beta_kl, kl_p=self.p)
-        L.call("rbvae_combine_losses", None, 0, 0.0, out["mse"], out["kl"], self._pair, float(self.beta_kl),
-               float(self.alpha), self.losses)
+                          target=x, recon_gscale=2.0 / numel, kl_p=self.p, after_hs=pair_term,
+                          defer_losses=True, repack=True)
+        eng.backward(model._flat, self.gflat, out["saved"], None, g_hs, None, kl_weight=self.beta_kl, kl_p=self.p,
+                     g_hs_inplace=True)
+        sse_ws, nparts, inv_n = out["sse"]
+        kl_parts, nkl, kl_scale = out["kl"]
+        # ... which also advances the device step counter and prepares Adam's bias corrections for _update()
+        b1, b2 = self.betas
+        L.call("rbvae_combine_losses", sse_ws, nparts, inv_n, None, kl_parts, nkl, kl_scale, self._pair,
+               float(self.beta_kl), float(self.alpha), self.losses, self.step_dev, float(self.lr), float(b1),
+               float(b2), self.hyper)
 
     def _update(self):
         b1, b2 = self.betas
         L.call("rbvae_adam_step", self.model._flat, self.gflat, self.m, self.vv, self.gflat.numel(), float(self.lr),
-               float(b1), float(b2), float(self.eps), 1, 1.0 / self.world, self.step_dev, self.hyper)
-        self.eng.pack(self.model._flat)
+               float(b1), float(b2), float(self.eps), 0, 1.0 / self.world, None, self.hyper)
+        # the packed bf16 copies are refreshed at the start of the next step (beside its first kernels)
 
     # ---- public --------------------------------------------------------------------
     def step(self, item: torch.Tensor, temperature: float, U: Optional[torch.Tensor] = None):
@@ -98,7 +107,6 @@ class FusedTrainer:
         if self.eng is None:
             self.eng = model._engine_for(item)
             self.eng.seed_dev = self.step_dev
-            self.eng.pack(model._flat)
         Ld = model.latent_dim
         if U is None and not self.device_noise:
             U = torch.rand((2, B * T, Ld)).to(item.device)
@@ -125,6 +133,7 @@ class FusedTrainer:
             self._allreduce()
             g[1].replay()
         self.steps += 1
+        self.model._packed_version = None     # anything else that runs the model before the next step repacks first
         return self.losses
 
     def _allreduce(self):

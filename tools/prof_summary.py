@@ -42,3 +42,12 @@ if len(sys.argv) > 2:
         if "gemm" in n:
             t = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
             print(f"    {n.replace('void rbvae::', '')[:44]:44s} grid=({int(r['Grid_Size_X']) // int(r['Workgroup_Size_X'])},{r['Grid_Size_Y']},{r['Grid_Size_Z']}) {t:7.1f} us")
+if len(sys.argv) > 3:
+    # timeline of one step: start offset, duration, queue/stream of every kernel (shows side-stream overlap)
+    a, b = marks[-3], marks[-2]
+    t0 = int(rows[a]["Start_Timestamp"])
+    for r in rows[a:b]:
+        n = r["Kernel_Name"].replace("void rbvae::", "").replace("rbvae::", "").split("(")[0][:44]
+        s, e = int(r["Start_Timestamp"]) - t0, int(r["End_Timestamp"]) - t0
+        wg = int(r["Grid_Size_X"]) // int(r["Workgroup_Size_X"]) * int(r["Grid_Size_Y"]) * int(r["Grid_Size_Z"])
+        print(f"    t={s / 1e3:8.1f} +{(e - s) / 1e3:6.1f} us  q={r.get('Queue_Id', '?'):>3s} wgs={wg:5d}  {n}")
