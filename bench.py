@@ -162,6 +162,10 @@ def main():
     tr = trainer_mod.FusedTrainer(model, lr=1e-3, alpha=ALPHA, beta_kl=BETA, bernoulli_p=BERN_P, noise_ratio=NOISE_R,
                                   device_noise=True, use_graph=not args.no_graph)
     frames_per_step = B_ITEMS * 2 * T_STATES
+    # the batch lives in the trainer's static input buffer (a device-resident data loader gathers into it in place)
+    buf = tr.input_buffer(B_ITEMS, T_STATES, C_IN, *HW)
+    buf.copy_(item)
+    item = buf
 
     for _ in range(args.warmup):
         tr.step(item, TAU)

@@ -191,6 +191,18 @@ int rbvae_col2im_sigmoid(int dtype, const void* Y, int ldy, const float* bias, i
                          int OW, int Cout, int KH, int KW, int pad, float* xr, const float* target,
                          float* sse_mean, float* ws, float* dpre, float gscale, const float* gscale_dev,
                          void* stream);
+/* The same with the frames addressed through a map instead of one stride: frame n starts at element
+ * (n / fd1) * fs0 + ((n % fd1) / fd2) * fs1 + (n % fd2) * fs2 of src / target.  The fused trainer reads an item
+ * batch [B][2][T][C][H][W] (percep_RBVAE_train.py:509-526: x_t = item[:, 0], x_t1 = item[:, 1]) as the 2B
+ * sequences "all of view 0, then all of view 1" with fd1 = B*T, fd2 = T, fs0 = T*CHW, fs1 = 2*T*CHW, fs2 = CHW,
+ * without first copying it into that order. */
+int rbvae_im2col_frames(int dtype, const float* src, int fd1, int fd2, long fs0, long fs1, long fs2, long sc, long sh,
+                        long sw, int N, int C, int IH, int IW, int OH, int OW, int KH, int KW, int stride, int pad,
+                        int Kpad, void* col, void* stream);
+int rbvae_col2im_sigmoid_frames(int dtype, const void* Y, int ldy, const float* bias, int N, int IH, int IW, int OH,
+                                int OW, int Cout, int KH, int KW, int pad, float* xr, const float* target, int fd1,
+                                int fd2, long fs0, long fs1, long fs2, float* sse_mean, float* ws, float* dpre,
+                                float gscale, const float* gscale_dev, void* stream);
 int rbvae_sigmoid_bwd_nhwc(const float* g_nchw, const float* xr_nchw, float* dpre_nhwc, int N, int C, int H, int W,
                            void* stream);
 /* Linear with few outputs (percep_RBVAE_model.py:61 forward; :74 backward-data):

@@ -87,10 +87,28 @@ __global__ __launch_bounds__(256) void colsum_final_k(const float* __restrict__ 
     }
 }
 
+// Frame n of a batch -> element offset of its first value.  d1 == 0: n * s2.  Otherwise n is read as the
+// mixed-radix number (n / d1, (n % d1) / d2, n % d2) with strides (s0, s1, s2): the fused trainer runs both
+// views of an item batch [B][2][T] as frames v*(B*T) + b*T + t without first copying them into that order.
+struct FrameMap {
+    int d1, d2;
+    long s0, s1, s2;
+};
+template <typename I> __device__ __forceinline__ I frame_off(const FrameMap& f, I n) {
+    if (f.d1 == 0) return n * (I)f.s2;
+    const I a = n / (I)f.d1, r = n - a * (I)f.d1;
+    const I b = r / (I)f.d2, c = r - b * (I)f.d2;
+    return a * (I)f.s0 + b * (I)f.s1 + c * (I)f.s2;
+}
+static long frame_span(const FrameMap& f, int N) {      // largest frame offset (non-negative strides)
+    if (f.d1 == 0) return (long)(N - 1) * f.s2;
+    return (long)((N - 1) / f.d1) * f.s0 + (long)(f.d1 / f.d2 - 1) * f.s1 + (long)(f.d2 - 1) * f.s2;
+}
+
 // ---- im2col: strided f32 source -> col[P][Kpad] (column (kh*KW+kw)*C + c) ----
 // one thread = 8 consecutive columns of one row (Kpad % 8 == 0): one 16-B (bf16) / two 16-B (f32) stores
 template <typename T>
-__global__ void im2col_k(const float* __restrict__ src, long sn, long sc, long sh, long sw, int N, int C, int IH,
+__global__ void im2col_k(const float* __restrict__ src, FrameMap fm, long sc, long sh, long sw, int N, int C, int IH,
                          int IW, int OH, int OW, int KH, int KW, int stride, int pad, int Kpad,
                          T* __restrict__ col) {
     const int gpr = Kpad >> 3;                          // column groups per row
@@ -114,7 +132,7 @@ __global__ void im2col_k(const float* __restrict__ src, long sn, long sc, long s
             const bool ok = kx < kreal && ih >= 0 && ih < IH && iw >= 0 && iw < IW;
             // clamped address: the load is unconditional (all 8 in flight), the select zeroes padding
             const int ihc = min(max(ih, 0), IH - 1), iwc = min(max(iw, 0), IW - 1);
-            const float x = src[n * sn + c * sc + ihc * sh + iwc * sw];
+            const float x = src[frame_off<long>(fm, n) + c * sc + ihc * sh + iwc * sw];
             v[e] = ok ? x : 0.f;
         }
         T* dst = col + pp * Kpad + kg * 8;
@@ -136,7 +154,7 @@ __global__ void im2col_k(const float* __restrict__ src, long sn, long sc, long s
 // of the general kernel above made it ALU bound: ~1000 instructions per 16-byte store).  CC / KWC > 0 fix the
 // channel count and kernel width at compile time (divisions become shifts / multiplies); 0 = runtime values.
 template <typename T, int CC, int KWC>
-__global__ __launch_bounds__(256) void im2col_fast_k(const float* __restrict__ src, int sn, int sc, int sh, int sw,
+__global__ __launch_bounds__(256) void im2col_fast_k(const float* __restrict__ src, FrameMap fm, int sc, int sh, int sw,
                                                      int N, int C_, int IH, int IW, int OH, int OW, int KH, int KW_,
                                                      int stride, int pad, int Kpad, T* __restrict__ col) {
     const unsigned C = CC > 0 ? CC : C_, KW = KWC > 0 ? KWC : KW_;
@@ -149,7 +167,7 @@ __global__ __launch_bounds__(256) void im2col_fast_k(const float* __restrict__ s
     const unsigned r = pp / OW, ow = pp - r * OW;
     const unsigned n = r / OH, oh = r - n * OH;
     const int ih0 = (int)oh * stride - pad, iw0 = (int)ow * stride - pad;
-    const float* base = src + n * sn;
+    const float* base = src + frame_off<unsigned>(fm, n);
     float v[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
@@ -183,7 +201,7 @@ __global__ __launch_bounds__(256) void im2col_fast_k(const float* __restrict__ s
 template <typename T, typename IDX>
 __global__ __launch_bounds__(256) void col2im_sigmoid_k(
     const T* __restrict__ Y, int ldy, const float* __restrict__ bias, int N, int IH, int IW, int OH, int OW,
-    int Cout, int KH, int KW, int pad, float* __restrict__ xr, const float* __restrict__ target,
+    int Cout, int KH, int KW, int pad, float* __restrict__ xr, const float* __restrict__ target, FrameMap tfm,
     float* __restrict__ sse_ws, float* __restrict__ dpre, float gscale, const float* __restrict__ gs_dev) {
     __shared__ float red[4];
     const IDX tot = (IDX)N * OH * OW * Cout;
@@ -210,7 +228,8 @@ __global__ __launch_bounds__(256) void col2im_sigmoid_k(
         const float s = sigmoidf_(v);
         xr[i] = s;
         if (target) {
-            const float d = s - target[i];
+            // frame n of the target sits at its mapped offset; inside a frame the layout is xr's (co, oh, ow)
+            const float d = s - target[frame_off<IDX>(tfm, (IDX)n) + (i - (IDX)n * (IDX)Cout * (IDX)OH * (IDX)OW)];
             sse += d * d;
             if (dpre) dpre[((long)(n * OH + oh) * OW + ow) * Cout + co] = gsc * d * s * (1.f - s);
         }
@@ -421,21 +440,24 @@ int rbvae_reduce_rows(const float* ws, int rows, int C, float* out, float scale,
     return RBVAE_OK;
 }
 
-int rbvae_im2col(int dtype, const float* src, long sn, long sc, long sh, long sw, int N, int C, int IH, int IW,
-                 int OH, int OW, int KH, int KW, int stride, int pad, int Kpad, void* col, void* stream) {
+static int im2col_impl(int dtype, const float* src, FrameMap fm, long sc, long sh, long sw, int N, int C, int IH, int IW,
+                       int OH, int OW, int KH, int KW, int stride, int pad, int Kpad, void* col, void* stream) {
+    const long sn = fm.s2;
     RBVAE_CHECK_ARG(src && col && N > 0 && C > 0 && Kpad >= KH * KW * C, "im2col: bad arguments");
+    RBVAE_CHECK_ARG(fm.d1 == 0 || (fm.d2 > 0 && fm.d1 % fm.d2 == 0 && fm.s0 >= 0 && fm.s1 >= 0),
+                    "im2col: frame map d1=%d d2=%d", fm.d1, fm.d2);
     RBVAE_CHECK_ARG(Kpad % 8 == 0 && (uintptr_t)col % 16 == 0, "im2col: Kpad=%d must be a multiple of 8, col 16-byte aligned", Kpad);
     const long tot = (long)N * OH * OW * (Kpad / 8);
     RBVAE_CHECK_ARG(dtype == RBVAE_F32 || dtype == RBVAE_BF16, "im2col: dtype %d", dtype);
     hipStream_t st = (hipStream_t)stream;
     // largest source offset the kernel forms (all strides non-negative in this library's callers)
-    const long span = (long)(N - 1) * sn + (long)(C - 1) * sc + (long)(IH - 1) * sh + (long)(IW - 1) * sw;
+    const long span = frame_span(fm, N) + (long)(C - 1) * sc + (long)(IH - 1) * sh + (long)(IW - 1) * sw;
     const bool fast = tot < (1l << 31) - 256 && span < (1l << 31) && (long)N * OH * OW * Kpad < (1l << 40) &&
                       sn >= 0 && sc >= 0 && sh >= 0 && sw >= 0;
     if (fast) {
         const dim3 grid(cdiv(tot, 256));
 #define RBVAE_IM2COL(TT, CC, KK)                                                                                      \
-    hipLaunchKernelGGL((im2col_fast_k<TT, CC, KK>), grid, dim3(256), 0, st, src, (int)sn, (int)sc, (int)sh, (int)sw, N, \
+    hipLaunchKernelGGL((im2col_fast_k<TT, CC, KK>), grid, dim3(256), 0, st, src, fm, (int)sc, (int)sh, (int)sw, N,      \
                        C, IH, IW, OH, OW, KH, KW, stride, pad, Kpad, (TT*)col)
         if (dtype == RBVAE_F32) {
             if (C == 4 && KW == 3) RBVAE_IM2COL(float, 4, 3);
@@ -449,22 +471,37 @@ int rbvae_im2col(int dtype, const float* src, long sn, long sc, long sh, long sw
 #undef RBVAE_IM2COL
     } else if (dtype == RBVAE_F32)
         hipLaunchKernelGGL(im2col_k<float>, dim3(grid_for(tot, 256, 8192)), dim3(256), 0, st, src,
-                           sn, sc, sh, sw, N, C, IH, IW, OH, OW, KH, KW, stride, pad, Kpad, (float*)col);
+                           fm, sc, sh, sw, N, C, IH, IW, OH, OW, KH, KW, stride, pad, Kpad, (float*)col);
     else
         hipLaunchKernelGGL(im2col_k<bf16_t>, dim3(grid_for(tot, 256, 8192)), dim3(256), 0, st, src,
-                           sn, sc, sh, sw, N, C, IH, IW, OH, OW, KH, KW, stride, pad, Kpad, (bf16_t*)col);
+                           fm, sc, sh, sw, N, C, IH, IW, OH, OW, KH, KW, stride, pad, Kpad, (bf16_t*)col);
     RBVAE_CHECK_LAUNCH("im2col");
     return RBVAE_OK;
+}
+
+int rbvae_im2col(int dtype, const float* src, long sn, long sc, long sh, long sw, int N, int C, int IH, int IW,
+                 int OH, int OW, int KH, int KW, int stride, int pad, int Kpad, void* col, void* stream) {
+    return im2col_impl(dtype, src, FrameMap{0, 0, 0, 0, sn}, sc, sh, sw, N, C, IH, IW, OH, OW, KH, KW, stride, pad, Kpad,
+                       col, stream);
+}
+
+int rbvae_im2col_frames(int dtype, const float* src, int fd1, int fd2, long fs0, long fs1, long fs2, long sc, long sh,
+                        long sw, int N, int C, int IH, int IW, int OH, int OW, int KH, int KW, int stride, int pad,
+                        int Kpad, void* col, void* stream) {
+    return im2col_impl(dtype, src, FrameMap{fd1, fd2, fs0, fs1, fs2}, sc, sh, sw, N, C, IH, IW, OH, OW, KH, KW, stride,
+                       pad, Kpad, col, stream);
 }
 
 size_t rbvae_col2im_ws_floats(void) { return 4096; }
 int rbvae_col2im_nparts(long n_out) { return grid_for(n_out, 256, 4096); }
 
-int rbvae_col2im_sigmoid(int dtype, const void* Y, int ldy, const float* bias, int N, int IH, int IW, int OH,
-                         int OW, int Cout, int KH, int KW, int pad, float* xr, const float* target,
-                         float* sse_mean, float* ws, float* dpre, float gscale, const float* gscale_dev,
-                         void* stream) {
+static int col2im_impl(int dtype, const void* Y, int ldy, const float* bias, int N, int IH, int IW, int OH,
+                       int OW, int Cout, int KH, int KW, int pad, float* xr, const float* target, FrameMap tfm,
+                       float* sse_mean, float* ws, float* dpre, float gscale, const float* gscale_dev,
+                       void* stream) {
     RBVAE_CHECK_ARG(Y && xr && N > 0 && Cout > 0 && ldy >= KH * KW * Cout, "col2im_sigmoid: bad arguments");
+    RBVAE_CHECK_ARG(tfm.d1 == 0 || (tfm.d2 > 0 && tfm.d1 % tfm.d2 == 0 && tfm.s0 >= 0 && tfm.s1 >= 0),
+                    "col2im_sigmoid: frame map d1=%d d2=%d", tfm.d1, tfm.d2);
     RBVAE_CHECK_ARG(!sse_mean || (target && ws), "col2im_sigmoid: sse_mean needs target and ws");
     RBVAE_CHECK_ARG(!dpre || target, "col2im_sigmoid: dpre needs target");
     const long tot = (long)N * OH * OW * Cout;
@@ -473,10 +510,11 @@ int rbvae_col2im_sigmoid(int dtype, const void* Y, int ldy, const float* bias, i
     // sse_mean == NULL with ws given: leave the nb per-block partial sums in ws (rbvae_combine_losses finishes them)
     float* sws = (sse_mean || ws) && target ? ws : nullptr;
     hipStream_t st = (hipStream_t)stream;
-    const bool small = tot < (1l << 31) - (1l << 20) && (long)N * IH * IW * ldy < (1l << 31);
+    const bool small = tot < (1l << 31) - (1l << 20) && (long)N * IH * IW * ldy < (1l << 31) &&
+                       frame_span(tfm, N) + (long)Cout * OH * OW < (1l << 31);
 #define RBVAE_COL2IM(TT, II)                                                                                       \
     hipLaunchKernelGGL((col2im_sigmoid_k<TT, II>), dim3(nb), dim3(256), 0, st, (const TT*)Y, ldy, bias, N, IH, IW, OH, \
-                       OW, Cout, KH, KW, pad, xr, target, sws, dpre, gscale, gscale_dev)
+                       OW, Cout, KH, KW, pad, xr, target, tfm, sws, dpre, gscale, gscale_dev)
     if (dtype == RBVAE_F32) { if (small) RBVAE_COL2IM(float, unsigned); else RBVAE_COL2IM(float, long); }
     else { if (small) RBVAE_COL2IM(bf16_t, unsigned); else RBVAE_COL2IM(bf16_t, long); }
 #undef RBVAE_COL2IM
@@ -484,6 +522,22 @@ int rbvae_col2im_sigmoid(int dtype, const void* Y, int ldy, const float* bias, i
         hipLaunchKernelGGL(sum_partials_k, dim3(1), dim3(1024), 0, st, ws, nb, 1.0f / (float)tot, sse_mean, 0);
     RBVAE_CHECK_LAUNCH("col2im_sigmoid");
     return RBVAE_OK;
+}
+
+int rbvae_col2im_sigmoid(int dtype, const void* Y, int ldy, const float* bias, int N, int IH, int IW, int OH,
+                         int OW, int Cout, int KH, int KW, int pad, float* xr, const float* target,
+                         float* sse_mean, float* ws, float* dpre, float gscale, const float* gscale_dev,
+                         void* stream) {
+    return col2im_impl(dtype, Y, ldy, bias, N, IH, IW, OH, OW, Cout, KH, KW, pad, xr, target,
+                       FrameMap{0, 0, 0, 0, (long)Cout * OH * OW}, sse_mean, ws, dpre, gscale, gscale_dev, stream);
+}
+
+int rbvae_col2im_sigmoid_frames(int dtype, const void* Y, int ldy, const float* bias, int N, int IH, int IW, int OH,
+                                int OW, int Cout, int KH, int KW, int pad, float* xr, const float* target, int fd1,
+                                int fd2, long fs0, long fs1, long fs2, float* sse_mean, float* ws, float* dpre,
+                                float gscale, const float* gscale_dev, void* stream) {
+    return col2im_impl(dtype, Y, ldy, bias, N, IH, IW, OH, OW, Cout, KH, KW, pad, xr, target,
+                       FrameMap{fd1, fd2, fs0, fs1, fs2}, sse_mean, ws, dpre, gscale, gscale_dev, stream);
 }
 
 // total = recon + beta*kl + alpha*pair, with recon finished from the col2im kernel's partial sums

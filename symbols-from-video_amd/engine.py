@@ -229,11 +229,12 @@ class Engine:
         self._bufs: Dict = {}          # persistent backward temporaries, keyed by (N, tag)
         self._bwd_tab: Dict = {}       # uploaded reduce-job tables, keyed by their signature
         self._jobs: Optional[JobList] = None
-        self._side: Optional[torch.cuda.Stream] = None
+        self._sides: List[Optional[torch.cuda.Stream]] = [None, None]
         # weight-gradient work of the decoder runs on a side stream beside the LSTM backward chain (RBVAE_OVERLAP=0:
         # everything in issue order on one stream)
         import os
         self.overlap = os.environ.get("RBVAE_OVERLAP", "1") == "1"
+        self.pack_late_split = os.environ.get("RBVAE_PACK_LATE", "0") == "1"
         self._alloc_packed()
 
     # ---- packed weights -------------------------------------------------------
@@ -267,27 +268,41 @@ class Engine:
             self._pack_tab[key] = tab
         L.call("rbvae_run_jobs", tab[0], tab[1], 256)
 
-    def pack_begin(self, flat: torch.Tensor):
-        """pack() split for the fused step: the first conv's weights on the current stream, every other packed
-        copy on the side stream beside the step's first kernels; pack_end() joins before they are needed."""
+    def _pack_split(self, flat: torch.Tensor):
+        """pack() cut by when the copies are first read in a fused step: `first` (the first conv, current
+        stream), `early` (rest of the encoder + both LSTM stacks: beside im2col / conv1), `late` (decoder and
+        backward-only copies: beside the fc / LSTM chain, where most of the chip is idle)."""
         key = ("split", flat.data_ptr())
         tab = self._pack_tab.get(key)
         if tab is None:
             jl = self._pack_jobs(flat)
-            first, rest = JobList(), JobList()
-            first.rows, rest.rows = jl.rows[:1], jl.rows[1:]
-            first.keep = rest.keep = jl.keep
-            tab = (first.upload(self.device), 1, rest.upload(self.device), len(rest.rows), jl)
+            late_dst = {t.data_ptr() for t in (self.V1f, self.V1d, self.V2f, self.V2d, self.V3p, self.V3f, self.Wdfc,
+                                                self.WdfcT, self.bdfc, self.WfcT)}
+            parts = [JobList(), JobList(), JobList()]
+            for i, row in enumerate(jl.rows):
+                which = 0 if i == 0 else (2 if row[2] in late_dst and self.pack_late_split else 1)
+                parts[which].rows.append(row)
+            tab = tuple((p.upload(self.device), len(p.rows)) for p in parts) + (jl,)
             self._pack_tab[key] = tab
-        if self._fork():
-            with self._on_side():
-                L.call("rbvae_run_jobs", tab[2], tab[3], 256)
-        else:
-            L.call("rbvae_run_jobs", tab[2], tab[3], 256)
-        L.call("rbvae_run_jobs", tab[0], tab[1], 256)
+        return tab
+
+    def pack_begin(self, flat: torch.Tensor):
+        first, early, _, _ = self._pack_split(flat)
+        self._fork(1)
+        with self._on_side(1):
+            L.call("rbvae_run_jobs", early[0], early[1], 256)
+        L.call("rbvae_run_jobs", first[0], first[1], 256)
+
+    def pack_late(self, flat: torch.Tensor):
+        late = self._pack_split(flat)[2]
+        if late[1] == 0:
+            return
+        self._fork(1)
+        with self._on_side(1):
+            L.call("rbvae_run_jobs", late[0], late[1], 256)
 
     def pack_end(self):
-        self._join()
+        self._join(1)
 
     def _pack_jobs(self, flat: torch.Tensor) -> JobList:
         lay, dt = self.layout, self.dt
@@ -394,26 +409,26 @@ class Engine:
     # ---- side stream ------------------------------------------------------------------
     # The LSTM chains occupy 2B workgroups for ~25 us per stack; weight-gradient GEMMs that do not feed them are
     # issued on a side stream over exactly those windows (graph capture turns the fork/join into graph edges).
-    def _fork(self):
-        """Side stream picks up after everything queued so far on the current stream."""
+    def _fork(self, which: int = 0):
+        """Side stream `which` picks up after everything queued so far on the current stream."""
         if not self.overlap:
             return False
-        if self._side is None:
-            self._side = torch.cuda.Stream(device=self.device)
-        self._side.wait_stream(torch.cuda.current_stream())
+        if self._sides[which] is None:
+            self._sides[which] = torch.cuda.Stream(device=self.device)
+        self._sides[which].wait_stream(torch.cuda.current_stream())
         return True
 
-    def _on_side(self):
+    def _on_side(self, which: int = 0):
         import contextlib
-        return torch.cuda.stream(self._side) if self.overlap else contextlib.nullcontext()
+        return torch.cuda.stream(self._sides[which]) if self.overlap else contextlib.nullcontext()
 
-    def _side_wait_main(self):
+    def _side_wait_main(self, which: int = 0):
         if self.overlap:
-            self._side.wait_stream(torch.cuda.current_stream())
+            self._sides[which].wait_stream(torch.cuda.current_stream())
 
-    def _join(self):
-        if self.overlap and self._side is not None:
-            torch.cuda.current_stream().wait_stream(self._side)
+    def _join(self, which: int = 0):
+        if self.overlap and self._sides[which] is not None:
+            torch.cuda.current_stream().wait_stream(self._sides[which])
 
     def _run_jobs(self):
         jl, self._jobs = self._jobs, None
@@ -432,12 +447,15 @@ class Engine:
                 noise_ratio: float, train: bool, masks: Optional[Sequence[torch.Tensor]] = None,
                 seed: int = 0, need_grad: bool = True, encode_only: bool = False,
                 target: Optional[torch.Tensor] = None, recon_gscale: float = 0.0, kl_p: Optional[float] = None,
-                after_hs=None, defer_losses: bool = False, repack: bool = False):
+                after_hs=None, defer_losses: bool = False, repack: bool = False,
+                frame_map: Optional[Tuple[int, int, int, int, int]] = None):
         """x: [S,T,C,H,W] f32 NCHW frames; U: [S*T, L] uniform noise.
         masks: explicit dropout keep-masks (u8, NHWC rows) for the 4 dropout sites, else a counter hash.
         target/recon_gscale: fuse recon_loss and its gradient into the last kernel (trainer path).
         defer_losses: leave recon_loss and the KL mean as per-block partial sums ("sse": (ws, nparts, 1/n),
         "kl": (parts, nparts, 1/rows)) for rbvae_combine_losses to finish.
+        frame_map: (d1, d2, s0, s1, s2) -- frame n of x (and of target) starts at element
+        (n // d1) * s0 + ((n % d1) // d2) * s1 + (n % d2) * s2 of the buffer x points at (rbvae_im2col_frames).
         repack: refresh the packed weight copies from `flat` first (all but the first conv's on the side stream).
         after_hs: optional callable(h_seq) issued on the side stream as soon as the encoder LSTM is done (the
         trainer's pairwise term runs there, beside the decoder); backward() joins it.
@@ -470,7 +488,11 @@ class Engine:
         if repack:
             self.pack_begin(flat)
         sv.col1 = self._E(N * h1 * w1, self.K1)
-        L.call("rbvae_im2col", self.dt, x, C * H * W, H * W, W, 1, N, C, H, W, h1, w1, k, k, 2, 1, self.K1, sv.col1)
+        if frame_map is None:
+            L.call("rbvae_im2col", self.dt, x, C * H * W, H * W, W, 1, N, C, H, W, h1, w1, k, k, 2, 1, self.K1, sv.col1)
+        else:
+            L.call("rbvae_im2col_frames", self.dt, x, *frame_map, H * W, W, 1, N, C, H, W, h1, w1, k, k, 2, 1, self.K1,
+                   sv.col1)
         sv.a1 = self._E(N * h1 * w1, c1)
         m, mk = dm(0)
         self._gemm(sv.col1, self.W1p, sv.a1, P(f"encoder_cnn.conv.{i0}.bias"), None, mk, N * h1 * w1, 1, 1, 1, 1, 1,
@@ -485,6 +507,8 @@ class Engine:
         sv.a3 = self._E(N * h3 * w3, c3)
         self._gemm(sv.a2, self.W3f, sv.a3, P(f"encoder_cnn.conv.{i2}.bias"), None, None, N, h2, w2, h3, w3, 2, h3,
                    w3, 1, c2, c3, c2, c3, kk, "conv", relu=1 if v.simple_order else 0)
+        if repack:
+            self.pack_late(flat)
         # fc -> logits e [N][L]
         nl = v.lstm_layers
         sv.hs_enc = self._E(nl + 1, S, T, Ld, dtype=torch.float32)
@@ -523,6 +547,8 @@ class Engine:
                 L.call("rbvae_binarize_kl_fwd", hs, U, sv.y, sv.z, kl, N, Ld, float(tau), float(r), v.eps, int(hard),
                        float(kl_p if kl_p is not None else 0.5), 1e-8, 1, int(seed) * 8 + 5, self.seed_dev)
             if encode_only:
+                if repack:
+                    self.pack_end()
                 return {"z": sv.z.view(S, T, Ld), "hs": hs, "saved": sv}
             L.call("rbvae_lstm_fwd", wdec, self.wT_dec, sv.hs_dec, sv.hp_dec, sv.acts_dec, sv.cs_dec, S, T, Ld, nl)
         else:
@@ -537,6 +563,8 @@ class Engine:
         # decoder CNN
         sv.ds_pad = self._E(N, self.Lp)
         L.call("rbvae_cast_pad", self.dt, ds, sv.ds_pad, N, Ld, self.Lp)
+        if repack:
+            self.pack_end()
         sv.f = self._E(N * h3 * w3, c3)
         self._gemm(sv.ds_pad, self.Wdfc, sv.f, self.bdfc, None, None, N, 1, 1, 1, 1, 1, 1, 1, 1, self.Lp, self.F3,
                    self.Lp, self.F3, 1, "one")
@@ -563,8 +591,13 @@ class Engine:
                 mse = self._E(1, dtype=torch.float32)
             if need_grad:
                 sv.dpre3 = self._E(N, H, W, self.out_ch, dtype=torch.float32)
-            L.call("rbvae_col2im_sigmoid", self.dt, Y, self.NY, P(f"decoder_cnn.deconv.{i2}.bias"), N, h1, w1, H, W,
-                   self.out_ch, k, k, 1, sv.xr, target.contiguous(), mse, ws, sv.dpre3, float(recon_gscale), None)
+            if frame_map is None:
+                L.call("rbvae_col2im_sigmoid", self.dt, Y, self.NY, P(f"decoder_cnn.deconv.{i2}.bias"), N, h1, w1, H, W,
+                       self.out_ch, k, k, 1, sv.xr, target.contiguous(), mse, ws, sv.dpre3, float(recon_gscale), None)
+            else:
+                L.call("rbvae_col2im_sigmoid_frames", self.dt, Y, self.NY, P(f"decoder_cnn.deconv.{i2}.bias"), N, h1,
+                       w1, H, W, self.out_ch, k, k, 1, sv.xr, target.contiguous(), *frame_map, mse, ws, sv.dpre3,
+                       float(recon_gscale), None)
         else:
             L.call("rbvae_col2im_sigmoid", self.dt, Y, self.NY, P(f"decoder_cnn.deconv.{i2}.bias"), N, h1, w1, H, W,
                    self.out_ch, k, k, 1, sv.xr, None, None, None, None, 0.0, None)

@@ -73,9 +73,11 @@ class FusedTrainer:
                 L.call("rbvae_contrast_term_bwd", h0, h1, B, T, Ld, float(self.alpha), None, g_hs[:B], g_hs[B:])
 
         # dropout follows the module's mode like the reference (model.train() in train_one_epoch, :501)
-        out = eng.forward(model._flat, x, U, tau, False, self.r, bool(model.training), None, seed=0, need_grad=True,
-                          target=x, recon_gscale=2.0 / numel, kl_p=self.p, after_hs=pair_term,
-                          defer_losses=True, repack=True)
+        # x is the item batch [B, 2, T, C, H, W] as it is; frame (v, b, t) = sequence v*B + b, state t
+        chw = numel // (2 * B * T)
+        out = eng.forward(model._flat, x.view(2 * B, T, *x.shape[3:]), U, tau, False, self.r, bool(model.training), None,
+                          seed=0, need_grad=True, target=x, recon_gscale=2.0 / numel, kl_p=self.p, after_hs=pair_term,
+                          defer_losses=True, repack=True, frame_map=(B * T, T, T * chw, 2 * T * chw, chw))
         eng.backward(model._flat, self.gflat, out["saved"], None, g_hs, None, kl_weight=self.beta_kl, kl_p=self.p,
                      g_hs_inplace=True)
         sse_ws, nparts, inv_n = out["sse"]
@@ -113,10 +115,11 @@ class FusedTrainer:
         key = (B, T, float(temperature), U is not None)
         st = self._static.get(key[:2])
         if st is None:
-            st = {"x": torch.empty(2 * B, T, C, H, W, device=self.dev),
+            st = {"x": torch.empty(B, 2, T, C, H, W, device=self.dev),
                   "U": torch.empty(2 * B * T, Ld, device=self.dev)}
             self._static[key[:2]] = st
-        st["x"].view(2, B, T, C, H, W).copy_(item.transpose(0, 1))
+        if item.data_ptr() != st["x"].data_ptr() or not item.is_contiguous():
+            st["x"].copy_(item)          # skipped when the caller fills input_buffer() in place
         if U is not None:
             st["U"].copy_(U.reshape(2 * B * T, Ld))
         Uarg = st["U"] if U is not None else None
@@ -135,6 +138,17 @@ class FusedTrainer:
         self.steps += 1
         self.model._packed_version = None     # anything else that runs the model before the next step repacks first
         return self.losses
+
+    def input_buffer(self, B: int, T: int, C: int, H: int, W: int) -> torch.Tensor:
+        """The step's static input [B, 2, T, C, H, W] (the address the captured graphs read).  A data loader that
+        writes its batch here (e.g. DeviceStatePairDataset gathering with out=) and passes the same tensor to
+        step() saves the device-to-device copy of the batch."""
+        st = self._static.get((B, T))
+        if st is None:
+            st = {"x": torch.empty(B, 2, T, C, H, W, device=self.dev),
+                  "U": torch.empty(2 * B * T, self.model.latent_dim, device=self.dev)}
+            self._static[(B, T)] = st
+        return st["x"]
 
     def _allreduce(self):
         if self.world > 1:
