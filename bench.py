@@ -25,10 +25,18 @@ import torch
 B_ITEMS, T_STATES, C_IN, HW, LATENT = 16, 8, 4, (32, 32), 32
 TAU, NOISE_R, BERN_P, ALPHA, BETA = 0.7, 0.1, 0.1, 1.0, 1.0
 MFMA_BF16_PEAK_TFLOPS = 2500.0     # MI355X_MICROARCH.md: dense bf16 MFMA peak
+# HBM bytes per launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this same command (separate
+# passes, FETCH doubled per the guide's gfx950 correction); filled in from profiles/ by tools/pmc_traffic.py
+PMC_TRAFFIC = {}
+try:
+    with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as _f:
+        PMC_TRAFFIC = json.load(_f)
+except (OSError, ValueError):
+    pass
 
 
 class KernelTimer:
-    """HIP events around every launch of one kernel family, on the stream it is launched on."""
+    """HIP events around every launch of one kernel instance, on the stream it is launched on."""
 
     def __init__(self):
         self.pairs = []
@@ -36,10 +44,11 @@ class KernelTimer:
 
     @contextlib.contextmanager
     def __call__(self, flops):
+        st = torch.cuda.current_stream()
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        a.record(torch.cuda.current_stream())
+        a.record(st)
         yield
-        b.record(torch.cuda.current_stream())
+        b.record(st)
         self.pairs.append((a, b))
         self.flops += flops
 
@@ -49,40 +58,76 @@ class KernelTimer:
         return ms, len(self.pairs), self.flops
 
 
-def roofline_leg(trainer, item, steps):
-    """Re-run `steps` steps eagerly with events bracketing every launch of the dominant kernel instance:
-    gather_gemm_k<bf16, NT=4, 8 waves, ring 3> = the deep-K 128x128 row-gather GEMM that runs conv2/conv3
-    forward, the first deconv forward and their input-gradient passes (6 launches per step)."""
+def roofline_leg(trainer, item, steps, tname):
+    """Re-run `steps` steps eagerly on ONE stream (RBVAE_OVERLAP off for this leg, so an event pair brackets exactly
+    one kernel) with HIP events around every launch of the two matrix-core kernel families, keyed by the template
+    instance the library's dispatch picks.  Returns {instance: (ms, launches, algorithmic flops)}.
+
+      gather_gemm_k<T,4,8,3>  128x128 row-gather GEMM, deep K, 129..256 workgroups: conv2 forward, first deconv
+                              forward (4 parity classes) and their two input-gradient twins
+      wgrad_gemm_k<T,2,3>     128x128 weight-gradient GEMM with K split over workgroups: the five 256-channel ones
+    Algorithmic FLOPs: 2 * output rows * Nout * Kc * taps for the gather GEMM (the 4 parity classes of a
+    transposed convolution share its k*k taps: taps/4 per output pixel), 2 * P * Co * Ci * taps for wgrad."""
     eng = trainer.eng
-    timer = KernelTimer()
-    orig = eng._gemm
+    timers = {}
+    orig_gemm, orig_wgrad = eng._gemm, eng._wgrad
     ke = eng.ke
 
-    def timed(A, W, out, bias, gate, mask, nimg, ih, iw, th, tw, sa, oh, ow, so, kc, nout, lda, ldo, taps, cls_key, **kw):
+    def timed_gemm(A, W, out, bias, gate, mask, nimg, ih, iw, th, tw, sa, oh, ow, so, kc, nout, lda, ldo, taps, cls_key,
+                   **kw):
         args = (A, W, out, bias, gate, mask, nimg, ih, iw, th, tw, sa, oh, ow, so, kc, nout, lda, ldo, taps, cls_key)
         ncls = 4 if cls_key == "dgrad" else 1
-        max_taps = {"one": 1, "conv": taps, "dgrad": max(1, (taps + 3) // 4 if taps == 9 else taps // 4)}[cls_key]
-        if cls_key == "dgrad" and taps == 9:
-            max_taps = 4
+        max_taps = {"one": 1, "conv": taps, "dgrad": 4 if taps == 9 else max(1, taps // 4)}[cls_key]
         blocks = -(-(nimg * th * tw) // 128) * -(-nout // 128) * ncls
-        deep_ring3 = nout > 64 and max_taps * (kc // ke) > 2 and blocks <= 256     # same rule as dispatch_gg()
-        if not deep_ring3:
-            return orig(*args, **kw)
-        # algorithmic FLOPs: the 4 parity classes share the k*k taps -> taps/4 per output pixel
+        deep = nout > 64 and max_taps * (kc // ke) > 2            # same rules as dispatch_gg()
+        if not deep:
+            name = "gather_gemm_k<%s, single/double buffer>" % tname
+        elif blocks > 256:
+            name = "gather_gemm_k<%s, 4, 8, 2>" % tname
+        elif blocks <= 64:
+            name = "gather_gemm_k<%s, 1, 4, 3>" % tname
+        elif blocks <= 128:
+            name = "gather_gemm_k<%s, 2, 4, 3>" % tname
+        else:
+            name = "gather_gemm_k<%s, 4, 8, 3>" % tname
         rows, t_eff = (nimg * th * tw * 4, taps / 4.0) if cls_key == "dgrad" else (nimg * th * tw, float(taps))
-        with timer(2.0 * rows * nout * kc * t_eff):
-            return orig(*args, **kw)
+        with timers.setdefault(name, KernelTimer())(2.0 * rows * nout * kc * t_eff):
+            return orig_gemm(*args, **kw)
 
-    eng._gemm = timed
+    def timed_wgrad(Dy, In, idx, P, Co, Ci, ldy, ldi, taps, out, dims, strides, tag=None):
+        name = "wgrad_gemm_k<%s, %d, K-split>" % (tname, 2 if Ci > 64 else 1)
+        with timers.setdefault(name, KernelTimer())(2.0 * P * Co * Ci * taps):
+            return orig_wgrad(Dy, In, idx, P, Co, Ci, ldy, ldi, taps, out, dims, strides, tag=tag)
+
+    calib = KernelTimer()                  # event pairs around nothing: the event records' own cost
+
+    eng._gemm, eng._wgrad = timed_gemm, timed_wgrad
+    overlap = eng.overlap
+    eng.overlap = False
     trainer.instrument = True
     try:
         for _ in range(steps):
+            # Hold the stream behind a ~20 ms device-side sleep while the host enqueues the whole step: the GPU then
+            # runs the launches and event records back to back, so an event pair brackets the kernel and not the
+            # host's launch latency (eager launches are host bound: ~10 us of idle queue per launch otherwise).
+            torch.cuda._sleep(40_000_000)
+            for _ in range(4):
+                with calib(0.0):
+                    pass
             trainer.step(item, TAU)
-        ms, launches, flops = timer.result()
+            torch.cuda.synchronize()
+        cms, cn, _ = calib.result()
+        per_pair = cms / max(cn, 1)
+        res = {}
+        for k, t in timers.items():
+            ms, n, fl = t.result()
+            res[k] = (max(ms - n * per_pair, 1e-6), n, fl)
+        res["_event_pair_overhead_us"] = per_pair * 1e3
     finally:
-        eng._gemm = orig
+        eng._gemm, eng._wgrad = orig_gemm, orig_wgrad
+        eng.overlap = overlap
         trainer.instrument = None
-    return ms, launches, flops
+    return res
 
 
 def cpu_baseline(seconds_budget=15.0):
@@ -186,15 +231,25 @@ def main():
     losses = [float(v) for v in tr.losses.tolist()]
 
     roof = None
+    roof_all = None
     cpu = None
     # every rank runs the instrumented leg (its steps contain the gradient all-reduce: a collective)
-    ms, launches, flops = roofline_leg(tr, item, min(args.steps, 20))
+    tname = "unsigned short" if args.dtype == "bf16" else "float"
+    legs = roofline_leg(tr, item, min(args.steps, 20), tname)
     if rank == 0:
-        achieved = flops / (ms * 1e-3) / 1e12
-        roof = {"bound": "mfma", "kernel": "gather_gemm_k<%s, NT=4, WAVES=8, NS=3>" % ("unsigned short" if args.dtype == "bf16" else "float"),
-                "achieved": round(achieved, 2), "peak": MFMA_BF16_PEAK_TFLOPS if args.dtype == "bf16" else 157.3,
-                "unit": "TFLOP/s", "frac": round(achieved / (MFMA_BF16_PEAK_TFLOPS if args.dtype == "bf16" else 157.3), 4),
-                "traffic": None, "launches": launches, "avg_us": round(ms * 1e3 / max(launches, 1), 2)}
+        peak = MFMA_BF16_PEAK_TFLOPS if args.dtype == "bf16" else 157.3
+        roof_all = {}
+        ev_us = legs.pop("_event_pair_overhead_us", 0.0)
+        for name, (ms, launches, flops) in sorted(legs.items(), key=lambda kv: -kv[1][0]):
+            ach = flops / (ms * 1e-3) / 1e12
+            roof_all[name] = {"achieved": round(ach, 2), "frac": round(ach / peak, 4), "launches": launches,
+                              "avg_us": round(ms * 1e3 / max(launches, 1), 2),
+                              "us_per_step": round(ms * 1e3 / min(args.steps, 20), 1)}
+        dom = next(iter(roof_all))                       # the instance with the largest total time
+        d = roof_all[dom]
+        roof = {"bound": "mfma", "kernel": dom, "achieved": d["achieved"], "peak": peak, "unit": "TFLOP/s",
+                "frac": d["frac"], "traffic": PMC_TRAFFIC.get(dom), "launches": d["launches"], "avg_us": d["avg_us"],
+                "us_per_step": d["us_per_step"], "event_pair_overhead_us_subtracted": round(ev_us, 2)}
         if world == 1 and not args.no_cpu:
             cpu = cpu_baseline()
     if world > 1:
@@ -211,7 +266,7 @@ def main():
                            "frames_per_step_per_gpu": frames_per_step, "global_frames_per_step": frames_per_step * world,
                            "parallelism": f"dp{world}", "graph": not args.no_graph,
                            "last_losses": {"total": losses[0], "recon": losses[1], "kl": losses[2], "pair": losses[3]}},
-                "roofline": roof, "cpu_baseline": cpu}
+                "roofline": roof, "roofline_all_mfma_kernels": roof_all, "cpu_baseline": cpu}
         print(json.dumps(line))
     if world > 1:
         torch.distributed.destroy_process_group()

@@ -105,8 +105,12 @@ template <int N> __device__ __forceinline__ void wait_vmcnt_barrier() {
 // GG_NS = LDS ring depth.  3: two K-slices in flight behind the one being multiplied (one workgroup per
 // CU, deep K); 2: classic double buffer, two workgroups per CU; 1: single buffer for 1-2 slice problems
 // where four workgroups per CU overlap each other's load / store latencies instead.
-template <typename T, int NT, int WAVES, int GG_NS>
-__global__ __launch_bounds__(WAVES * 64, 1) void gather_gemm_k(const GgArgs p) {
+// OCC = waves per SIMD the register allocation must leave room for.  The single-buffer instances (1-2 slice
+// problems: the 3/4-channel ends of the CNNs, the fc products) live on having four workgroups per CU in flight;
+// the 128 x 128 one takes 230 registers unconstrained (2 per CU: a 1024-workgroup grid runs as two rounds) and
+// spills accumulators when held to 128, the 128 x 64 one fits 128 registers without spilling.
+template <typename T, int NT, int WAVES, int GG_NS, int OCC = 1>
+__global__ __launch_bounds__(WAVES * 64, OCC) void gather_gemm_k(const GgArgs p) {
     constexpr int THREADS = WAVES * 64;
     constexpr int BN = NT * 32;
     constexpr int ES = sizeof(T);
@@ -291,12 +295,14 @@ __global__ __launch_bounds__(WAVES * 64, 1) void gather_gemm_k(const GgArgs p) {
             if (s > 0) __syncthreads();              // everyone is done reading the single buffer
             stage_next();
             wait_vmcnt_barrier<0>();
+            // one fragment set, reused by both halves (registers, see the launch bounds)
             read_half(lds0, 0, fa0, fb0);
-            read_half(lds0, 1, fa1, fb1);
-            landed(Younger{}, fa0, fb0);
+            landed(None{}, fa0, fb0);
             mma_half(fa0, fb0);
-            landed(None{}, fa1, fb1);
-            mma_half(fa1, fb1);
+            __builtin_amdgcn_sched_barrier(0);
+            read_half(lds0, 1, fa0, fb0);
+            landed(None{}, fa0, fb0);
+            mma_half(fa0, fb0);
         }
     } else {
         // Software pipeline over the 32-k halves: while the matrix pipe works on one half the LDS serves the
@@ -436,7 +442,7 @@ __global__ __launch_bounds__(WAVES * 64, 1) void gather_gemm_k(const GgArgs p) {
     }
 }
 
-template <typename T, int NT, int WAVES, int NS>
+template <typename T, int NT, int WAVES, int NS, int OCC = 1>
 static int launch_gg(const GgArgs& a, hipStream_t st) {
     constexpr int BN = NT * 32;
     constexpr int ES = sizeof(T);
@@ -446,12 +452,12 @@ static int launch_gg(const GgArgs& a, hipStream_t st) {
     const size_t lds = (ring > tile ? ring : tile) + GG_BM * sizeof(int) + 64 * sizeof(int);
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute((const void*)gather_gemm_k<T, NT, WAVES, NS>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        hipFuncSetAttribute((const void*)gather_gemm_k<T, NT, WAVES, NS, OCC>, hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)lds);
         attr_set = true;
     }
     dim3 grid(cdiv(Mc, GG_BM), cdiv(a.Nout, BN), a.nclass);
-    hipLaunchKernelGGL((gather_gemm_k<T, NT, WAVES, NS>), grid, dim3(WAVES * 64), lds, st, a);
+    hipLaunchKernelGGL((gather_gemm_k<T, NT, WAVES, NS, OCC>), grid, dim3(WAVES * 64), lds, st, a);
     RBVAE_CHECK_LAUNCH("gather_gemm");
     return RBVAE_OK;
 }
@@ -470,7 +476,8 @@ static int dispatch_gg(const GgArgs& a, hipStream_t st, int max_steps) {
         if (small >= 2 && blocks <= 64) return launch_gg<T, 1, 4, 3>(a, st);
         if (blocks <= 128) return launch_gg<T, 2, 4, 3>(a, st);
     }
-    if (ns == 1) return launch_gg<T, 4, 4, 1>(a, st);
+    static const int one = getenv("RBVAE_GG_ONE") ? atoi(getenv("RBVAE_GG_ONE")) : 1;
+    if (ns == 1) return one == 1 && blocks > 512 ? launch_gg<T, 2, 4, 1, 4>(a, st) : launch_gg<T, 4, 4, 1>(a, st);
     if (ns >= 2 && (dbg == 5 || dbg == 6)) return dbg == 5 ? launch_gg<T, 2, 4, 3>(a, st) : launch_gg<T, 2, 4, 2>(a, st);
     if (ns == 2) return launch_gg<T, 4, 8, 2>(a, st);
     if (dbg == 4) return launch_gg<T, 4, 4, 3>(a, st);       // 4 waves, 64x64 wave tiles (less LDS traffic)

@@ -107,12 +107,28 @@ __global__ __launch_bounds__(256) void run_jobs_k(const Job* __restrict__ jobs) 
                     else ((bf16_t*)j.dst)[so] = f32_to_bf16(j.src[lin0 + i2]);
                 }
             } else {
-                // all d2 (<= 16) loads of a slab are independent and in flight together; slabs in fixed order
+                // slabs in fixed order, four at a time: all 4 * d2 loads of a group are independent and in flight
+                // together (one slab per iteration was a memory round trip per slab: 7 for the 256-channel weights)
                 float a[16];
 #pragma unroll
                 for (int i2 = 0; i2 < 16; ++i2) a[i2] = 0.f;
                 const float* p = j.src + so0;
-                for (unsigned k = 0; k < ns; ++k, p += j.slab) {
+                unsigned k = 0;
+                if (d2 <= 9) {
+                    for (; k + 4 <= ns; k += 4, p += 4 * j.slab) {
+                        float v[4][9];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+#pragma unroll
+                            for (int i2 = 0; i2 < 9; ++i2)
+                                v[q][i2] = (unsigned)i2 < d2 ? p[(size_t)q * j.slab + (size_t)i2 * j.s2] : 0.f;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+#pragma unroll
+                            for (int i2 = 0; i2 < 9; ++i2) a[i2] += v[q][i2];
+                    }
+                }
+                for (; k < ns; ++k, p += j.slab) {
                     float v[16];
 #pragma unroll
                     for (int i2 = 0; i2 < 16; ++i2) v[i2] = (unsigned)i2 < d2 ? p[(size_t)i2 * j.s2] : 0.f;

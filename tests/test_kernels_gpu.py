@@ -255,3 +255,79 @@ def test_adam_matches_torch(sfv):
         opt.step()
         sfv._lib.call("rbvae_adam_step", wd, gr.cuda(), m, v, n, 1e-3, 0.9, 0.999, 1e-8, step, 1.0, None, None)
         np.testing.assert_allclose(wd.cpu().numpy(), p.detach().numpy(), atol=2e-7, rtol=0)
+
+
+def test_frame_mapped_im2col_col2im(sfv):
+    """rbvae_im2col_frames / rbvae_col2im_sigmoid_frames read an item batch [B, 2, T, C, H, W] in place as the
+    sequences "view 0 of every item, then view 1" -- the same numbers as the plain calls on the copied batch."""
+    g = torch.Generator().manual_seed(16)
+    B, T, C, H, W, k = 3, 2, 4, 8, 12, 3
+    item = torch.rand(B, 2, T, C, H, W, generator=g).cuda()
+    x = item.transpose(0, 1).reshape(2 * B * T, C, H, W).contiguous()      # what the reference feeds, view by view
+    N, Ho, Wo, Kp = 2 * B * T, H // 2, W // 2, 64
+    chw = C * H * W
+    fm = (B * T, T, T * chw, 2 * T * chw, chw)
+    col_ref = torch.empty(N * Ho * Wo, Kp, device="cuda")
+    col = torch.empty_like(col_ref)
+    sfv._lib.call("rbvae_im2col", 0, x, chw, H * W, W, 1, N, C, H, W, Ho, Wo, k, k, 2, 1, Kp, col_ref)
+    sfv._lib.call("rbvae_im2col_frames", 0, item, *fm, H * W, W, 1, N, C, H, W, Ho, Wo, k, k, 2, 1, Kp, col)
+    assert torch.equal(col, col_ref)
+    NY = 40
+    Y = torch.randn(N * Ho * Wo, NY, generator=g).cuda()
+    bias = torch.randn(C, generator=g).cuda()
+    outs = []
+    for mapped in (False, True):
+        xr = torch.empty(N, C, H, W, device="cuda")
+        ws = torch.zeros(sfv._lib.query("rbvae_col2im_ws_floats"), device="cuda")
+        mse = torch.empty(1, device="cuda")
+        dpre = torch.empty(N, H, W, C, device="cuda")
+        if mapped:
+            sfv._lib.call("rbvae_col2im_sigmoid_frames", 0, Y, NY, bias, N, Ho, Wo, H, W, C, k, k, 1, xr, item, *fm, mse,
+                          ws, dpre, 0.25, None)
+        else:
+            sfv._lib.call("rbvae_col2im_sigmoid", 0, Y, NY, bias, N, Ho, Wo, H, W, C, k, k, 1, xr, x, mse, ws, dpre, 0.25,
+                          None)
+        outs.append((xr, mse, dpre))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+    assert abs(outs[0][1].item() - ((outs[0][0] - x) ** 2).mean().item()) < 1e-6
+
+
+def test_binarize_parts_and_combine(sfv):
+    """Many-workgroup binarise + per-block KL sums finished by rbvae_combine_losses == the one-workgroup kernel
+    (same y / z bit for bit, KL mean to f32 rounding), and the step counter / Adam terms it prepares."""
+    g = torch.Generator().manual_seed(17)
+    rows, L = 200, 25
+    h = torch.randn(rows, L, generator=g).cuda()
+    U = torch.rand(rows, L, generator=g).cuda()
+    y0, z0, y1, z1 = (torch.empty(rows, L, device="cuda") for _ in range(4))
+    kl0 = torch.empty(1, device="cuda")
+    sfv._lib.call("rbvae_binarize_kl_fwd", h, U, y0, z0, kl0, rows, L, 0.7, 0.1, 1e-8, 0, 0.1, 1e-8, 1, 0, None)
+    nparts = sfv._lib.query("rbvae_binarize_kl_nparts", rows, L)
+    assert nparts == -(-rows * L // 256)
+    parts = torch.empty(nparts, device="cuda")
+    sfv._lib.call("rbvae_binarize_kl_fwd_parts", h, U, y1, z1, parts, rows, L, 0.7, 0.1, 1e-8, 0, 0.1, 1e-8, 1, 0, None)
+    assert torch.equal(y0, y1) and torch.equal(z0, z1)
+    sse = torch.rand(37, generator=g).cuda()
+    pair = torch.tensor([0.375], device="cuda")
+    out4 = torch.empty(4, device="cuda")
+    step = torch.tensor([4], dtype=torch.int64, device="cuda")
+    hyper = torch.zeros(2, device="cuda")
+    sfv._lib.call("rbvae_combine_losses", sse, 37, 1.0 / 1000, None, parts, nparts, 1.0 / rows, pair, 0.5, 2.0, out4,
+                  step, 1e-3, 0.9, 0.999, hyper)
+    recon, kl = float(sse.sum()) / 1000, kl0.item()
+    got = out4.cpu().tolist()
+    assert abs(got[1] - recon) < 1e-6 and abs(got[2] - kl) < 1e-5 * max(1.0, abs(kl)) and got[3] == 0.375
+    assert abs(got[0] - (recon + 0.5 * kl + 2.0 * 0.375)) < 1e-5 * max(1.0, abs(kl))
+    assert int(step.item()) == 5
+    hy = hyper.cpu().tolist()
+    assert abs(hy[0] - 1e-3 / (1 - 0.9 ** 5)) < 1e-9 and abs(hy[1] - (1 - 0.999 ** 5) ** 0.5) < 1e-7
+    # Adam with prepared terms == Adam told the step number
+    n = 1000
+    w = torch.randn(n, generator=g).cuda()
+    gr = torch.randn(n, generator=g).cuda()
+    wa, ma, va = w.clone(), torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
+    wb, mb, vb = w.clone(), torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
+    sfv._lib.call("rbvae_adam_step", wa, gr, ma, va, n, 1e-3, 0.9, 0.999, 1e-8, 5, 1.0, None, None)
+    sfv._lib.call("rbvae_adam_step", wb, gr, mb, vb, n, 1e-3, 0.9, 0.999, 1e-8, 0, 1.0, None, hyper)
+    np.testing.assert_allclose(wb.cpu().numpy(), wa.cpu().numpy(), atol=1e-7, rtol=0)

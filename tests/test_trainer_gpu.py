@@ -70,3 +70,28 @@ def test_step_rejects_bad_input():
         tr.step(torch.zeros(2, 2, 1, 4, 16, 16, device="cuda"), 1.0)
     with pytest.raises(ValueError):
         FusedTrainer(sfv.Seq2SeqBinaryVAE(3, 3, 16, 16, variant="simple").cuda())
+
+
+def test_input_buffer_is_read_in_place():
+    """A batch written into trainer.input_buffer() and passed back to step() gives the same losses and weights as
+    the same batch passed as a separate tensor (which step() copies into that buffer)."""
+    import sfv_amd as sfv
+    from importlib import import_module
+    FusedTrainer = import_module("symbols-from-video_amd.trainer").FusedTrainer
+    B, T, Ld, hw = 2, 3, 32, (16, 16)
+    g = torch.Generator().manual_seed(9)
+    item = torch.rand(B, 2, T, 4, *hw, generator=g).cuda()
+    U = torch.rand(2, B * T, Ld, generator=g).cuda()
+    res = []
+    for in_place in (False, True):
+        torch.manual_seed(8)
+        m = sfv.Seq2SeqBinaryVAE(4, 4, Ld, Ld, variant="percep", input_hw=hw, compute_dtype="f32").cuda().eval()
+        tr = FusedTrainer(m, device_noise=False, use_graph=True)
+        x = item
+        if in_place:
+            x = tr.input_buffer(B, T, 4, *hw)
+            x.copy_(item)
+        for _ in range(2):
+            losses = tr.step(x, 0.9, U=U).clone()
+        res.append((losses, m._flat.clone()))
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])

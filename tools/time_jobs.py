@@ -31,7 +31,9 @@ def time_tab(label, tab, n, jl):
     for i, r in enumerate(jl.rows):
         us = t(tab[i:], 1)
         print(f"  job {i:2d} {names[r[0]]:15s} dims=({r[3]},{r[4]},{r[5]}) strides=({r[6]},{r[7]},{r[8]}) nslab={r[9]} fast={r[13] >> 32} inner={r[14]}: {us:6.1f} us")
-for key, (tab, n, jl) in eng._pack_tab.items():
-    time_tab("pack", tab, n, jl)
+eng.pack(model._flat)
+for key, val in eng._pack_tab.items():
+    if len(val) == 3:
+        time_tab("pack", *val)
 for sig, (tab, n, jl) in eng._bwd_tab.items():
     time_tab("bwd reduce", tab, n, jl)
