@@ -263,6 +263,8 @@ int rbvae_posterior_sample(int dtype, const void* moments, int ld, const float* 
 int rbvae_dbg_mfma_bf16(const void* A, const void* B, float* D, void* stream);   /* [16x32]x[32x16] bf16 */
 int rbvae_dbg_mfma_f32(const float* A, const float* B, float* D, void* stream);  /* [16x4]x[4x16] f32 */
 int rbvae_dbg_glds(const void* src, const int* lane_src_chunk, void* out, void* stream);
+/* every later rbvae_gather_gemm launch writes 8 phase time stamps (100 MHz) per workgroup into buf (NULL = off) */
+int rbvae_dbg_gg_stamps(unsigned long long* buf, void* stream);
 int rbvae_dbg_tr16(const void* img, const int* rowsel, const int* colsel, void* out, void* stream);
 
 #ifdef __cplusplus

@@ -10,7 +10,7 @@ import torch
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 HEADER = os.path.join(os.path.dirname(HERE), "include", "rbvae_hip.h")
-LIB_PATH = os.path.join(HERE, "librbvae_hip.so")
+LIB_PATH = os.environ.get("RBVAE_LIB") or os.path.join(HERE, "librbvae_hip.so")   # RBVAE_LIB: A/B another build
 
 E_INVALID, E_LAUNCH, E_UNSUPPORTED = -1, -2, -3
 

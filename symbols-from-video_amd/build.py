@@ -33,7 +33,11 @@ def _compile(src):
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed on {src}:\n{r.stdout}\n{r.stderr}")
         if src in ISA_CHECKED:
-            _check_asm_reads(src)
+            try:
+                _check_asm_reads(src)
+            except Exception:
+                os.remove(obj)          # a failed check must not leave an object the next build would link
+                raise
         return obj, True
     return obj, False
 

@@ -60,6 +60,8 @@ struct GgArgs {
     float* colsum_ws;          // optional [nclass * m-tiles][Nout]: per-tile column sums of the stored values
     int nclass;
     int dephase;               // 8-wave kernels: the two waves of a SIMD stage at different points of the step
+    int sh_thw, sh_tw;         // log2(TH*TW), log2(TW) when those are powers of two, else -1 (row index -> (n, a, b) by shifts)
+    unsigned long long* stamps; // debug (rbvae_dbg_gg_stamps): [workgroup][8] phase time stamps (100 MHz), or null
     TapClass cls[4];
 };
 
@@ -96,6 +98,43 @@ template <> __device__ __forceinline__ bool elem_pos<bf16_t>(const unsigned char
 
 constexpr int GG_BM = 128;
 
+// build-time experiment switches (tools/ab_variants.sh builds one library per setting for same-box A/B runs).
+// Measured on the bench step, same GPU, 3 runs each: both cut the workgroup's setup / store phases by 0.3-0.9 us
+// in the phase stamps yet left the step 0.5-1 % SLOWER (more live registers around the K loop), so both are off.
+#ifndef GG_BIAS_LDS
+#define GG_BIAS_LDS 0      // 1: stage the tile's bias in LDS during the table setup
+#endif
+#ifndef GG_PREFETCH
+#define GG_PREFETCH 0      // 1: fetch the store phase's gate / residual chunks before the register phase
+#endif
+
+// tile row m -> (image n, grid row a, grid column b); integer divisions only when the grid is not a power of two
+// (the setup phases of a workgroup were ~2 us of mostly these divisions, against a 1.6 us single-slice K loop)
+__device__ __forceinline__ void split_row(const GgArgs& p, int m, int& n, int& a, int& b) {
+    int rem;
+    if (p.sh_thw >= 0) { n = m >> p.sh_thw; rem = m & ((1 << p.sh_thw) - 1); }
+    else { n = m / (p.TH * p.TW); rem = m - n * (p.TH * p.TW); }
+    if (p.sh_tw >= 0) { a = rem >> p.sh_tw; b = rem & ((1 << p.sh_tw) - 1); }
+    else { a = rem / p.TW; b = rem - a * p.TW; }
+}
+
+// phase stamp of a workgroup (wave 0 writes; s_memrealtime: constant 100 MHz).  Compiled in only with
+// -DGG_STAMPS=1 (tools/ab_variants.sh): the conditional stores cost the product kernel ~2 % (they fence the
+// compiler's scheduling of the epilogue loads).
+#ifndef GG_STAMPS
+#define GG_STAMPS 0
+#endif
+#if !GG_STAMPS
+#define GG_STAMP(slot) do {} while (0)
+#else
+#define GG_STAMP(slot)                                                                                     \
+    do {                                                                                                    \
+        if (p.stamps && threadIdx.x == 0)                                                                   \
+            p.stamps[((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 8 + (slot)] = \
+                wall_clock64();                                          \
+    } while (0)
+#endif
+
 template <int N> __device__ __forceinline__ void wait_vmcnt_barrier() {
     // counted wait (LDS-DMA of the slice about to be read has landed for THIS wave), then the
     // workgroup barrier; no vmcnt(0) drain, so younger slices stay in flight across the barrier
@@ -129,21 +168,26 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void gather_gemm_k(const GgArgs p)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     int* s_orow = (int*)(smem + RING);           // [128]
     int* s_tap = s_orow + GG_BM;                 // [16][4]: widx, dh, dw of this class
+    float* s_bias = (float*)(s_tap + 64);        // [BN]: this tile's bias (0 without one), loaded while the tables are built
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave id, provably uniform (scalar LDS addressing)
+    GG_STAMP(0);
     const TapClass& tc = p.cls[blockIdx.z];
     const int Mc = p.Nimg * p.TH * p.TW;
     const int m0 = blockIdx.x * GG_BM, n0 = blockIdx.y * BN;
     const int ntaps = tc.ntaps;
 
     // output row of every tile row (for the store phase) and the class's tap table
+#if GG_BIAS_LDS
+    for (int i = tid; i < BN; i += THREADS) s_bias[i] = (p.bias && n0 + i < p.Nout) ? p.bias[n0 + i] : 0.f;
+#endif
     if (tid < GG_BM) {
         const int m = m0 + tid;
         int o = -1;
         if (m < Mc) {
-            const int n = m / (p.TH * p.TW), rem = m - n * (p.TH * p.TW);
-            const int a = rem / p.TW, b = rem - a * p.TW;
+            int n, a, b;
+            split_row(p, m, n, a, b);
             const int oh = a * p.so + tc.oh0, ow = b * p.so + tc.ow0;
             if (oh < p.OH && ow < p.OW) o = (n * p.OH + oh) * p.OW + ow;
         }
@@ -155,6 +199,7 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void gather_gemm_k(const GgArgs p)
         s_tap[j * 4 + 2] = tc.dw[j];
     }
     __syncthreads();
+    GG_STAMP(1);
 
     // staging roles: one LDS-DMA instruction moves 8 rows x 128 B; wave w issues rows
     // (w*A_INSTR+i)*8 .. +7 of A and (w*B_INSTR+i)*8 .. +7 of B
@@ -167,8 +212,7 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void gather_gemm_k(const GgArgs p)
         const int m = m0 + r;
         a_sw[i] = (unsigned)((schunk ^ ((r >> 1) & 7)) * 16);
         if (m < Mc) {
-            const int n = m / (p.TH * p.TW), rem = m - n * (p.TH * p.TW);
-            an[i] = n; aa[i] = rem / p.TW; ab[i] = rem - aa[i] * p.TW;
+            split_row(p, m, an[i], aa[i], ab[i]);
         } else {
             an[i] = -1; aa[i] = 0; ab[i] = 0;
         }
@@ -290,6 +334,7 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void gather_gemm_k(const GgArgs p)
     using Younger = std::integral_constant<int, RPH>;
     using None = std::integral_constant<int, 0>;
     u32x4_t fa0[MT], fb0[NTW], fa1[MT], fb1[NTW];
+    GG_STAMP(2);
     if constexpr (GG_NS == 1) {
         for (int s = 0; s < nsteps; ++s) {
             if (s > 0) __syncthreads();              // everyone is done reading the single buffer
@@ -320,7 +365,8 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void gather_gemm_k(const GgArgs p)
         // wave for ~60-180 cycles, so the two take turns: the low wave stages the next slice right after the
         // barrier while its partner multiplies, the high wave stages after that MFMA group.
         const bool late = WAVES == 8 && w >= 4 && p.dephase;
-        for (int s = 0; s < nsteps; ++s) {
+        // every step but the last: multiply slice s while slice s+1's first half is read behind it
+        for (int s = 0; s + 1 < nsteps; ++s) {
             const unsigned lcur = lds0 + cbuf * STAGE;
             cbuf = (cbuf + 1 == GG_NS) ? 0 : cbuf + 1;
             read_half(lcur, 1, fa1, fb1);
@@ -329,33 +375,71 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void gather_gemm_k(const GgArgs p)
             mma_half(fa0, fb0);
             __builtin_amdgcn_sched_barrier(0);
             landed(None{}, fa1, fb1);                    // issued a whole MFMA group ago (one wait site per set)
-            if (s + 1 < nsteps) {
-                // slice s+1 landed (GG_NS-2 younger ones may stay in flight); after the barrier every wave
-                // holds both halves of slice s in registers, so its buffer can be refilled
-                if (GG_NS > 2 && nsteps - s - 2 >= GG_NS - 2) wait_vmcnt_barrier<(GG_NS > 2 ? GG_NS - 2 : 0) * LOADS>();
-                else wait_vmcnt_barrier<0>();
-                if (!late && s + GG_NS < nsteps) stage_next();
-                read_half(lds0 + cbuf * STAGE, 0, fa0, fb0);
-            }
+            // slice s+1 landed (GG_NS-2 younger ones may stay in flight); after the barrier every wave
+            // holds both halves of slice s in registers, so its buffer can be refilled
+            if (GG_NS > 2 && nsteps - s - 2 >= GG_NS - 2) wait_vmcnt_barrier<(GG_NS > 2 ? GG_NS - 2 : 0) * LOADS>();
+            else wait_vmcnt_barrier<0>();
+            if (!late && s + GG_NS < nsteps) stage_next();
+            read_half(lds0 + cbuf * STAGE, 0, fa0, fb0);
             __builtin_amdgcn_sched_barrier(0);
             mma_half(fa1, fb1);
             __builtin_amdgcn_sched_barrier(0);
             if (late && s + GG_NS < nsteps) stage_next();
         }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // nothing is in flight here; keeps the ISA check linear
+        // the last step reads nothing ahead: when it is done no LDS read is in flight (the loop above is peeled
+        // this way so that the build's ISA check can see that on every path, without a catch-all wait)
+        {
+            const unsigned lcur = lds0 + cbuf * STAGE;
+            read_half(lcur, 1, fa1, fb1);
+            landed(Younger{}, fa0, fb0);
+            __builtin_amdgcn_sched_barrier(0);
+            mma_half(fa0, fb0);
+            __builtin_amdgcn_sched_barrier(0);
+            landed(None{}, fa1, fb1);
+            __builtin_amdgcn_sched_barrier(0);
+            mma_half(fa1, fb1);
+        }
     }
+    GG_STAMP(3);
     __syncthreads();
+
+    // ---- store roles, and the global operands of the store phase (saved-activation gate, residual) fetched now,
+    // so their latency runs under the register phase and the LDS round trip instead of once per store pass
+    constexpr int CPR = BN / EC;                 // 16-B chunks per tile row
+    constexpr int RL = THREADS / CPR;            // row lanes of the store phase
+    constexpr int ITERS = GG_BM / RL;            // store passes: pass `it` handles tile row it * RL + rl
+    constexpr bool PREFETCH = GG_PREFETCH && ITERS <= 8;
+    const int sch = tid % CPR, rl = tid / CPR;
+    const int scol = n0 + sch * EC;
+    int orow_[ITERS];
+    u32x4_t gv[PREFETCH ? ITERS : 1], av[PREFETCH ? ITERS : 1];
+#pragma unroll
+    for (int it = 0; it < ITERS; ++it) {
+        const int o = s_orow[it * RL + rl];
+        orow_[it] = scol < p.Nout ? o : -1;
+        if constexpr (PREFETCH) {
+            const size_t off = ((size_t)(orow_[it] < 0 ? 0 : orow_[it]) * p.ldo + (orow_[it] < 0 ? 0 : scol)) * ES;
+            if (p.gate) gv[it] = *(const u32x4_t*)(p.gate + off);
+            if (p.addend) av[it] = *(const u32x4_t*)(p.addend + off);
+        }
+    }
 
     // ---- epilogue, register phase: bias, relu, scale; lane owns pixel fi, channels 4*fg..+3
     unsigned char* tile = smem;
 #pragma unroll
     for (int nt = 0; nt < NTW; ++nt) {
         const int cb = (wc * NTW + nt) * 16 + 4 * fg;        // tile-local channel
+#if GG_BIAS_LDS
+        const float4 b4 = *(const float4*)(s_bias + cb);
+        const float bz[4] = {b4.x, b4.y, b4.z, b4.w};
+#else
         float bz[4] = {0.f, 0.f, 0.f, 0.f};
         if (p.bias && n0 + cb < p.Nout) {
             const float4 b4 = *(const float4*)(p.bias + n0 + cb);
             bz[0] = b4.x; bz[1] = b4.y; bz[2] = b4.z; bz[3] = b4.w;
         }
+        (void)s_bias;
+#endif
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
             const int row = (wr * MT + mt) * 16 + fi;
@@ -378,60 +462,64 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void gather_gemm_k(const GgArgs p)
         }
     }
     __syncthreads();
+    GG_STAMP(4);
 
     // ---- store phase: whole 16-B chunks of NHWC rows; dropout / gate zeroing happens here
-    constexpr int CPR = BN / EC;
-    constexpr int RL = THREADS / CPR;            // row lanes of the store phase
     float csum[EC];
 #pragma unroll
     for (int e = 0; e < EC; ++e) csum[e] = 0.f;
     DropKey dkey{0u, 0u};
     if (p.drop_mode == 1) dkey = drop_key(p.seed + (p.seed_dev ? p.seed_dev[0] * 0x9E3779B97F4A7C15ull : 0ull));
-    for (int idx = tid; idx < GG_BM * CPR; idx += THREADS) {
-        const int row = idx / CPR, ch = idx - row * CPR;     // ch == tid % CPR on every pass
-        const int orow = s_orow[row];
-        const int col = n0 + ch * EC;
-        if (orow < 0 || col >= p.Nout) continue;
-        u32x4_t val = *(const u32x4_t*)(tile + row * PITCH + ch * 16);
-        T* ev = (T*)&val;
-        if (p.drop_mode == 1) {
-            const unsigned run = drop_run(dkey, (unsigned long long)orow * p.Nout + col);
-            const unsigned dm = drop_chunk_mask<EC>(run, p.drop_thresh >> 16);
 #pragma unroll
-            for (int e = 0; e < EC; ++e)
-                if ((dm >> e) & 1u) ev[e] = 0;
-        } else if (p.drop_mode == 2) {
-            const unsigned char* mk = p.mask + (size_t)orow * p.Nout + col;
+    for (int it = 0; it < ITERS; ++it) {
+        const int row = it * RL + rl;
+        const int orow = orow_[it];
+        if (orow >= 0) {
+            const int col = scol;
+            u32x4_t val = *(const u32x4_t*)(tile + row * PITCH + sch * 16);
+            T* ev = (T*)&val;
+            if (p.drop_mode == 1) {
+                const unsigned run = drop_run(dkey, (unsigned long long)orow * p.Nout + col);
+                const unsigned dm = drop_chunk_mask<EC>(run, p.drop_thresh >> 16);
 #pragma unroll
-            for (int e = 0; e < EC; ++e)
-                if (!mk[e]) ev[e] = 0;
-        }
-        if (p.addend) {
-            const u32x4_t av = *(const u32x4_t*)(p.addend + ((size_t)orow * p.ldo + col) * ES);
-            const T* ae = (const T*)&av;
+                for (int e = 0; e < EC; ++e)
+                    if ((dm >> e) & 1u) ev[e] = 0;
+            } else if (p.drop_mode == 2) {
+                const unsigned char* mk = p.mask + (size_t)orow * p.Nout + col;
 #pragma unroll
-            for (int e = 0; e < EC; ++e) Elem<T>::store(ev + e, Elem<T>::load(ev + e) + Elem<T>::load(ae + e));
-        }
-        if (p.gate) {
-            const unsigned char* gp = p.gate + ((size_t)orow * p.ldo + col) * ES;
-            const u32x4_t gv = *(const u32x4_t*)gp;
+                for (int e = 0; e < EC; ++e)
+                    if (!mk[e]) ev[e] = 0;
+            }
+            if (p.addend) {
+                u32x4_t a4;
+                if constexpr (PREFETCH) a4 = av[it];
+                else a4 = *(const u32x4_t*)(p.addend + ((size_t)orow * p.ldo + col) * ES);
+                const T* ae = (const T*)&a4;
 #pragma unroll
-            for (int e = 0; e < EC; ++e)
-                if (!elem_pos<T>((const unsigned char*)&gv, e)) ev[e] = 0;
-        }
-        *(u32x4_t*)(p.Out + ((size_t)orow * p.ldo + col) * ES) = val;
-        if (p.colsum_ws) {
+                for (int e = 0; e < EC; ++e) Elem<T>::store(ev + e, Elem<T>::load(ev + e) + Elem<T>::load(ae + e));
+            }
+            if (p.gate) {
+                u32x4_t g4;
+                if constexpr (PREFETCH) g4 = gv[it];
+                else g4 = *(const u32x4_t*)(p.gate + ((size_t)orow * p.ldo + col) * ES);
 #pragma unroll
-            for (int e = 0; e < EC; ++e) csum[e] += Elem<T>::load(ev + e);
+                for (int e = 0; e < EC; ++e)
+                    if (!elem_pos<T>((const unsigned char*)&g4, e)) ev[e] = 0;
+            }
+            *(u32x4_t*)(p.Out + ((size_t)orow * p.ldo + col) * ES) = val;
+            if (p.colsum_ws) {
+#pragma unroll
+                for (int e = 0; e < EC; ++e) csum[e] += Elem<T>::load(ev + e);
+            }
         }
     }
+    GG_STAMP(5);
     if (p.colsum_ws) {
         // bias gradient: column sums of this tile's stored rows, reduced over the row lanes in LDS
         __syncthreads();
         float* red = (float*)smem;                     // [RL][BN]
-        const int rl = tid / CPR, ch = tid - rl * CPR;
 #pragma unroll
-        for (int e = 0; e < EC; ++e) red[rl * BN + ch * EC + e] = csum[e];
+        for (int e = 0; e < EC; ++e) red[rl * BN + sch * EC + e] = csum[e];
         __syncthreads();
         if (tid < BN && n0 + tid < p.Nout) {
             float t = 0.f;
@@ -440,6 +528,12 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void gather_gemm_k(const GgArgs p)
             p.colsum_ws[((size_t)blockIdx.z * gridDim.x + blockIdx.x) * p.Nout + n0 + tid] = t;
         }
     }
+#if GG_STAMPS
+    if (p.stamps) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's stores acknowledged
+        GG_STAMP(6);
+    }
+#endif
 }
 
 template <typename T, int NT, int WAVES, int NS, int OCC = 1>
@@ -449,7 +543,7 @@ static int launch_gg(const GgArgs& a, hipStream_t st) {
     const int Mc = a.Nimg * a.TH * a.TW;
     const size_t ring = (size_t)NS * (GG_BM * 128 + BN * 128);
     const size_t tile = (size_t)GG_BM * (BN * ES + 16);
-    const size_t lds = (ring > tile ? ring : tile) + GG_BM * sizeof(int) + 64 * sizeof(int);
+    const size_t lds = (ring > tile ? ring : tile) + GG_BM * sizeof(int) + 64 * sizeof(int) + BN * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
         hipFuncSetAttribute((const void*)gather_gemm_k<T, NT, WAVES, NS, OCC>, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -489,6 +583,14 @@ static int dispatch_gg(const GgArgs& a, hipStream_t st, int max_steps) {
 
 using namespace rbvae;
 
+static unsigned long long* g_gg_stamps = nullptr;
+/* debug: every later rbvae_gather_gemm launch writes 8 phase stamps per workgroup into buf (null = off) */
+extern "C" int rbvae_dbg_gg_stamps(unsigned long long* buf, void* stream) {
+    (void)stream;
+    g_gg_stamps = buf;
+    return RBVAE_OK;
+}
+
 extern "C" int rbvae_gather_gemm(int dtype, const void* A, const void* W, void* Out, const float* bias,
                                  const void* gate, const void* mask, const void* addend, const void* zero_page, int Nimg, int IH,
                                  int IW, int TH, int TW, int sa, int OH, int OW, int so, int Kc, int Nout, int lda,
@@ -521,6 +623,10 @@ extern "C" int rbvae_gather_gemm(int dtype, const void* A, const void* W, void* 
     a.nclass = nclass;
     static const int dephase = getenv("RBVAE_GG_DEPHASE") ? atoi(getenv("RBVAE_GG_DEPHASE")) : 1;
     a.dephase = dephase;
+    a.stamps = g_gg_stamps;
+    auto log2_or_neg = [](int v) { int s = 0; while ((1 << s) < v) ++s; return (1 << s) == v ? s : -1; };
+    a.sh_thw = log2_or_neg(TH * TW);
+    a.sh_tw = log2_or_neg(TW);
     // class_desc (host ints): per class [ntaps, oh0, ow0, then ntaps x (widx, dh, dw)], classes back to back
     const int* d = class_desc;
     for (int c = 0; c < nclass; ++c) {
