@@ -235,6 +235,12 @@ class Engine:
         import os
         self.overlap = os.environ.get("RBVAE_OVERLAP", "1") == "1"
         self.pack_late_split = os.environ.get("RBVAE_PACK_LATE", "0") == "1"
+        # RBVAE_STREAM_GEMM=1 sends the K = 64 products of the 3/4-channel ends to the row-streaming kernel
+        # (rbvae_stream_gemm) instead of the tiled gather GEMM.  Bit-identical results; measured on the bench shapes
+        # (tools/abl_stream.py): conv1 forward 17.5 -> 15.4-16.6 us, last-deconv backward (gate + column sums)
+        # 19.3 -> 27 us, step 0.597 -> 0.603 ms -- both kernels are bound by the per-element epilogue ALU work,
+        # not by HBM -- so it stays off.
+        self.stream_gemm = os.environ.get("RBVAE_STREAM_GEMM", "0") == "1"
         self._alloc_packed()
 
     # ---- packed weights -------------------------------------------------------
@@ -362,6 +368,17 @@ class Engine:
         """bias_grad: f32 [nout] tensor that receives the column sums of the stored output (a reduce job
         over the kernel's per-tile partial sums, run with the other jobs at the end of backward)."""
         seed_dev = self.seed_dev
+        if (self.stream_gemm and self.dt == BF16 and cls_key == "one" and kc == 64 and lda == 64 and nout <= 256
+                and nout % 8 == 0 and nimg >= 8192 and ih * iw * th * tw * oh * ow == 1 and mask is None
+                and drop_mode != 2 and colsum_ws is None):
+            ws = None
+            if bias_grad is not None:
+                nb = L.query("rbvae_stream_gemm_blocks", nimg)
+                ws = self._buf(("colsum_sg", tag), nb * nout)
+                self._jobs.add(JOB_ROWS, ws, bias_grad, (1, 1, nout), (0, 0, 1), nslab=nb, slab=nout)
+            L.call("rbvae_stream_gemm", A, W, out, bias, gate, nimg, nout, ldo, relu, drop_mode, float(drop_p),
+                   float(scale), int(seed), seed_dev, ws)
+            return
         if cls_key == "one":
             desc, ncls = self._desc("one", ONE_TAP), 1
         elif cls_key == "conv":

@@ -34,11 +34,11 @@ def from_rows(r, N, H, W):
 
 
 def gemm(sfv, dt, A, Wp, out, bias, gate, mask, geom, kc, nout, taps, desc, ncls, relu=0, drop_mode=0, drop_p=0.0,
-         scale=1.0, seed=0):
+         scale=1.0, seed=0, colsum_ws=None):
     zero = torch.zeros(256, dtype=torch.uint8, device="cuda")
     d = (ctypes.c_int * len(desc))(*desc)
     sfv._lib.call("rbvae_gather_gemm", dt, A, Wp, out, bias, gate, mask, None, zero, *geom, kc, nout, A.shape[1],
-                  out.shape[1], taps, ncls, ctypes.addressof(d), relu, drop_mode, drop_p, scale, seed, None, None)
+                  out.shape[1], taps, ncls, ctypes.addressof(d), relu, drop_mode, drop_p, scale, seed, None, colsum_ws)
 
 
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
@@ -331,3 +331,29 @@ def test_binarize_parts_and_combine(sfv):
     sfv._lib.call("rbvae_adam_step", wa, gr, ma, va, n, 1e-3, 0.9, 0.999, 1e-8, 5, 1.0, None, None)
     sfv._lib.call("rbvae_adam_step", wb, gr, mb, vb, n, 1e-3, 0.9, 0.999, 1e-8, 0, 1.0, None, hyper)
     np.testing.assert_allclose(wb.cpu().numpy(), wa.cpu().numpy(), atol=1e-7, rtol=0)
+
+
+@pytest.mark.parametrize("M,Nout", [(1000, 256), (4096, 64), (777, 136)])
+def test_stream_gemm_equals_gather_gemm(sfv, M, Nout):
+    """rbvae_stream_gemm (row-streaming, resident weights) gives the tiled gather GEMM's result bit for bit:
+    same MFMA chain per element, same keyed dropout mask, same gate; column sums to f32 rounding."""
+    g = torch.Generator().manual_seed(18)
+    K = 64
+    A = torch.randn(M, K, generator=g).bfloat16().cuda()
+    Wt = (torch.randn(Nout, K, generator=g) / 8).bfloat16().cuda()
+    bias = torch.randn(Nout, generator=g).cuda()
+    gate = torch.randn(M, Nout, generator=g).bfloat16().cuda()
+    for use_gate, drop, relu, use_bias in ((False, 1, 1, True), (True, 0, 0, False), (True, 1, 1, True)):
+        ref = torch.empty(M, Nout, dtype=torch.bfloat16, device="cuda")
+        out = torch.full((M, Nout), 7.0, dtype=torch.bfloat16, device="cuda")
+        mt = -(-M // 128)
+        ws_ref = torch.zeros(mt, Nout, device="cuda")
+        gemm(sfv, DT["bf16"][0], A, Wt, ref, bias if use_bias else None, gate if use_gate else None, None,
+             (M, 1, 1, 1, 1, 1, 1, 1, 1), K, Nout, 1, [1, 0, 0, 0, 0, 0], 1, relu=relu, drop_mode=drop, drop_p=0.2,
+             scale=1.25, seed=23, colsum_ws=ws_ref)
+        nb = sfv._lib.query("rbvae_stream_gemm_blocks", M)
+        ws = torch.zeros(nb, Nout, device="cuda")
+        sfv._lib.call("rbvae_stream_gemm", A, Wt, out, bias if use_bias else None, gate if use_gate else None, M, Nout,
+                      Nout, relu, drop, 0.2, 1.25, 23, None, ws)
+        assert torch.equal(out, ref), (use_gate, drop)
+        np.testing.assert_allclose(ws.sum(0).cpu().numpy(), ws_ref.sum(0).cpu().numpy(), rtol=1e-5, atol=1e-3)
