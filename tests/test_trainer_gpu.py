@@ -95,3 +95,61 @@ def test_input_buffer_is_read_in_place():
             losses = tr.step(x, 0.9, U=U).clone()
         res.append((losses, m._flat.clone()))
     assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+
+
+# The reference's own sweeps: latent_dim 25 / 50 / 75 / 100, T = 5 / 9 / 17 states, batches of
+# odd size, native 88x160 frames whose 11x20 bottleneck is not a power of two.  One fused step (exact-f32 mode,
+# eval: no dropout on either side) against the oracle's step: losses 2e-4, gradients 2e-3 relative L2.
+@pytest.mark.parametrize("variant,in_ch,B,T,Ld,hw", [
+    ("percep", 4, 3, 5, 25, (24, 40)),
+    ("percep", 4, 1, 9, 50, (16, 16)),
+    ("percep", 4, 2, 17, 100, (8, 16)),
+    ("percep", 4, 1, 2, 75, (88, 160)),
+    ("contrastive", 3, 2, 5, 50, (32, 24)),
+    ("triplet", 3, 3, 9, 16, (16, 16)),
+])
+def test_fused_step_parameter_ranges(variant, in_ch, B, T, Ld, hw):
+    import sfv_amd as sfv
+    from importlib import import_module
+    FusedTrainer = import_module("symbols-from-video_amd.trainer").FusedTrainer
+    torch.manual_seed(21)
+    m = sfv.Seq2SeqBinaryVAE(in_ch, in_ch, Ld, Ld, variant=variant, input_hw=hw, compute_dtype="f32")
+    params = {k: v.clone().requires_grad_() for k, v in m.state_dict().items()}
+    m = m.cuda().eval()
+    g = torch.Generator().manual_seed(22)
+    item = torch.rand(B, 2, T, in_ch, *hw, generator=g)
+    U = torch.rand(2, B * T, Ld, generator=g)
+    tau, r, p, alpha, beta, margin = 0.6, 0.3, 0.1, 0.7, 0.4, 0.2
+    hist, grads = _oracle_step(variant, params, item, [U[0], U[1]], tau, r, p, alpha, beta, margin, 1)
+    tr = FusedTrainer(m, lr=1e-3, alpha=alpha, beta_kl=beta, bernoulli_p=p, noise_ratio=r, margin=margin,
+                      device_noise=False, use_graph=False)
+    losses = tr.step(item.cuda(), tau, U=U.cuda()).cpu().tolist()
+    for got, k in zip(losses, ("total", "recon", "kl", "pair")):
+        assert abs(got - hist[0][k]) < 2e-4 * max(1.0, abs(hist[0][k])), (k, got, hist[0][k])
+    lay = tr.eng.layout
+    for k in lay.names:
+        gr = lay.view(tr.gflat, k).cpu().double().reshape(-1)
+        rf = grads[k].double().reshape(-1)
+        assert float((gr - rf).norm()) <= 2e-3 * max(float(rf.norm()), 1e-7), k
+
+
+def test_bf16_graph_steps_track_f32_steps():
+    """The bench configuration in small: bf16 storage, dropout on, device-side noise, HIP-graph replay.  Twenty
+    steps must keep the loss finite, close to the exact-f32 trainer fed the same noise-free setting, and going down."""
+    import sfv_amd as sfv
+    from importlib import import_module
+    FusedTrainer = import_module("symbols-from-video_amd.trainer").FusedTrainer
+    B, T, Ld, hw = 4, 8, 32, (32, 32)
+    g = torch.Generator().manual_seed(31)
+    item = torch.randn(B, 2, T, 4, *hw, generator=g).cuda()
+    U = torch.rand(2, B * T, Ld, generator=g).cuda()
+    curves = {}
+    for dt in ("f32", "bf16"):
+        torch.manual_seed(30)
+        m = sfv.Seq2SeqBinaryVAE(4, 4, Ld, Ld, variant="percep", input_hw=hw, compute_dtype=dt).cuda().eval()
+        tr = FusedTrainer(m, lr=1e-3, alpha=1.0, beta_kl=1.0, bernoulli_p=0.1, noise_ratio=0.1, device_noise=False,
+                          use_graph=True)
+        curves[dt] = [tr.step(item, 0.7, U=U)[0].item() for _ in range(20)]
+    f, b = curves["f32"], curves["bf16"]
+    assert all(np.isfinite(b)) and b[-1] < b[0]
+    assert max(abs(x - y) / abs(x) for x, y in zip(f, b)) < 2e-2, (f[-1], b[-1])
