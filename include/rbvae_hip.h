@@ -219,6 +219,10 @@ int rbvae_sigmoid_bwd_nhwc(const float* g_nchw, const float* xr_nchw, float* dpr
  * out[M][Nc] f32 = A[M][K] * B[Nc][K]^T + bias. */
 int rbvae_skinny_linear(int dtype, const void* A, const void* B, const float* bias, float* out, int M, int Nc,
                         int K, int lda, int ldb, int ldo, void* stream);
+/* K split over `ksplit` workgroup groups (the one-group form keeps 32 CUs busy at M = 256): slab q =
+ * out_parts + q*M*ldo holds the partial product over K range q (+ bias in slab 0); the consumer sums the slabs. */
+int rbvae_skinny_linear_parts(int dtype, const void* A, const void* B, const float* bias, float* out_parts, int M,
+                              int Nc, int K, int lda, int ldb, int ldo, int ksplit, void* stream);
 
 /* ---- stacked LSTM (percep_RBVAE_model.py:94-122) ------------------------------------
  * wblk: per layer w_ih[4L][L], w_hh[4L][L], b_ih[4L], b_hh[4L] (the reference's registration
@@ -229,6 +233,14 @@ int rbvae_lstm_fwd(const float* wblk, const float* wT, float* hs_all, float* hpr
                    int T, int L, int layers, void* stream);
 int rbvae_lstm_bwd(const float* wblk, const float* acts, const float* cs, const float* g_top, float* dG, float* dx,
                    int S, int T, int L, int layers, void* stream);
+/* The same with the stack input (forward) / the top-layer gradient (backward) given as `nparts` K-split slabs of
+ * the fc product that feeds them (rbvae_skinny_linear_parts; slab q at + q*part_stride floats): summed in slab
+ * order inside the kernel's prologue; the forward also writes the sum to slot 0 of hs_all.  Wavefront kernel
+ * only (L <= 32, layers * roundup64(4L) <= 1024), else RBVAE_E_INVALID. */
+int rbvae_lstm_fwd_parts(const float* wblk, const float* wT, float* hs_all, float* hprev, float* acts, float* cs, int S,
+                         int T, int L, int layers, const float* in_parts, int nparts, long part_stride, void* stream);
+int rbvae_lstm_bwd_parts(const float* wblk, const float* acts, const float* cs, const float* g_top_parts, int nparts,
+                         long part_stride, float* dG, float* dx, int S, int T, int L, int layers, void* stream);
 int rbvae_lstm_wgrad(const float* dG, const float* hs_all, const float* hprev, float* gblk, int S, int T, int L,
                      int layers, int accumulate, void* stream);
 /* the same for two stacks of equal shape (the encoder and decoder LSTMs) in one launch */

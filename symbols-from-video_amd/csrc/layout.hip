@@ -268,7 +268,14 @@ __global__ void sigmoid_bwd_nhwc_k(const float* __restrict__ g, const float* __r
 template <typename T>
 __global__ __launch_bounds__(512) void skinny_linear_k(const T* __restrict__ A, const T* __restrict__ B,
                                                        const float* __restrict__ bias, float* __restrict__ out,
-                                                       int M, int Nc, int K, int lda, int ldb, int ldo) {
+                                                       int M, int Nc, int K, int lda, int ldb, int ldo, int kper) {
+    // gridDim.z > 1: K split over workgroups, part z covers [z*kper, (z+1)*kper) and writes its own [M][ldo] slab
+    // (the bias goes into part 0); the consumer sums the slabs in order (rbvae_lstm_fwd_parts / _bwd_parts)
+    const int kbeg = blockIdx.z * kper;
+    A += kbeg; B += kbeg;
+    K = min(K - kbeg, kper);
+    out += (size_t)blockIdx.z * M * ldo;
+    if (blockIdx.z) bias = nullptr;
     constexpr int ES = sizeof(T);
     constexpr int KS = (ES == 2) ? 32 : 16;      // k per step (16 B per lane per operand)
     constexpr int EC = 16 / ES;
@@ -604,9 +611,9 @@ int rbvae_sigmoid_bwd_nhwc(const float* g_nchw, const float* xr_nchw, float* dpr
     return RBVAE_OK;
 }
 
-int rbvae_skinny_linear(int dtype, const void* A, const void* B, const float* bias, float* out, int M, int Nc,
-                        int K, int lda, int ldb, int ldo, void* stream) {
-    RBVAE_CHECK_ARG(A && B && out && M > 0 && Nc > 0 && K > 0, "skinny_linear: bad arguments");
+static int skinny_impl(int dtype, const void* A, const void* B, const float* bias, float* out, int M, int Nc,
+                       int K, int lda, int ldb, int ldo, int ksplit, void* stream) {
+    RBVAE_CHECK_ARG(A && B && out && M > 0 && Nc > 0 && K > 0 && ksplit >= 1, "skinny_linear: bad arguments");
     RBVAE_CHECK_ARG(dtype == RBVAE_F32 || dtype == RBVAE_BF16, "skinny_linear: dtype %d", dtype);
     const int ES = dtype == RBVAE_F32 ? 4 : 2;
     const int KS = dtype == RBVAE_F32 ? 16 : 32;
@@ -614,15 +621,27 @@ int rbvae_skinny_linear(int dtype, const void* A, const void* B, const float* bi
     RBVAE_CHECK_ARG((lda * ES) % 16 == 0 && (ldb * ES) % 16 == 0 && lda >= K && ldb >= K && ldo >= Nc,
                     "skinny_linear: leading dimensions");
     RBVAE_CHECK_ARG(((uintptr_t)A | (uintptr_t)B) % 16 == 0, "skinny_linear: operands must be 16-byte aligned");
-    dim3 grid(cdiv(M, 16), cdiv(Nc, 16));
+    RBVAE_CHECK_ARG(K % (ksplit * KS) == 0, "skinny_linear: K=%d not divisible into %d parts of whole %d-steps", K, ksplit, KS);
+    dim3 grid(cdiv(M, 16), cdiv(Nc, 16), ksplit);
+    const int kper = K / ksplit;
     if (dtype == RBVAE_F32)
         hipLaunchKernelGGL(skinny_linear_k<float>, grid, dim3(512), 0, (hipStream_t)stream, (const float*)A,
-                           (const float*)B, bias, out, M, Nc, K, lda, ldb, ldo);
+                           (const float*)B, bias, out, M, Nc, K, lda, ldb, ldo, kper);
     else
         hipLaunchKernelGGL(skinny_linear_k<bf16_t>, grid, dim3(512), 0, (hipStream_t)stream, (const bf16_t*)A,
-                           (const bf16_t*)B, bias, out, M, Nc, K, lda, ldb, ldo);
+                           (const bf16_t*)B, bias, out, M, Nc, K, lda, ldb, ldo, kper);
     RBVAE_CHECK_LAUNCH("skinny_linear");
     return RBVAE_OK;
+}
+
+int rbvae_skinny_linear(int dtype, const void* A, const void* B, const float* bias, float* out, int M, int Nc,
+                        int K, int lda, int ldb, int ldo, void* stream) {
+    return skinny_impl(dtype, A, B, bias, out, M, Nc, K, lda, ldb, ldo, 1, stream);
+}
+
+int rbvae_skinny_linear_parts(int dtype, const void* A, const void* B, const float* bias, float* out_parts, int M,
+                              int Nc, int K, int lda, int ldb, int ldo, int ksplit, void* stream) {
+    return skinny_impl(dtype, A, B, bias, out_parts, M, Nc, K, lda, ldb, ldo, ksplit, stream);
 }
 
 // hyper[0] = lr / (1 - b1^step), hyper[1] = sqrt(1 - b2^step) from a DEVICE step counter, which this

@@ -233,7 +233,8 @@ __global__ __launch_bounds__(1024) void lstm_fwd_wave_k(const float* __restrict_
                                                         float* __restrict__ hs_all,
                                                         float* __restrict__ hprev, float* __restrict__ acts,
                                                         float* __restrict__ cs, int S, int T, int L_, int layers,
-                                                        int G) {
+                                                        int G, const float* __restrict__ in_parts, int nparts,
+                                                        long part_stride) {
     const int L = EXACT ? LMAX : L_;
     extern __shared__ __attribute__((aligned(16))) float sm[];
     float* hbuf = sm;                               // [layers+1][T][L]
@@ -242,7 +243,19 @@ __global__ __launch_bounds__(1024) void lstm_fwd_wave_k(const float* __restrict_
     const int s = blockIdx.x;
     const bool row = j < 4 * L;
     const bool is_g = j >= 2 * L && j < 3 * L;      // the tanh gate
-    for (int i = threadIdx.x; i < T * L; i += blockDim.x) hbuf[i] = hs_all[((long)s * T) * L + i];
+    if (in_parts) {
+        // the stack input arrives as K-split slabs of the fc product (rbvae_skinny_linear_parts): summed here in
+        // slab order and written to slot 0, where the backward pass expects the input
+        for (int i = threadIdx.x; i < T * L; i += blockDim.x) {
+            const long o = ((long)s * T) * L + i;
+            float v = in_parts[o];
+            for (int q = 1; q < nparts; ++q) v += in_parts[q * part_stride + o];
+            hbuf[i] = v;
+            hs_all[o] = v;
+        }
+    } else {
+        for (int i = threadIdx.x; i < T * L; i += blockDim.x) hbuf[i] = hs_all[((long)s * T) * L + i];
+    }
     const float* wl = wblk + l * lstm_layer_floats(L);
     float wih[LMAX], whh[LMAX];
     float bsum = 0.f;
@@ -319,7 +332,7 @@ template <int LMAX, bool EXACT>
 __global__ __launch_bounds__(1024) void lstm_bwd_wave_k(const float* __restrict__ wblk, const float* __restrict__ acts,
                                                         const float* __restrict__ cs, const float* __restrict__ g_top,
                                                         float* __restrict__ dG, float* __restrict__ dx, int S, int T,
-                                                        int L_, int layers, int G) {
+                                                        int L_, int layers, int G, int nparts, long part_stride) {
     const int L = EXACT ? LMAX : L_;
     extern __shared__ float sm[];
     float* gtop = sm;                              // [T][L]
@@ -344,6 +357,14 @@ __global__ __launch_bounds__(1024) void lstm_bwd_wave_k(const float* __restrict_
                 int i = base + u * blockDim.x;
                 i = i < ntot ? i : ntot - 1;
                 const float* src;
+                if (i < n0 && nparts > 1) {
+                    // g_top as K-split slabs (rbvae_skinny_linear_parts): summed in slab order
+                    const float* gp = g_top + ((long)s * T) * L + i;
+                    float a = gp[0];
+                    for (int q = 1; q < nparts; ++q) a += gp[q * part_stride];
+                    v[u] = a;
+                    continue;
+                }
                 if (i < n0) src = g_top + ((long)s * T) * L + i;
                 else if (i < n1) { const int ll = (i - n0) / na, r = (i - n0) - ll * na; src = acts + (((long)ll * S + s) * T) * 4 * L + r; }
                 else { const int ll = (i - n1) / n0, r = (i - n1) - ll * n0; src = cs + (((long)ll * S + s) * T) * L + r; }
@@ -509,8 +530,8 @@ using namespace rbvae;
 
 extern "C" {
 
-int rbvae_lstm_fwd(const float* wblk, const float* wT, float* hs_all, float* hprev, float* acts, float* cs, int S,
-                   int T, int L, int layers, void* stream) {
+static int lstm_fwd_impl(const float* wblk, const float* wT, float* hs_all, float* hprev, float* acts, float* cs, int S,
+                         int T, int L, int layers, const float* in_parts, int nparts, long part_stride, void* stream) {
     RBVAE_CHECK_ARG(wblk && hs_all && S > 0 && T > 0 && L > 0 && layers > 0, "lstm_fwd: bad arguments");
     RBVAE_CHECK_ARG(L <= 128, "lstm_fwd: latent_dim %d > 128 is not supported", L);
     RBVAE_CHECK_ARG((acts == nullptr) == (cs == nullptr) && (acts == nullptr) == (hprev == nullptr),
@@ -524,16 +545,17 @@ int rbvae_lstm_fwd(const float* wblk, const float* wT, float* hs_all, float* hpr
     if (L <= 32 && layers * threads <= 1024 && wlds <= 64 * 1024) {
         if (L == 32)
             hipLaunchKernelGGL((lstm_fwd_wave_k<32, true, true>), dim3(S), dim3(layers * threads), wlds, st, wblk, wT,
-                               hs_all, hprev, acts, cs, S, T, L, layers, threads);
+                               hs_all, hprev, acts, cs, S, T, L, layers, threads, in_parts, nparts, part_stride);
         else if (L % 4 == 0)
             hipLaunchKernelGGL((lstm_fwd_wave_k<32, true, false>), dim3(S), dim3(layers * threads), wlds, st, wblk, wT,
-                               hs_all, hprev, acts, cs, S, T, L, layers, threads);
+                               hs_all, hprev, acts, cs, S, T, L, layers, threads, in_parts, nparts, part_stride);
         else
             hipLaunchKernelGGL((lstm_fwd_wave_k<32, false, false>), dim3(S), dim3(layers * threads), wlds, st, wblk, wT,
-                               hs_all, hprev, acts, cs, S, T, L, layers, threads);
+                               hs_all, hprev, acts, cs, S, T, L, layers, threads, in_parts, nparts, part_stride);
         RBVAE_CHECK_LAUNCH("lstm_fwd_wave");
         return RBVAE_OK;
     }
+    RBVAE_CHECK_ARG(!in_parts, "lstm_fwd_parts: only the wavefront kernel (L <= 32, layers * roundup64(4L) <= 1024) sums input slabs");
     if (L <= 32)
         hipLaunchKernelGGL(lstm_fwd_k<32>, dim3(S), dim3(threads), lds, st, wblk, hs_all, hprev, acts, cs, S, T, L, layers);
     else if (L <= 64)
@@ -544,8 +566,19 @@ int rbvae_lstm_fwd(const float* wblk, const float* wT, float* hs_all, float* hpr
     return RBVAE_OK;
 }
 
-int rbvae_lstm_bwd(const float* wblk, const float* acts, const float* cs, const float* g_top, float* dG, float* dx,
-                   int S, int T, int L, int layers, void* stream) {
+int rbvae_lstm_fwd(const float* wblk, const float* wT, float* hs_all, float* hprev, float* acts, float* cs, int S,
+                   int T, int L, int layers, void* stream) {
+    return lstm_fwd_impl(wblk, wT, hs_all, hprev, acts, cs, S, T, L, layers, nullptr, 1, 0, stream);
+}
+
+int rbvae_lstm_fwd_parts(const float* wblk, const float* wT, float* hs_all, float* hprev, float* acts, float* cs, int S,
+                         int T, int L, int layers, const float* in_parts, int nparts, long part_stride, void* stream) {
+    RBVAE_CHECK_ARG(in_parts && nparts >= 1 && part_stride >= (long)S * T * L, "lstm_fwd_parts: bad slabs");
+    return lstm_fwd_impl(wblk, wT, hs_all, hprev, acts, cs, S, T, L, layers, in_parts, nparts, part_stride, stream);
+}
+
+static int lstm_bwd_impl(const float* wblk, const float* acts, const float* cs, const float* g_top, float* dG, float* dx,
+                         int S, int T, int L, int layers, int nparts, long part_stride, void* stream) {
     RBVAE_CHECK_ARG(wblk && acts && cs && g_top && dG && dx && S > 0 && T > 0 && L > 0 && layers > 0,
                     "lstm_bwd: bad arguments");
     RBVAE_CHECK_ARG(L <= 128, "lstm_bwd: latent_dim %d > 128 is not supported", L);
@@ -557,13 +590,14 @@ int rbvae_lstm_bwd(const float* wblk, const float* acts, const float* cs, const 
     if (L <= 32 && layers * threads <= 1024 && wlds <= 64 * 1024) {
         if (L == 32)
             hipLaunchKernelGGL((lstm_bwd_wave_k<32, true>), dim3(S), dim3(layers * threads), wlds, st, wblk, acts, cs,
-                               g_top, dG, dx, S, T, L, layers, threads);
+                               g_top, dG, dx, S, T, L, layers, threads, nparts, part_stride);
         else
             hipLaunchKernelGGL((lstm_bwd_wave_k<32, false>), dim3(S), dim3(layers * threads), wlds, st, wblk, acts, cs,
-                               g_top, dG, dx, S, T, L, layers, threads);
+                               g_top, dG, dx, S, T, L, layers, threads, nparts, part_stride);
         RBVAE_CHECK_LAUNCH("lstm_bwd_wave");
         return RBVAE_OK;
     }
+    RBVAE_CHECK_ARG(nparts == 1, "lstm_bwd_parts: only the wavefront kernel (L <= 32, layers * roundup64(4L) <= 1024) sums gradient slabs");
     if (L <= 32)
         hipLaunchKernelGGL(lstm_bwd_k<32>, dim3(S), dim3(threads), lds, st, wblk, acts, cs, g_top, dG, dx, S, T, L, layers);
     else if (L <= 64)
@@ -572,6 +606,17 @@ int rbvae_lstm_bwd(const float* wblk, const float* acts, const float* cs, const 
         hipLaunchKernelGGL(lstm_bwd_k<0>, dim3(S), dim3(threads), lds, st, wblk, acts, cs, g_top, dG, dx, S, T, L, layers);
     RBVAE_CHECK_LAUNCH("lstm_bwd");
     return RBVAE_OK;
+}
+
+int rbvae_lstm_bwd(const float* wblk, const float* acts, const float* cs, const float* g_top, float* dG, float* dx,
+                   int S, int T, int L, int layers, void* stream) {
+    return lstm_bwd_impl(wblk, acts, cs, g_top, dG, dx, S, T, L, layers, 1, 0, stream);
+}
+
+int rbvae_lstm_bwd_parts(const float* wblk, const float* acts, const float* cs, const float* g_top_parts, int nparts,
+                         long part_stride, float* dG, float* dx, int S, int T, int L, int layers, void* stream) {
+    RBVAE_CHECK_ARG(nparts >= 1 && part_stride >= (long)S * T * L, "lstm_bwd_parts: bad slabs");
+    return lstm_bwd_impl(wblk, acts, cs, g_top_parts, dG, dx, S, T, L, layers, nparts, part_stride, stream);
 }
 
 static int launch_lstm_wgrad(const float* dG, const float* hs_all, const float* hprev, float* gblk, const float* dG2,

@@ -241,6 +241,13 @@ class Engine:
         # 19.3 -> 27 us, step 0.597 -> 0.603 ms -- both kernels are bound by the per-element epilogue ALU work,
         # not by HBM -- so it stays off.
         self.stream_gemm = os.environ.get("RBVAE_STREAM_GEMM", "0") == "1"
+        # The fc products on either side of the LSTM stacks (M = frames, 32 outputs, K = thousands) run K-split over
+        # 4x the workgroups, and the LSTM kernels sum the slabs while staging their input (RBVAE_FC_SPLIT=1: one
+        # group, 32 CUs busy at 256 frames).  Needs the wavefront LSTM kernels (latent <= 32).
+        ks_unit = 32 if dtype == "bf16" else 16
+        want = int(os.environ.get("RBVAE_FC_SPLIT", "4"))
+        wave_ok = latent <= 32 and self.v.lstm_layers * _ru(4 * latent, 64) <= 1024 and not self.v.simple_order
+        self.fc_split = want if (want > 1 and wave_ok and self.F3 % (want * ks_unit) == 0 and self.F3 >= 2048) else 1
         self._alloc_packed()
 
     # ---- packed weights -------------------------------------------------------
@@ -531,8 +538,14 @@ class Engine:
         sv.hs_enc = self._E(nl + 1, S, T, Ld, dtype=torch.float32)
         sv.hs_dec = self._E(nl + 1, S, T, Ld, dtype=torch.float32)
         sv.e = self._E(N, Ld, dtype=torch.float32) if v.simple_order else sv.hs_enc[0].view(N, Ld)
-        L.call("rbvae_skinny_linear", self.dt, sv.a3, self.Wfc, P("encoder_cnn.fc.bias"), sv.e, N, Ld, self.F3,
-               self.F3, self.F3, Ld)
+        e_parts = None
+        if self.fc_split > 1:
+            e_parts = self._buf((N, "e_parts"), self.fc_split * N * Ld)
+            L.call("rbvae_skinny_linear_parts", self.dt, sv.a3, self.Wfc, P("encoder_cnn.fc.bias"), e_parts, N, Ld,
+                   self.F3, self.F3, self.F3, Ld, self.fc_split)
+        else:
+            L.call("rbvae_skinny_linear", self.dt, sv.a3, self.Wfc, P("encoder_cnn.fc.bias"), sv.e, N, Ld, self.F3,
+                   self.F3, self.F3, Ld)
         keep = need_grad
         if keep:
             sv.hp_enc = self._E(nl, S, T, Ld, dtype=torch.float32)
@@ -547,7 +560,11 @@ class Engine:
         kl = self._E(1, dtype=torch.float32) if kl_p is not None else None
         wenc, wdec = P("encoder_rnn.lstm.weight_ih_l0"), P("decoder_rnn.lstm.weight_ih_l0")
         if not v.simple_order:
-            L.call("rbvae_lstm_fwd", wenc, self.wT_enc, sv.hs_enc, sv.hp_enc, sv.acts_enc, sv.cs_enc, S, T, Ld, nl)
+            if e_parts is not None:
+                L.call("rbvae_lstm_fwd_parts", wenc, self.wT_enc, sv.hs_enc, sv.hp_enc, sv.acts_enc, sv.cs_enc, S, T, Ld,
+                       nl, e_parts, self.fc_split, N * Ld)
+            else:
+                L.call("rbvae_lstm_fwd", wenc, self.wT_enc, sv.hs_enc, sv.hp_enc, sv.acts_enc, sv.cs_enc, S, T, Ld, nl)
             hs = sv.hs_enc[nl]
             if after_hs is not None:
                 self._fork()
@@ -698,14 +715,23 @@ class Engine:
                 # the decoder's slab / partial-sum reductions now, beside the LSTM chain, not at the end of the pass
                 self._run_jobs()
                 self._jobs = JobList()
-        dds = tmp("dds", N, Ld, dtype=f32)
-        L.call("rbvae_skinny_linear", self.dt, df, self.WdfcT, None, dds, N, Ld, self.F3, self.F3, self.F3, Ld)
+        if self.fc_split > 1:
+            dds = tmp("dds", self.fc_split, N, Ld, dtype=f32)
+            L.call("rbvae_skinny_linear_parts", self.dt, df, self.WdfcT, None, dds, N, Ld, self.F3, self.F3, self.F3,
+                   Ld, self.fc_split)
+        else:
+            dds = tmp("dds", N, Ld, dtype=f32)
+            L.call("rbvae_skinny_linear", self.dt, df, self.WdfcT, None, dds, N, Ld, self.F3, self.F3, self.F3, Ld)
         # --- decoder LSTM
         wenc, wdec = P("encoder_rnn.lstm.weight_ih_l0"), P("decoder_rnn.lstm.weight_ih_l0")
         dG = tmp("dG_dec", nl, S, T, 4 * Ld, dtype=f32)
         dGe = tmp("dG_enc", nl, S, T, 4 * Ld, dtype=f32)
         d_in_dec = tmp("d_in_dec", N, Ld, dtype=f32)
-        L.call("rbvae_lstm_bwd", wdec, sv.acts_dec, sv.cs_dec, dds, dG, d_in_dec, S, T, Ld, nl)
+        if self.fc_split > 1:
+            L.call("rbvae_lstm_bwd_parts", wdec, sv.acts_dec, sv.cs_dec, dds, self.fc_split, N * Ld, dG, d_in_dec, S, T,
+                   Ld, nl)
+        else:
+            L.call("rbvae_lstm_bwd", wdec, sv.acts_dec, sv.cs_dec, dds, dG, d_in_dec, S, T, Ld, nl)
         de = tmp("de", N, Ld, dtype=f32)
         if not v.simple_order:
             # z -> binarise backward (+ fused KL) -> gradient of h_seq

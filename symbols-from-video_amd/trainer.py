@@ -53,6 +53,8 @@ class FusedTrainer:
         self._static: Dict = {}
         self.eng = None
         self.instrument = None       # optional callable(name, flops) -> context manager (bench roofline leg)
+        import os
+        self.one_graph = os.environ.get("RBVAE_ONE_GRAPH", "1") == "1"
 
     # ---- the two halves of a step (plain launches; captured below) ------------------
     def _fwd_bwd(self, x, U, tau, B, T):
@@ -133,8 +135,9 @@ class FusedTrainer:
                 g = self._capture(st["x"], Uarg, float(temperature), B, T)
                 self._graphs[key] = g
             g[0].replay()
-            self._allreduce()
-            g[1].replay()
+            if g[1] is not None:
+                self._allreduce()
+                g[1].replay()
         self.steps += 1
         self.model._packed_version = None     # anything else that runs the model before the next step repacks first
         return self.losses
@@ -166,11 +169,18 @@ class FusedTrainer:
                 self._update()
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
-        g1, g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g1):
-            self._fwd_bwd(x, U, tau, B, T)
-        with torch.cuda.graph(g2, pool=g1.pool()):
-            self._update()
+        g1, g2 = torch.cuda.CUDAGraph(), None
+        if self.world == 1 and self.one_graph:
+            # no collective between backward and Adam: the whole step is one graph launch
+            with torch.cuda.graph(g1):
+                self._fwd_bwd(x, U, tau, B, T)
+                self._update()
+        else:
+            g2 = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g1):
+                self._fwd_bwd(x, U, tau, B, T)
+            with torch.cuda.graph(g2, pool=g1.pool()):
+                self._update()
         self.model._flat.copy_(flat0)
         self.m.copy_(m0)
         self.vv.copy_(v0)

@@ -357,3 +357,49 @@ def test_stream_gemm_equals_gather_gemm(sfv, M, Nout):
                       Nout, relu, drop, 0.2, 1.25, 23, None, ws)
         assert torch.equal(out, ref), (use_gate, drop)
         np.testing.assert_allclose(ws.sum(0).cpu().numpy(), ws_ref.sum(0).cpu().numpy(), rtol=1e-5, atol=1e-3)
+
+
+def test_split_fc_slabs_feed_the_lstm_kernels(sfv):
+    """rbvae_skinny_linear_parts + rbvae_lstm_fwd_parts / _bwd_parts == the unsplit product fed to rbvae_lstm_fwd /
+    _bwd (slab sums differ from the one-pass product only by f32 summation order)."""
+    g = torch.Generator().manual_seed(19)
+    S, T, L, layers, K, ks = 6, 8, 32, 4, 4096, 4
+    N = S * T
+    A = torch.randn(N, K, generator=g).bfloat16().cuda()
+    Wt = (torch.randn(L, K, generator=g) / K ** 0.5).bfloat16().cuda()
+    bias = torch.randn(L, generator=g).cuda()
+    one = torch.empty(N, L, device="cuda")
+    parts = torch.empty(ks, N, L, device="cuda")
+    sfv._lib.call("rbvae_skinny_linear", 1, A, Wt, bias, one, N, L, K, K, K, L)
+    sfv._lib.call("rbvae_skinny_linear_parts", 1, A, Wt, bias, parts, N, L, K, K, K, L, ks)
+    np.testing.assert_allclose(parts.sum(0).cpu().numpy(), one.cpu().numpy(), atol=2e-5)
+    wblk = (torch.randn(layers * (8 * L * L + 8 * L), generator=g) * 0.2).cuda()
+
+    def fwd(use_parts):
+        hs = torch.zeros(layers + 1, S, T, L, device="cuda")
+        hp, cs = torch.empty(layers, S, T, L, device="cuda"), torch.empty(layers, S, T, L, device="cuda")
+        acts = torch.empty(layers, S, T, 4 * L, device="cuda")
+        if use_parts:
+            sfv._lib.call("rbvae_lstm_fwd_parts", wblk, None, hs, hp, acts, cs, S, T, L, layers, parts, ks, N * L)
+        else:
+            hs[0] = parts.sum(0).view(S, T, L)
+            sfv._lib.call("rbvae_lstm_fwd", wblk, None, hs, hp, acts, cs, S, T, L, layers)
+        return hs, acts, cs
+    (h0, a0, c0), (h1, a1, c1) = fwd(False), fwd(True)
+    np.testing.assert_allclose(h1.cpu().numpy(), h0.cpu().numpy(), atol=1e-6)
+    gparts = torch.randn(ks, N, L, generator=g).cuda()
+    outs = []
+    for use_parts in (False, True):
+        dG, dx = torch.empty(layers, S, T, 4 * L, device="cuda"), torch.empty(N, L, device="cuda")
+        if use_parts:
+            sfv._lib.call("rbvae_lstm_bwd_parts", wblk, a0, c0, gparts, ks, N * L, dG, dx, S, T, L, layers)
+        else:
+            sfv._lib.call("rbvae_lstm_bwd", wblk, a0, c0, gparts.sum(0).contiguous(), dG, dx, S, T, L, layers)
+        outs.append((dG, dx))
+    np.testing.assert_allclose(outs[1][0].cpu().numpy(), outs[0][0].cpu().numpy(), atol=1e-5)
+    np.testing.assert_allclose(outs[1][1].cpu().numpy(), outs[0][1].cpu().numpy(), atol=1e-5)
+    # a latent size the wavefront kernel does not cover is refused, not silently mis-summed
+    with pytest.raises(ValueError):
+        hs = torch.zeros(2, 2, 3, 64, device="cuda")
+        sfv._lib.call("rbvae_lstm_fwd_parts", torch.zeros(8 * 64 * 64 + 8 * 64, device="cuda"), None, hs, None, None, None, 2, 3,
+                      64, 1, torch.zeros(2, 6, 64, device="cuda"), 2, 6 * 64)
