@@ -233,14 +233,20 @@ int rbvae_lstm_fwd(const float* wblk, const float* wT, float* hs_all, float* hpr
                    int T, int L, int layers, void* stream);
 int rbvae_lstm_bwd(const float* wblk, const float* acts, const float* cs, const float* g_top, float* dG, float* dx,
                    int S, int T, int L, int layers, void* stream);
-/* The same with the stack input (forward) / the top-layer gradient (backward) given as `nparts` K-split slabs of
- * the fc product that feeds them (rbvae_skinny_linear_parts; slab q at + q*part_stride floats): summed in slab
- * order inside the kernel's prologue; the forward also writes the sum to slot 0 of hs_all.  Wavefront kernel
- * only (L <= 32, layers * roundup64(4L) <= 1024), else RBVAE_E_INVALID. */
-int rbvae_lstm_fwd_parts(const float* wblk, const float* wT, float* hs_all, float* hprev, float* acts, float* cs, int S,
-                         int T, int L, int layers, const float* in_parts, int nparts, long part_stride, void* stream);
-int rbvae_lstm_bwd_parts(const float* wblk, const float* acts, const float* cs, const float* g_top_parts, int nparts,
-                         long part_stride, float* dG, float* dx, int S, int T, int L, int layers, void* stream);
+/* Extended forms that take over the small kernels around the stacks (wavefront kernel only: L <= 32,
+ * layers * roundup64(4L) <= 1024, else RBVAE_E_INVALID):
+ *  - in_parts / g_top_parts: the stack input (forward) / top-layer gradient (backward) as `nparts` K-split slabs of
+ *    the fc product that feeds them (rbvae_skinny_linear_parts; slab q at + q*part_stride floats), summed in slab
+ *    order in the kernel's prologue; the forward also writes the sum to slot 0 of hs_all.  in_parts NULL /
+ *    nparts 1: plain input as in rbvae_lstm_fwd / _bwd;
+ *  - cast_out (may be NULL): the top layer's outputs (forward) / the input gradient dx (backward) once more as
+ *    [S*T][cast_ld] rows of cast_dtype, zero padded -- the operand of the GEMM that follows (rbvae_cast_pad). */
+int rbvae_lstm_fwd_ex(const float* wblk, const float* wT, float* hs_all, float* hprev, float* acts, float* cs, int S,
+                      int T, int L, int layers, const float* in_parts, int nparts, long part_stride, void* cast_out,
+                      int cast_dtype, int cast_ld, void* stream);
+int rbvae_lstm_bwd_ex(const float* wblk, const float* acts, const float* cs, const float* g_top_parts, int nparts,
+                      long part_stride, float* dG, float* dx, void* cast_out, int cast_dtype, int cast_ld, int S, int T,
+                      int L, int layers, void* stream);
 int rbvae_lstm_wgrad(const float* dG, const float* hs_all, const float* hprev, float* gblk, int S, int T, int L,
                      int layers, int accumulate, void* stream);
 /* the same for two stacks of equal shape (the encoder and decoder LSTMs) in one launch */

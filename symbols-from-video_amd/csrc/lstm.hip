@@ -234,7 +234,8 @@ __global__ __launch_bounds__(1024) void lstm_fwd_wave_k(const float* __restrict_
                                                         float* __restrict__ hprev, float* __restrict__ acts,
                                                         float* __restrict__ cs, int S, int T, int L_, int layers,
                                                         int G, const float* __restrict__ in_parts, int nparts,
-                                                        long part_stride) {
+                                                        long part_stride, void* __restrict__ cast_out, int cast_bf16,
+                                                        int cast_ld) {
     const int L = EXACT ? LMAX : L_;
     extern __shared__ __attribute__((aligned(16))) float sm[];
     float* hbuf = sm;                               // [layers+1][T][L]
@@ -255,6 +256,15 @@ __global__ __launch_bounds__(1024) void lstm_fwd_wave_k(const float* __restrict_
         }
     } else {
         for (int i = threadIdx.x; i < T * L; i += blockDim.x) hbuf[i] = hs_all[((long)s * T) * L + i];
+    }
+    if (cast_out) {
+        // padding columns [L, cast_ld) of this sequence's rows of the cast copy (the consumer GEMM reads whole
+        // 128-byte K slices)
+        const int pw = cast_ld - L;
+        for (int i = threadIdx.x; i < T * pw; i += blockDim.x) {
+            const long o = ((long)s * T + i / pw) * cast_ld + L + i % pw;
+            if (cast_bf16) ((bf16_t*)cast_out)[o] = 0; else ((float*)cast_out)[o] = 0.f;
+        }
     }
     const float* wl = wblk + l * lstm_layer_floats(L);
     float wih[LMAX], whh[LMAX];
@@ -323,6 +333,11 @@ __global__ __launch_bounds__(1024) void lstm_fwd_wave_k(const float* __restrict_
                 hprev[o * L + j] = hp;
             }
             hs_all[(((long)(l + 1) * S + s) * T + t) * L + j] = h;
+            if (cast_out && l == layers - 1) {
+                // the top layer's output again in the next GEMM's operand type (what rbvae_cast_pad would make of it)
+                const long o = ((long)s * T + t) * cast_ld + j;
+                if (cast_bf16) ((bf16_t*)cast_out)[o] = f32_to_bf16(h); else ((float*)cast_out)[o] = h;
+            }
         }
         lds_barrier();
     }
@@ -332,7 +347,8 @@ template <int LMAX, bool EXACT>
 __global__ __launch_bounds__(1024) void lstm_bwd_wave_k(const float* __restrict__ wblk, const float* __restrict__ acts,
                                                         const float* __restrict__ cs, const float* __restrict__ g_top,
                                                         float* __restrict__ dG, float* __restrict__ dx, int S, int T,
-                                                        int L_, int layers, int G, int nparts, long part_stride) {
+                                                        int L_, int layers, int G, int nparts, long part_stride,
+                                                        void* __restrict__ cast_out, int cast_bf16, int cast_ld) {
     const int L = EXACT ? LMAX : L_;
     extern __shared__ float sm[];
     float* gtop = sm;                              // [T][L]
@@ -377,6 +393,13 @@ __global__ __launch_bounds__(1024) void lstm_bwd_wave_k(const float* __restrict_
             }
         }
     }
+    if (cast_out) {
+        const int pw = cast_ld - L;
+        for (int i = threadIdx.x; i < T * pw; i += blockDim.x) {
+            const long o = ((long)s * T + i / pw) * cast_ld + L + i % pw;
+            if (cast_bf16) ((bf16_t*)cast_out)[o] = 0; else ((float*)cast_out)[o] = 0.f;
+        }
+    }
     const float* wl = wblk + l * lstm_layer_floats(L);
     float wic[LMAX], whc[LMAX];
     if (row) {
@@ -402,7 +425,12 @@ __global__ __launch_bounds__(1024) void lstm_bwd_wave_k(const float* __restrict_
             // layer 0: the input gradient of the step finished at the previous diagonal (time t+1)
             if (l == 0 && q >= 1 && q <= T) {
                 const float* p0 = part;
-                dx[((long)s * T + t + 1) * L + j] = p0[0 * L + j] + p0[2 * L + j] + p0[4 * L + j] + p0[6 * L + j];
+                const float dv = p0[0 * L + j] + p0[2 * L + j] + p0[4 * L + j] + p0[6 * L + j];
+                dx[((long)s * T + t + 1) * L + j] = dv;
+                if (cast_out) {
+                    const long o = ((long)s * T + t + 1) * cast_ld + j;
+                    if (cast_bf16) ((bf16_t*)cast_out)[o] = f32_to_bf16(dv); else ((float*)cast_out)[o] = dv;
+                }
             }
             if (active) {
                 float dh;
@@ -452,7 +480,14 @@ __global__ __launch_bounds__(1024) void lstm_bwd_wave_k(const float* __restrict_
         }
         lds_barrier();
     }
-    if (l == 0 && j < L) dx[((long)s * T) * L + j] = part[0 * L + j] + part[2 * L + j] + part[4 * L + j] + part[6 * L + j];
+    if (l == 0 && j < L) {
+        const float dv = part[0 * L + j] + part[2 * L + j] + part[4 * L + j] + part[6 * L + j];
+        dx[((long)s * T) * L + j] = dv;
+        if (cast_out) {
+            const long o = ((long)s * T) * cast_ld + j;
+            if (cast_bf16) ((bf16_t*)cast_out)[o] = f32_to_bf16(dv); else ((float*)cast_out)[o] = dv;
+        }
+    }
 }
 
 // Weight gradients, LDS-tiled: block = (8 gate rows, ih|hh, layer); thread (jj, kq) owns gate row jj and
@@ -531,8 +566,12 @@ using namespace rbvae;
 extern "C" {
 
 static int lstm_fwd_impl(const float* wblk, const float* wT, float* hs_all, float* hprev, float* acts, float* cs, int S,
-                         int T, int L, int layers, const float* in_parts, int nparts, long part_stride, void* stream) {
+                         int T, int L, int layers, const float* in_parts, int nparts, long part_stride, void* cast_out,
+                         int cast_dtype, int cast_ld, void* stream) {
     RBVAE_CHECK_ARG(wblk && hs_all && S > 0 && T > 0 && L > 0 && layers > 0, "lstm_fwd: bad arguments");
+    RBVAE_CHECK_ARG(!cast_out || ((cast_dtype == RBVAE_F32 || cast_dtype == RBVAE_BF16) && cast_ld >= L),
+                    "lstm_fwd: cast output dtype %d ld %d", cast_dtype, cast_ld);
+    const int cast_bf16 = cast_dtype == RBVAE_BF16;
     RBVAE_CHECK_ARG(L <= 128, "lstm_fwd: latent_dim %d > 128 is not supported", L);
     RBVAE_CHECK_ARG((acts == nullptr) == (cs == nullptr) && (acts == nullptr) == (hprev == nullptr),
                     "lstm_fwd: hprev/acts/cs must be given together");
@@ -545,17 +584,20 @@ static int lstm_fwd_impl(const float* wblk, const float* wT, float* hs_all, floa
     if (L <= 32 && layers * threads <= 1024 && wlds <= 64 * 1024) {
         if (L == 32)
             hipLaunchKernelGGL((lstm_fwd_wave_k<32, true, true>), dim3(S), dim3(layers * threads), wlds, st, wblk, wT,
-                               hs_all, hprev, acts, cs, S, T, L, layers, threads, in_parts, nparts, part_stride);
+                               hs_all, hprev, acts, cs, S, T, L, layers, threads, in_parts, nparts, part_stride, cast_out,
+                               cast_bf16, cast_ld);
         else if (L % 4 == 0)
             hipLaunchKernelGGL((lstm_fwd_wave_k<32, true, false>), dim3(S), dim3(layers * threads), wlds, st, wblk, wT,
-                               hs_all, hprev, acts, cs, S, T, L, layers, threads, in_parts, nparts, part_stride);
+                               hs_all, hprev, acts, cs, S, T, L, layers, threads, in_parts, nparts, part_stride, cast_out,
+                               cast_bf16, cast_ld);
         else
             hipLaunchKernelGGL((lstm_fwd_wave_k<32, false, false>), dim3(S), dim3(layers * threads), wlds, st, wblk, wT,
-                               hs_all, hprev, acts, cs, S, T, L, layers, threads, in_parts, nparts, part_stride);
+                               hs_all, hprev, acts, cs, S, T, L, layers, threads, in_parts, nparts, part_stride, cast_out,
+                               cast_bf16, cast_ld);
         RBVAE_CHECK_LAUNCH("lstm_fwd_wave");
         return RBVAE_OK;
     }
-    RBVAE_CHECK_ARG(!in_parts, "lstm_fwd_parts: only the wavefront kernel (L <= 32, layers * roundup64(4L) <= 1024) sums input slabs");
+    RBVAE_CHECK_ARG(!in_parts && !cast_out, "lstm_fwd_ex: only the wavefront kernel (L <= 32, layers * roundup64(4L) <= 1024) sums input slabs / writes a cast copy");
     if (L <= 32)
         hipLaunchKernelGGL(lstm_fwd_k<32>, dim3(S), dim3(threads), lds, st, wblk, hs_all, hprev, acts, cs, S, T, L, layers);
     else if (L <= 64)
@@ -568,19 +610,25 @@ static int lstm_fwd_impl(const float* wblk, const float* wT, float* hs_all, floa
 
 int rbvae_lstm_fwd(const float* wblk, const float* wT, float* hs_all, float* hprev, float* acts, float* cs, int S,
                    int T, int L, int layers, void* stream) {
-    return lstm_fwd_impl(wblk, wT, hs_all, hprev, acts, cs, S, T, L, layers, nullptr, 1, 0, stream);
+    return lstm_fwd_impl(wblk, wT, hs_all, hprev, acts, cs, S, T, L, layers, nullptr, 1, 0, nullptr, 0, 0, stream);
 }
 
-int rbvae_lstm_fwd_parts(const float* wblk, const float* wT, float* hs_all, float* hprev, float* acts, float* cs, int S,
-                         int T, int L, int layers, const float* in_parts, int nparts, long part_stride, void* stream) {
-    RBVAE_CHECK_ARG(in_parts && nparts >= 1 && part_stride >= (long)S * T * L, "lstm_fwd_parts: bad slabs");
-    return lstm_fwd_impl(wblk, wT, hs_all, hprev, acts, cs, S, T, L, layers, in_parts, nparts, part_stride, stream);
+int rbvae_lstm_fwd_ex(const float* wblk, const float* wT, float* hs_all, float* hprev, float* acts, float* cs, int S,
+                      int T, int L, int layers, const float* in_parts, int nparts, long part_stride, void* cast_out,
+                      int cast_dtype, int cast_ld, void* stream) {
+    RBVAE_CHECK_ARG(!in_parts || (nparts >= 1 && part_stride >= (long)S * T * L), "lstm_fwd_ex: bad slabs");
+    return lstm_fwd_impl(wblk, wT, hs_all, hprev, acts, cs, S, T, L, layers, in_parts, nparts, part_stride, cast_out,
+                         cast_dtype, cast_ld, stream);
 }
 
 static int lstm_bwd_impl(const float* wblk, const float* acts, const float* cs, const float* g_top, float* dG, float* dx,
-                         int S, int T, int L, int layers, int nparts, long part_stride, void* stream) {
+                         int S, int T, int L, int layers, int nparts, long part_stride, void* cast_out, int cast_dtype,
+                         int cast_ld, void* stream) {
     RBVAE_CHECK_ARG(wblk && acts && cs && g_top && dG && dx && S > 0 && T > 0 && L > 0 && layers > 0,
                     "lstm_bwd: bad arguments");
+    RBVAE_CHECK_ARG(!cast_out || ((cast_dtype == RBVAE_F32 || cast_dtype == RBVAE_BF16) && cast_ld >= L),
+                    "lstm_bwd: cast output dtype %d ld %d", cast_dtype, cast_ld);
+    const int cast_bf16 = cast_dtype == RBVAE_BF16;
     RBVAE_CHECK_ARG(L <= 128, "lstm_bwd: latent_dim %d > 128 is not supported", L);
     const int threads = ((4 * L + 63) / 64) * 64;
     const size_t lds = (size_t)(2 * T * L + 13 * L) * sizeof(float);
@@ -590,14 +638,14 @@ static int lstm_bwd_impl(const float* wblk, const float* acts, const float* cs, 
     if (L <= 32 && layers * threads <= 1024 && wlds <= 64 * 1024) {
         if (L == 32)
             hipLaunchKernelGGL((lstm_bwd_wave_k<32, true>), dim3(S), dim3(layers * threads), wlds, st, wblk, acts, cs,
-                               g_top, dG, dx, S, T, L, layers, threads, nparts, part_stride);
+                               g_top, dG, dx, S, T, L, layers, threads, nparts, part_stride, cast_out, cast_bf16, cast_ld);
         else
             hipLaunchKernelGGL((lstm_bwd_wave_k<32, false>), dim3(S), dim3(layers * threads), wlds, st, wblk, acts, cs,
-                               g_top, dG, dx, S, T, L, layers, threads, nparts, part_stride);
+                               g_top, dG, dx, S, T, L, layers, threads, nparts, part_stride, cast_out, cast_bf16, cast_ld);
         RBVAE_CHECK_LAUNCH("lstm_bwd_wave");
         return RBVAE_OK;
     }
-    RBVAE_CHECK_ARG(nparts == 1, "lstm_bwd_parts: only the wavefront kernel (L <= 32, layers * roundup64(4L) <= 1024) sums gradient slabs");
+    RBVAE_CHECK_ARG(nparts == 1 && !cast_out, "lstm_bwd_ex: only the wavefront kernel (L <= 32, layers * roundup64(4L) <= 1024) sums gradient slabs / writes a cast copy");
     if (L <= 32)
         hipLaunchKernelGGL(lstm_bwd_k<32>, dim3(S), dim3(threads), lds, st, wblk, acts, cs, g_top, dG, dx, S, T, L, layers);
     else if (L <= 64)
@@ -610,13 +658,15 @@ static int lstm_bwd_impl(const float* wblk, const float* acts, const float* cs, 
 
 int rbvae_lstm_bwd(const float* wblk, const float* acts, const float* cs, const float* g_top, float* dG, float* dx,
                    int S, int T, int L, int layers, void* stream) {
-    return lstm_bwd_impl(wblk, acts, cs, g_top, dG, dx, S, T, L, layers, 1, 0, stream);
+    return lstm_bwd_impl(wblk, acts, cs, g_top, dG, dx, S, T, L, layers, 1, 0, nullptr, 0, 0, stream);
 }
 
-int rbvae_lstm_bwd_parts(const float* wblk, const float* acts, const float* cs, const float* g_top_parts, int nparts,
-                         long part_stride, float* dG, float* dx, int S, int T, int L, int layers, void* stream) {
-    RBVAE_CHECK_ARG(nparts >= 1 && part_stride >= (long)S * T * L, "lstm_bwd_parts: bad slabs");
-    return lstm_bwd_impl(wblk, acts, cs, g_top_parts, dG, dx, S, T, L, layers, nparts, part_stride, stream);
+int rbvae_lstm_bwd_ex(const float* wblk, const float* acts, const float* cs, const float* g_top_parts, int nparts,
+                      long part_stride, float* dG, float* dx, void* cast_out, int cast_dtype, int cast_ld, int S, int T,
+                      int L, int layers, void* stream) {
+    RBVAE_CHECK_ARG(nparts >= 1 && (nparts == 1 || part_stride >= (long)S * T * L), "lstm_bwd_ex: bad slabs");
+    return lstm_bwd_impl(wblk, acts, cs, g_top_parts, dG, dx, S, T, L, layers, nparts, part_stride, cast_out, cast_dtype,
+                         cast_ld, stream);
 }
 
 static int launch_lstm_wgrad(const float* dG, const float* hs_all, const float* hprev, float* gblk, const float* dG2,

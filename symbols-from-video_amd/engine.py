@@ -248,6 +248,8 @@ class Engine:
         want = int(os.environ.get("RBVAE_FC_SPLIT", "4"))
         wave_ok = latent <= 32 and self.v.lstm_layers * _ru(4 * latent, 64) <= 1024 and not self.v.simple_order
         self.fc_split = want if (want > 1 and wave_ok and self.F3 % (want * ks_unit) == 0 and self.F3 >= 2048) else 1
+        # ... and write the bf16 / padded copy of their output that the next GEMM reads (rbvae_cast_pad otherwise)
+        self.lstm_cast = wave_ok and os.environ.get("RBVAE_LSTM_CAST", "1") == "1"
         self._alloc_packed()
 
     # ---- packed weights -------------------------------------------------------
@@ -561,8 +563,8 @@ class Engine:
         wenc, wdec = P("encoder_rnn.lstm.weight_ih_l0"), P("decoder_rnn.lstm.weight_ih_l0")
         if not v.simple_order:
             if e_parts is not None:
-                L.call("rbvae_lstm_fwd_parts", wenc, self.wT_enc, sv.hs_enc, sv.hp_enc, sv.acts_enc, sv.cs_enc, S, T, Ld,
-                       nl, e_parts, self.fc_split, N * Ld)
+                L.call("rbvae_lstm_fwd_ex", wenc, self.wT_enc, sv.hs_enc, sv.hp_enc, sv.acts_enc, sv.cs_enc, S, T, Ld,
+                       nl, e_parts, self.fc_split, N * Ld, None, 0, 0)
             else:
                 L.call("rbvae_lstm_fwd", wenc, self.wT_enc, sv.hs_enc, sv.hp_enc, sv.acts_enc, sv.cs_enc, S, T, Ld, nl)
             hs = sv.hs_enc[nl]
@@ -584,7 +586,12 @@ class Engine:
                 if repack:
                     self.pack_end()
                 return {"z": sv.z.view(S, T, Ld), "hs": hs, "saved": sv}
-            L.call("rbvae_lstm_fwd", wdec, self.wT_dec, sv.hs_dec, sv.hp_dec, sv.acts_dec, sv.cs_dec, S, T, Ld, nl)
+            if self.lstm_cast:
+                sv.ds_pad = self._E(N, self.Lp)
+                L.call("rbvae_lstm_fwd_ex", wdec, self.wT_dec, sv.hs_dec, sv.hp_dec, sv.acts_dec, sv.cs_dec, S, T, Ld, nl,
+                       None, 1, 0, sv.ds_pad, self.dt, self.Lp)
+            else:
+                L.call("rbvae_lstm_fwd", wdec, self.wT_dec, sv.hs_dec, sv.hp_dec, sv.acts_dec, sv.cs_dec, S, T, Ld, nl)
         else:
             sv.z = sv.hs_enc[0].view(N, Ld)
             L.call("rbvae_binarize_kl_fwd", sv.e, U, sv.y, sv.z, None, N, Ld, float(tau), float(r), v.eps, int(hard),
@@ -595,8 +602,9 @@ class Engine:
             L.call("rbvae_lstm_fwd", wdec, self.wT_dec, sv.hs_dec, sv.hp_dec, sv.acts_dec, sv.cs_dec, S, T, Ld, nl)
         ds = sv.hs_dec[nl]
         # decoder CNN
-        sv.ds_pad = self._E(N, self.Lp)
-        L.call("rbvae_cast_pad", self.dt, ds, sv.ds_pad, N, Ld, self.Lp)
+        if not (self.lstm_cast and not v.simple_order):
+            sv.ds_pad = self._E(N, self.Lp)
+            L.call("rbvae_cast_pad", self.dt, ds, sv.ds_pad, N, Ld, self.Lp)
         if repack:
             self.pack_end()
         sv.f = self._E(N * h3 * w3, c3)
@@ -728,8 +736,8 @@ class Engine:
         dGe = tmp("dG_enc", nl, S, T, 4 * Ld, dtype=f32)
         d_in_dec = tmp("d_in_dec", N, Ld, dtype=f32)
         if self.fc_split > 1:
-            L.call("rbvae_lstm_bwd_parts", wdec, sv.acts_dec, sv.cs_dec, dds, self.fc_split, N * Ld, dG, d_in_dec, S, T,
-                   Ld, nl)
+            L.call("rbvae_lstm_bwd_ex", wdec, sv.acts_dec, sv.cs_dec, dds, self.fc_split, N * Ld, dG, d_in_dec, None, 0, 0,
+                   S, T, Ld, nl)
         else:
             L.call("rbvae_lstm_bwd", wdec, sv.acts_dec, sv.cs_dec, dds, dG, d_in_dec, S, T, Ld, nl)
         de = tmp("de", N, Ld, dtype=f32)
@@ -748,8 +756,15 @@ class Engine:
                        float(kl_p), 1e-8, 1)
                 if g_hs is not None:
                     dh = dh + g_hs.reshape(N, Ld)
-            L.call("rbvae_lstm_bwd", wenc, sv.acts_enc, sv.cs_enc, dh, dGe, de, S, T, Ld, nl)
+            de_pad = None
+            if self.lstm_cast:
+                de_pad = tmp("de_pad", N, self.Lp)
+                L.call("rbvae_lstm_bwd_ex", wenc, sv.acts_enc, sv.cs_enc, dh, 1, 0, dGe, de, de_pad, self.dt, self.Lp, S, T,
+                       Ld, nl)
+            else:
+                L.call("rbvae_lstm_bwd", wenc, sv.acts_enc, sv.cs_enc, dh, dGe, de, S, T, Ld, nl)
         else:
+            de_pad = None
             # decoder stack input = encoder stack output
             dz = tmp("dz", N, Ld, dtype=f32)
             L.call("rbvae_lstm_bwd", wenc, sv.acts_enc, sv.cs_enc, d_in_dec, dGe, dz, S, T, Ld, nl)
@@ -763,8 +778,9 @@ class Engine:
                    dGe, sv.hs_enc, sv.hp_enc, G("encoder_rnn.lstm.weight_ih_l0"), S, T, Ld, nl, 0)
             self._colsum(F32, de, N, Ld, Ld, G("encoder_cnn.fc.bias"), tag=(N, "bfc"))
         # --- encoder fc
-        de_pad = tmp("de_pad", N, self.Lp)
-        L.call("rbvae_cast_pad", self.dt, de, de_pad, N, Ld, self.Lp)
+        if de_pad is None:
+            de_pad = tmp("de_pad", N, self.Lp)
+            L.call("rbvae_cast_pad", self.dt, de, de_pad, N, Ld, self.Lp)
         self._wgrad(de_pad, sv.a3, None, N, self.Lp, self.F3, self.Lp, self.F3, 1, G("encoder_cnn.fc.weight"),
                     (Ld, c3, g3), (self.F3, 1, c3), tag=(N, "Wfc"))
         da3 = tmp("da3", P3, c3)

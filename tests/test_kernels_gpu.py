@@ -360,7 +360,7 @@ def test_stream_gemm_equals_gather_gemm(sfv, M, Nout):
 
 
 def test_split_fc_slabs_feed_the_lstm_kernels(sfv):
-    """rbvae_skinny_linear_parts + rbvae_lstm_fwd_parts / _bwd_parts == the unsplit product fed to rbvae_lstm_fwd /
+    """rbvae_skinny_linear_parts + rbvae_lstm_fwd_ex / _bwd_ex == the unsplit product fed to rbvae_lstm_fwd /
     _bwd (slab sums differ from the one-pass product only by f32 summation order)."""
     g = torch.Generator().manual_seed(19)
     S, T, L, layers, K, ks = 6, 8, 32, 4, 4096, 4
@@ -380,7 +380,11 @@ def test_split_fc_slabs_feed_the_lstm_kernels(sfv):
         hp, cs = torch.empty(layers, S, T, L, device="cuda"), torch.empty(layers, S, T, L, device="cuda")
         acts = torch.empty(layers, S, T, 4 * L, device="cuda")
         if use_parts:
-            sfv._lib.call("rbvae_lstm_fwd_parts", wblk, None, hs, hp, acts, cs, S, T, L, layers, parts, ks, N * L)
+            pad = torch.full((N, 64), 9.0, dtype=torch.bfloat16, device="cuda")
+            sfv._lib.call("rbvae_lstm_fwd_ex", wblk, None, hs, hp, acts, cs, S, T, L, layers, parts, ks, N * L, pad, 1, 64)
+            ref = torch.zeros(N, 64, dtype=torch.bfloat16, device="cuda")
+            sfv._lib.call("rbvae_cast_pad", 1, hs[layers].contiguous(), ref, N, L, 64)
+            assert torch.equal(pad, ref)                       # the cast copy == rbvae_cast_pad of the top layer
         else:
             hs[0] = parts.sum(0).view(S, T, L)
             sfv._lib.call("rbvae_lstm_fwd", wblk, None, hs, hp, acts, cs, S, T, L, layers)
@@ -392,7 +396,9 @@ def test_split_fc_slabs_feed_the_lstm_kernels(sfv):
     for use_parts in (False, True):
         dG, dx = torch.empty(layers, S, T, 4 * L, device="cuda"), torch.empty(N, L, device="cuda")
         if use_parts:
-            sfv._lib.call("rbvae_lstm_bwd_parts", wblk, a0, c0, gparts, ks, N * L, dG, dx, S, T, L, layers)
+            pad = torch.full((N, 32), 9.0, device="cuda")
+            sfv._lib.call("rbvae_lstm_bwd_ex", wblk, a0, c0, gparts, ks, N * L, dG, dx, pad, 0, 32, S, T, L, layers)
+            assert torch.equal(pad, dx)
         else:
             sfv._lib.call("rbvae_lstm_bwd", wblk, a0, c0, gparts.sum(0).contiguous(), dG, dx, S, T, L, layers)
         outs.append((dG, dx))
@@ -401,5 +407,5 @@ def test_split_fc_slabs_feed_the_lstm_kernels(sfv):
     # a latent size the wavefront kernel does not cover is refused, not silently mis-summed
     with pytest.raises(ValueError):
         hs = torch.zeros(2, 2, 3, 64, device="cuda")
-        sfv._lib.call("rbvae_lstm_fwd_parts", torch.zeros(8 * 64 * 64 + 8 * 64, device="cuda"), None, hs, None, None, None, 2, 3,
-                      64, 1, torch.zeros(2, 6, 64, device="cuda"), 2, 6 * 64)
+        sfv._lib.call("rbvae_lstm_fwd_ex", torch.zeros(8 * 64 * 64 + 8 * 64, device="cuda"), None, hs, None, None, None, 2, 3,
+                      64, 1, torch.zeros(2, 6, 64, device="cuda"), 2, 6 * 64, None, 0, 0)
