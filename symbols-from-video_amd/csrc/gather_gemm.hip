@@ -571,7 +571,10 @@ static int dispatch_gg(const GgArgs& a, hipStream_t st, int max_steps) {
         if (blocks <= 128) return launch_gg<T, 2, 4, 3>(a, st);
     }
     static const int one = getenv("RBVAE_GG_ONE") ? atoi(getenv("RBVAE_GG_ONE")) : 1;
-    if (ns == 1) return one == 1 && blocks > 512 ? launch_gg<T, 2, 4, 1, 4>(a, st) : launch_gg<T, 4, 4, 1>(a, st);
+    if (ns == 1 && one >= 1 && blocks > 512) return launch_gg<T, 2, 4, 1, 4>(a, st);
+    // few 128-wide tiles (the fc products at 256 frames: 64): 128 x 32 tiles put a workgroup on every CU
+    if (ns == 1 && one >= 2 && blocks <= 64) return launch_gg<T, 1, 4, 1>(a, st);
+    if (ns == 1) return launch_gg<T, 4, 4, 1>(a, st);
     if (ns >= 2 && (dbg == 5 || dbg == 6)) return dbg == 5 ? launch_gg<T, 2, 4, 3>(a, st) : launch_gg<T, 2, 4, 2>(a, st);
     if (ns == 2) return launch_gg<T, 4, 8, 2>(a, st);
     if (dbg == 4) return launch_gg<T, 4, 4, 3>(a, st);       // 4 waves, 64x64 wave tiles (less LDS traffic)

@@ -3,6 +3,7 @@
 // network, the col2im + sigmoid + MSE epilogue of the last ConvTranspose2d, column
 // sums (bias gradients), f32 -> T casts, the skinny Linear (N <= 128) and Adam.
 #include "common.h"
+#include <stdlib.h>
 
 namespace rbvae {
 
@@ -232,6 +233,66 @@ __global__ __launch_bounds__(256) void col2im_sigmoid_k(
             const float d = s - target[frame_off<IDX>(tfm, (IDX)n) + (i - (IDX)n * (IDX)Cout * (IDX)OH * (IDX)OW)];
             sse += d * d;
             if (dpre) dpre[((long)(n * OH + oh) * OW + ow) * Cout + co] = gsc * d * s * (1.f - s);
+        }
+    }
+    if (sse_ws) {
+        const float tot_b = block_sum(sse, red);
+        if (threadIdx.x == 0) sse_ws[blockIdx.x] = tot_b;
+    }
+}
+// The same for Cout <= 4 with one thread per output PIXEL: a tap's Cout products are one contiguous 6-8 byte
+// read (the element-per-thread form above issues Cout scattered 2-byte reads per tap), dpre leaves as one
+// 16-byte store, xr / target stay coalesced along ow per channel plane.  Same sums in the same order.
+template <typename T>
+__global__ __launch_bounds__(256) void col2im_sigmoid_pix_k(
+    const T* __restrict__ Y, int ldy, const float* __restrict__ bias, int N, int IH, int IW, int OH, int OW,
+    int Cout, int KH, int KW, int pad, float* __restrict__ xr, const float* __restrict__ target, FrameMap tfm,
+    float* __restrict__ sse_ws, float* __restrict__ dpre, float gscale, const float* __restrict__ gs_dev) {
+    __shared__ float red[4];
+    const unsigned npix = (unsigned)N * OH * OW;
+    float sse = 0.f;
+    float gsc = gscale;
+    if (gs_dev) gsc *= gs_dev[0];
+    const unsigned plane = (unsigned)OH * OW;
+    for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < npix; i += gridDim.x * 256u) {
+        const unsigned r = i / (unsigned)OW, ow = i - r * (unsigned)OW;
+        const unsigned n = r / (unsigned)OH, oh = r - n * (unsigned)OH;
+        float v[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) v[c] = (bias && c < Cout) ? bias[c] : 0.f;
+        for (int kh = (oh + pad) & 1; kh < KH; kh += 2) {
+            const int a = ((int)oh + pad - kh) >> 1;
+            if (a < 0 || a >= IH) continue;
+            for (int kw = (ow + pad) & 1; kw < KW; kw += 2) {
+                const int b = ((int)ow + pad - kw) >> 1;
+                if (b < 0 || b >= IW) continue;
+                const T* yp = Y + ((size_t)(n * IH + a) * IW + b) * ldy + (kh * KW + kw) * Cout;
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+                    if (c < Cout) v[c] += Elem<T>::load(yp + c);
+            }
+        }
+        const size_t xo = (size_t)n * Cout * plane + (size_t)oh * OW + ow;
+        const float* tp = target ? target + frame_off<unsigned>(tfm, n) + (size_t)oh * OW + ow : nullptr;
+        float d4[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            if (c >= Cout) break;
+            const float sg = sigmoidf_(v[c]);
+            xr[xo + (size_t)c * plane] = sg;
+            if (target) {
+                const float d = sg - tp[(size_t)c * plane];
+                sse += d * d;
+                d4[c] = gsc * d * sg * (1.f - sg);
+            }
+        }
+        if (target && dpre) {
+            float* dp = dpre + (size_t)i * Cout;
+            if (Cout == 4) *(float4*)dp = make_float4(d4[0], d4[1], d4[2], d4[3]);
+            else
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+                    if (c < Cout) dp[c] = d4[c];
         }
     }
     if (sse_ws) {
@@ -519,11 +580,18 @@ static int col2im_impl(int dtype, const void* Y, int ldy, const float* bias, int
     hipStream_t st = (hipStream_t)stream;
     const bool small = tot < (1l << 31) - (1l << 20) && (long)N * IH * IW * ldy < (1l << 31) &&
                        frame_span(tfm, N) + (long)Cout * OH * OW < (1l << 31);
+    static const int pix_on = getenv("RBVAE_COL2IM_PIX") ? atoi(getenv("RBVAE_COL2IM_PIX")) : 1;
+    const bool pix = pix_on && small && Cout <= 4 && (!dpre || (uintptr_t)dpre % 16 == 0);
 #define RBVAE_COL2IM(TT, II)                                                                                       \
     hipLaunchKernelGGL((col2im_sigmoid_k<TT, II>), dim3(nb), dim3(256), 0, st, (const TT*)Y, ldy, bias, N, IH, IW, OH, \
                        OW, Cout, KH, KW, pad, xr, target, tfm, sws, dpre, gscale, gscale_dev)
-    if (dtype == RBVAE_F32) { if (small) RBVAE_COL2IM(float, unsigned); else RBVAE_COL2IM(float, long); }
+#define RBVAE_COL2IM_PIX(TT)                                                                                    \
+    hipLaunchKernelGGL((col2im_sigmoid_pix_k<TT>), dim3(nb), dim3(256), 0, st, (const TT*)Y, ldy, bias, N, IH, IW, OH, \
+                       OW, Cout, KH, KW, pad, xr, target, tfm, sws, dpre, gscale, gscale_dev)
+    if (pix) { if (dtype == RBVAE_F32) RBVAE_COL2IM_PIX(float); else RBVAE_COL2IM_PIX(bf16_t); }
+    else if (dtype == RBVAE_F32) { if (small) RBVAE_COL2IM(float, unsigned); else RBVAE_COL2IM(float, long); }
     else { if (small) RBVAE_COL2IM(bf16_t, unsigned); else RBVAE_COL2IM(bf16_t, long); }
+#undef RBVAE_COL2IM_PIX
 #undef RBVAE_COL2IM
     if (sse_mean)
         hipLaunchKernelGGL(sum_partials_k, dim3(1), dim3(1024), 0, st, ws, nb, 1.0f / (float)tot, sse_mean, 0);

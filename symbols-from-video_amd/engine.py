@@ -648,14 +648,20 @@ class Engine:
     # ---- backward --------------------------------------------------------------
     def backward(self, flat: torch.Tensor, gflat: torch.Tensor, sv: Saved, g_xr: Optional[torch.Tensor],
                  g_hs: Optional[torch.Tensor], g_z: Optional[torch.Tensor], g_e: Optional[torch.Tensor] = None,
-                 kl_weight: float = 0.0, kl_p: float = 0.5, g_hs_inplace: bool = False):
+                 kl_weight: float = 0.0, kl_p: float = 0.5, g_hs_inplace: bool = False, side_first=None):
         """Writes every parameter gradient into gflat (same layout as flat).
         g_xr: [S,T,C,H,W] upstream gradient of x_recon (None: use the fused dpre3 of forward()).
         g_hs / g_z: [S,T,L] upstream gradients of h_seq / z_seq (None = 0).
         g_e: upstream gradient of the conv logits (simple variant's second output).
         kl_weight: d(loss)/d(kl_mean) when the KL term was fused into forward().
-        g_hs_inplace: the caller gives g_hs away (the binarise backward accumulates into it)."""
+        g_hs_inplace: the caller gives g_hs away (the binarise backward accumulates into it).
+        side_first: optional callable issued on the side stream before anything else of this pass (the trainer's
+        loss bookkeeping: everything it reads exists once forward() is done)."""
         self._join()                       # side-stream work of forward() (after_hs)
+        if side_first is not None:
+            self._fork()
+            with self._on_side():
+                side_first()
         v = self.v
         N, S, T = sv.N, sv.S, sv.T
         H, W = sv.hw

@@ -80,15 +80,19 @@ class FusedTrainer:
         out = eng.forward(model._flat, x.view(2 * B, T, *x.shape[3:]), U, tau, False, self.r, bool(model.training), None,
                           seed=0, need_grad=True, target=x, recon_gscale=2.0 / numel, kl_p=self.p, after_hs=pair_term,
                           defer_losses=True, repack=True, frame_map=(B * T, T, T * chw, 2 * T * chw, chw))
-        eng.backward(model._flat, self.gflat, out["saved"], None, g_hs, None, kl_weight=self.beta_kl, kl_p=self.p,
-                     g_hs_inplace=True)
         sse_ws, nparts, inv_n = out["sse"]
         kl_parts, nkl, kl_scale = out["kl"]
-        # ... which also advances the device step counter and prepares Adam's bias corrections for _update()
         b1, b2 = self.betas
-        L.call("rbvae_combine_losses", sse_ws, nparts, inv_n, None, kl_parts, nkl, kl_scale, self._pair,
-               float(self.beta_kl), float(self.alpha), self.losses, self.step_dev, float(self.lr), float(b1),
-               float(b2), self.hyper)
+
+        def bookkeeping():
+            # [total, recon, kl, pair] from the partial sums; also advances the device step counter and prepares
+            # Adam's bias corrections for _update().  Runs on the side stream beside the backward pass.
+            L.call("rbvae_combine_losses", sse_ws, nparts, inv_n, None, kl_parts, nkl, kl_scale, self._pair,
+                   float(self.beta_kl), float(self.alpha), self.losses, self.step_dev, float(self.lr), float(b1),
+                   float(b2), self.hyper)
+
+        eng.backward(model._flat, self.gflat, out["saved"], None, g_hs, None, kl_weight=self.beta_kl, kl_p=self.p,
+                     g_hs_inplace=True, side_first=bookkeeping)
 
     def _update(self):
         b1, b2 = self.betas
