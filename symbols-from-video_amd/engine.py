@@ -235,6 +235,7 @@ class Engine:
         import os
         self.overlap = os.environ.get("RBVAE_OVERLAP", "1") == "1"
         self.pack_late_split = os.environ.get("RBVAE_PACK_LATE", "0") == "1"
+        self.early_reduce = os.environ.get("RBVAE_EARLY_REDUCE", "1") == "1"
         # RBVAE_STREAM_GEMM=1 sends the K = 64 products of the 3/4-channel ends to the row-streaming kernel
         # (rbvae_stream_gemm) instead of the tiled gather GEMM.  Bit-identical results; measured on the bench shapes
         # (tools/abl_stream.py): conv1 forward 17.5 -> 15.4-16.6 us, last-deconv backward (gate + column sums)
@@ -806,6 +807,14 @@ class Engine:
         # --- conv2
         self._wgrad(da2, sv.a1, self._conv_idx(N, h1, w1, h2, w2), P2, c2, c1, c2, c1, kk,
                     G(f"encoder_cnn.conv.{i1}.weight"), (c2, c1, kk), (kk * c1, 1, c1), tag=(N, "W2"))
+        if self.overlap and self.early_reduce:
+            # everything reducible so far (fc, conv3, conv2 slabs; the LSTM-side column sums) goes to the side stream
+            # now, beside the last data-gradient GEMM and conv1's weight gradient; only those two's reductions
+            # remain for the end of the pass
+            self._fork()
+            with self._on_side():
+                self._run_jobs()
+            self._jobs = JobList()
         da1 = tmp("da1", P1, c1)
         self._gemm(da2, self.W2d, da1, None, sv.a1, None, N, h2, w2, h2, w2, 1, h1, w1, 2, c2, c1, c2, c1, kk, "dgrad",
                    scale=gs, bias_grad=G(f"encoder_cnn.conv.{i0}.bias"), tag=(N, "da1"))
