@@ -10,6 +10,7 @@
 // Weight block layout (= the reference's registration order, per layer):
 //   w_ih [4L][L], w_hh [4L][L], b_ih [4L], b_hh [4L]      -> 8*L*L + 8*L floats per layer
 #include "common.h"
+#include <stdlib.h>
 
 namespace rbvae {
 
@@ -559,6 +560,62 @@ __global__ __launch_bounds__(256) void lstm_wgrad_tiled_k(const float* __restric
     }
 }
 
+// Weight gradients on the f32 matrix cores (v_mfma_f32_16x16x4_f32: an exact f32 fma chain).  One workgroup per
+// 16 x 16 tile of one (stack, layer, ih|hh) gradient [4L gate rows][L inputs + bias column]; its four waves take a
+// quarter of the S*T rows each, operands straight from global memory in MFMA layout (a lane's loads are all
+// independent: one batch per 16 rows), partial tiles meet in LDS in wave order.  The LDS-tiled kernel above spends
+// ~20 us on this at the bench shape (256 rows): it is all latency, and this form has a tenth of the dependent steps.
+__global__ __launch_bounds__(256) void lstm_wgrad_mfma_k(const float* __restrict__ dG, const float* __restrict__ hs_all,
+                                                         const float* __restrict__ hprev, float* __restrict__ gblk,
+                                                         const float* __restrict__ dG2, const float* __restrict__ hs_all2,
+                                                         const float* __restrict__ hprev2, float* __restrict__ gblk2,
+                                                         int S, int T, int L, int layers, int accumulate) {
+    typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+    __shared__ float part[4][256];
+    int l = blockIdx.z;
+    if (l >= layers) { l -= layers; dG = dG2; hs_all = hs_all2; hprev = hprev2; gblk = gblk2; }
+    const int hh = blockIdx.y;
+    const int ktiles = (L + 1 + 15) / 16;
+    const int j0 = (blockIdx.x / ktiles) * 16, k0 = (blockIdx.x % ktiles) * 16;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int i = lane & 15, g = lane >> 4;
+    const int R = S * T;
+    const float* gp = dG + (long)l * R * 4 * L + min(j0 + i, 4 * L - 1);
+    const float* xp = (hh ? hprev + (long)l * R * L : hs_all + (long)l * R * L) + min(k0 + i, L - 1);
+    const bool jv = j0 + i < 4 * L;
+    const int kcol = k0 + i;                       // < L: an input column, == L: the bias (ones) column, > L: padding
+    const int rq = (R + 3) / 4;                    // rows of this wave's quarter, in steps of 4
+    const int rbeg = w * rq, rend = min(R, rbeg + rq);
+    f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+    constexpr int UB = 16;
+    for (int r0 = rbeg; r0 < rend; r0 += 4 * UB) {
+        float a[UB], b[UB];
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+            const int r = r0 + 4 * u + g;
+            const int rc = min(r, R - 1);
+            const float av = gp[(long)rc * 4 * L], bv = xp[(long)rc * L];
+            const bool rv = r < rend;
+            a[u] = (rv && jv) ? av : 0.f;
+            b[u] = rv ? (kcol < L ? bv : (kcol == L ? 1.f : 0.f)) : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < UB; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u], b[u], acc, 0, 0, 0);
+    }
+    // D[gate row 4g + r][column i]
+#pragma unroll
+    for (int r = 0; r < 4; ++r) part[w][(4 * g + r) * 16 + i] = acc[r];
+    __syncthreads();
+    const int rr = threadIdx.x >> 4, cc = threadIdx.x & 15;
+    const int jrow = j0 + rr, k = k0 + cc;
+    if (jrow < 4 * L && k <= L) {
+        const float v = ((part[0][threadIdx.x] + part[1][threadIdx.x]) + part[2][threadIdx.x]) + part[3][threadIdx.x];
+        float* out = gblk + l * (8l * L * L + 8l * L);
+        float* dst = k < L ? out + (hh ? 4l * L * L : 0) + (long)jrow * L + k : out + 8l * L * L + (hh ? 4 * L : 0) + jrow;
+        *dst = accumulate ? *dst + v : v;
+    }
+}
+
 }  // namespace rbvae
 
 using namespace rbvae;
@@ -672,6 +729,14 @@ int rbvae_lstm_bwd_ex(const float* wblk, const float* acts, const float* cs, con
 static int launch_lstm_wgrad(const float* dG, const float* hs_all, const float* hprev, float* gblk, const float* dG2,
                              const float* hs_all2, const float* hprev2, float* gblk2, int S, int T, int L, int layers,
                              int accumulate, void* stream) {
+    static const int use_mfma = getenv("RBVAE_LSTM_WGRAD_MFMA") ? atoi(getenv("RBVAE_LSTM_WGRAD_MFMA")) : 1;
+    if (use_mfma) {
+        dim3 mgrid(cdiv(4 * L, 16) * cdiv(L + 1, 16), 2, dG2 ? 2 * layers : layers);
+        hipLaunchKernelGGL(lstm_wgrad_mfma_k, mgrid, dim3(256), 0, (hipStream_t)stream, dG, hs_all, hprev, gblk, dG2,
+                           hs_all2, hprev2, gblk2, S, T, L, layers, accumulate);
+        RBVAE_CHECK_LAUNCH("lstm_wgrad_mfma");
+        return RBVAE_OK;
+    }
     dim3 grid(cdiv(4 * L, LW_JT), 2, dG2 ? 2 * layers : layers);
     const size_t lds = (size_t)(LW_ROWS * LW_JT + LW_ROWS * (L + 1)) * sizeof(float);
     RBVAE_CHECK_ARG(lds <= 64 * 1024, "lstm_wgrad: L=%d too large", L);

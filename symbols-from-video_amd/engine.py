@@ -235,7 +235,10 @@ class Engine:
         import os
         self.overlap = os.environ.get("RBVAE_OVERLAP", "1") == "1"
         self.pack_late_split = os.environ.get("RBVAE_PACK_LATE", "0") == "1"
-        self.early_reduce = os.environ.get("RBVAE_EARLY_REDUCE", "1") == "1"
+        # default 14 = pair term + decoder weight gradients + their reductions (same-GPU sweep, ms/step: 14 0.547,
+        # 12 0.553, 6 0.554, 30 0.556, 4 0.556, 63 0.568, 0 0.591: the weight repack, the loss bookkeeping and the
+        # LSTM weight gradients are better left on the main stream)
+        self.side_mask = int(os.environ.get("RBVAE_SIDE", "14"))
         # RBVAE_STREAM_GEMM=1 sends the K = 64 products of the 3/4-channel ends to the row-streaming kernel
         # (rbvae_stream_gemm) instead of the tiled gather GEMM.  Bit-identical results; measured on the bench shapes
         # (tools/abl_stream.py): conv1 forward 17.5 -> 15.4-16.6 us, last-deconv backward (gate + column sums)
@@ -304,8 +307,8 @@ class Engine:
 
     def pack_begin(self, flat: torch.Tensor):
         first, early, _, _ = self._pack_split(flat)
-        self._fork(1)
-        with self._on_side(1):
+        self._fork(1, self.SIDE_PACK)
+        with self._on_side(1, self.SIDE_PACK):
             L.call("rbvae_run_jobs", early[0], early[1], 256)
         L.call("rbvae_run_jobs", first[0], first[1], 256)
 
@@ -313,8 +316,8 @@ class Engine:
         late = self._pack_split(flat)[2]
         if late[1] == 0:
             return
-        self._fork(1)
-        with self._on_side(1):
+        self._fork(1, self.SIDE_PACK)
+        with self._on_side(1, self.SIDE_PACK):
             L.call("rbvae_run_jobs", late[0], late[1], 256)
 
     def pack_end(self):
@@ -436,21 +439,30 @@ class Engine:
     # ---- side stream ------------------------------------------------------------------
     # The LSTM chains occupy 2B workgroups for ~25 us per stack; weight-gradient GEMMs that do not feed them are
     # issued on a side stream over exactly those windows (graph capture turns the fork/join into graph edges).
-    def _fork(self, which: int = 0):
+    # Which pieces of side work actually leave the main stream is a bit mask (RBVAE_SIDE, default below): every piece
+    # was A/B'd on one GPU -- full-chip side kernels beside full-chip main kernels only contend.
+    SIDE_PACK, SIDE_PAIR, SIDE_DEC_WGRAD, SIDE_DEC_REDUCE, SIDE_LSTM_WGRAD, SIDE_BOOK, SIDE_ENC_REDUCE = 1, 2, 4, 8, 16, 32, 64
+
+    def _side_on(self, bit: int) -> bool:
+        return self.overlap and (bit == 0 or bool(self.side_mask & bit))
+
+    def _fork(self, which: int = 0, bit: int = 0):
         """Side stream `which` picks up after everything queued so far on the current stream."""
-        if not self.overlap:
+        if not self._side_on(bit):
             return False
         if self._sides[which] is None:
             self._sides[which] = torch.cuda.Stream(device=self.device)
         self._sides[which].wait_stream(torch.cuda.current_stream())
         return True
 
-    def _on_side(self, which: int = 0):
+    def _on_side(self, which: int = 0, bit: int = 0):
         import contextlib
-        return torch.cuda.stream(self._sides[which]) if self.overlap else contextlib.nullcontext()
+        return torch.cuda.stream(self._sides[which]) if self._side_on(bit) else contextlib.nullcontext()
 
-    def _side_wait_main(self, which: int = 0):
-        if self.overlap:
+    def _side_wait_main(self, which: int = 0, bit: int = 0):
+        if self._side_on(bit):
+            if self._sides[which] is None:
+                self._sides[which] = torch.cuda.Stream(device=self.device)
             self._sides[which].wait_stream(torch.cuda.current_stream())
 
     def _join(self, which: int = 0):
@@ -570,8 +582,8 @@ class Engine:
                 L.call("rbvae_lstm_fwd", wenc, self.wT_enc, sv.hs_enc, sv.hp_enc, sv.acts_enc, sv.cs_enc, S, T, Ld, nl)
             hs = sv.hs_enc[nl]
             if after_hs is not None:
-                self._fork()
-                with self._on_side():
+                self._fork(0, self.SIDE_PAIR)
+                with self._on_side(0, self.SIDE_PAIR):
                     after_hs(hs)
             sv.z = sv.hs_dec[0].view(N, Ld)
             if defer_losses and kl_p is not None:
@@ -660,8 +672,8 @@ class Engine:
         loss bookkeeping: everything it reads exists once forward() is done)."""
         self._join()                       # side-stream work of forward() (after_hs)
         if side_first is not None:
-            self._fork()
-            with self._on_side():
+            self._fork(0, self.SIDE_BOOK)
+            with self._on_side(0, self.SIDE_BOOK):
                 side_first()
         v = self.v
         N, S, T = sv.N, sv.S, sv.T
@@ -723,10 +735,10 @@ class Engine:
             self._wgrad(df, sv.ds_pad, None, N, self.F3, self.Lp, self.F3, self.Lp, 1, G("decoder_cnn.fc.weight"),
                         (c3, g3, Ld), (self.Lp, c3 * self.Lp, 1), tag=(N, "Wdfc"))
 
-        self._fork()
-        with self._on_side():
+        self._fork(0, self.SIDE_DEC_WGRAD)
+        with self._on_side(0, self.SIDE_DEC_WGRAD):
             decoder_wgrads()
-            if self.overlap:
+            if self._side_on(self.SIDE_DEC_WGRAD) and self._side_on(self.SIDE_DEC_REDUCE):
                 # the decoder's slab / partial-sum reductions now, beside the LSTM chain, not at the end of the pass
                 self._run_jobs()
                 self._jobs = JobList()
@@ -779,8 +791,8 @@ class Engine:
             if g_e is not None:
                 de = de + g_e.reshape(N, Ld)
         # LSTM weight gradients (few workgroups, latency bound) ride the side stream beside the encoder CNN backward
-        self._side_wait_main()
-        with self._on_side():
+        self._side_wait_main(0, self.SIDE_LSTM_WGRAD)
+        with self._on_side(0, self.SIDE_LSTM_WGRAD):
             L.call("rbvae_lstm_wgrad_pair", dG, sv.hs_dec, sv.hp_dec, G("decoder_rnn.lstm.weight_ih_l0"),
                    dGe, sv.hs_enc, sv.hp_enc, G("encoder_rnn.lstm.weight_ih_l0"), S, T, Ld, nl, 0)
             self._colsum(F32, de, N, Ld, Ld, G("encoder_cnn.fc.bias"), tag=(N, "bfc"))
@@ -807,12 +819,12 @@ class Engine:
         # --- conv2
         self._wgrad(da2, sv.a1, self._conv_idx(N, h1, w1, h2, w2), P2, c2, c1, c2, c1, kk,
                     G(f"encoder_cnn.conv.{i1}.weight"), (c2, c1, kk), (kk * c1, 1, c1), tag=(N, "W2"))
-        if self.overlap and self.early_reduce:
+        if self._side_on(self.SIDE_ENC_REDUCE):
             # everything reducible so far (fc, conv3, conv2 slabs; the LSTM-side column sums) goes to the side stream
             # now, beside the last data-gradient GEMM and conv1's weight gradient; only those two's reductions
             # remain for the end of the pass
-            self._fork()
-            with self._on_side():
+            self._fork(0, self.SIDE_ENC_REDUCE)
+            with self._on_side(0, self.SIDE_ENC_REDUCE):
                 self._run_jobs()
             self._jobs = JobList()
         da1 = tmp("da1", P1, c1)
