@@ -234,7 +234,7 @@ class Engine:
         # everything in issue order on one stream)
         import os
         self.overlap = os.environ.get("RBVAE_OVERLAP", "1") == "1"
-        self.pack_late_split = os.environ.get("RBVAE_PACK_LATE", "0") == "1"
+        self.pack_late_split = os.environ.get("RBVAE_PACK_LATE", "0") == "1" or bool(int(os.environ.get("RBVAE_SIDE", "14")) & 128)
         # default 14 = pair term + decoder weight gradients + their reductions (same-GPU sweep, ms/step: 14 0.547,
         # 12 0.553, 6 0.554, 30 0.556, 4 0.556, 63 0.568, 0 0.591: the weight repack, the loss bookkeeping and the
         # LSTM weight gradients are better left on the main stream)
@@ -316,8 +316,9 @@ class Engine:
         late = self._pack_split(flat)[2]
         if late[1] == 0:
             return
-        self._fork(1, self.SIDE_PACK)
-        with self._on_side(1, self.SIDE_PACK):
+        bit = self.SIDE_PACK_LATE if (self.side_mask & self.SIDE_PACK_LATE) else self.SIDE_PACK
+        self._fork(1, bit)
+        with self._on_side(1, bit):
             L.call("rbvae_run_jobs", late[0], late[1], 256)
 
     def pack_end(self):
@@ -442,6 +443,7 @@ class Engine:
     # Which pieces of side work actually leave the main stream is a bit mask (RBVAE_SIDE, default below): every piece
     # was A/B'd on one GPU -- full-chip side kernels beside full-chip main kernels only contend.
     SIDE_PACK, SIDE_PAIR, SIDE_DEC_WGRAD, SIDE_DEC_REDUCE, SIDE_LSTM_WGRAD, SIDE_BOOK, SIDE_ENC_REDUCE = 1, 2, 4, 8, 16, 32, 64
+    SIDE_PACK_LATE = 128     # decoder / backward-only weight copies repacked beside the fc / LSTM chain of the forward pass
 
     def _side_on(self, bit: int) -> bool:
         return self.overlap and (bit == 0 or bool(self.side_mask & bit))
