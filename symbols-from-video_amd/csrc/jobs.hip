@@ -38,12 +38,29 @@ __device__ __forceinline__ void conv_pack_tile(const Job& j, float* tile) {
     for (unsigned t = blockIdx.x; t < tco * tci; t += gridDim.x) {
         const unsigned co0 = (t / tci) * CP_TCO, ci0 = (t % tci) * TCI;
         __syncthreads();
-        for (unsigned i = threadIdx.x; i < CP_TCO * row; i += 256) {
-            const unsigned r = i / row, e = i - r * row;
-            const unsigned c = e / kk;
-            float v = 0.f;
-            if (co0 + r < Co && ci0 + c < Ci) v = j.src[((size_t)(co0 + r) * Ci + ci0) * kk + e];
-            tile[r * pitch + e] = v;
+        // the tile's rows, six loads per thread in flight at a time (one load per iteration paid a memory round
+        // trip each: 18 of them per tile)
+        constexpr unsigned LB = 6;
+        for (unsigned i0 = threadIdx.x; i0 < CP_TCO * row; i0 += LB * 256) {
+            float v[LB];
+#pragma unroll
+            for (unsigned u = 0; u < LB; ++u) {
+                const unsigned i = i0 + u * 256;
+                const unsigned ic = i < CP_TCO * row ? i : 0;
+                const unsigned r = ic / row, e = ic - r * row;
+                const unsigned c = e / kk;
+                const bool ok = i < CP_TCO * row && co0 + r < Co && ci0 + c < Ci;
+                const float x = j.src[ok ? ((size_t)(co0 + r) * Ci + ci0) * kk + e : 0];
+                v[u] = ok ? x : 0.f;
+            }
+#pragma unroll
+            for (unsigned u = 0; u < LB; ++u) {
+                const unsigned i = i0 + u * 256;
+                if (i < CP_TCO * row) {
+                    const unsigned r = i / row, e = i - r * row;
+                    tile[r * pitch + e] = v[u];
+                }
+            }
         }
         __syncthreads();
         for (unsigned i = threadIdx.x; i < CP_TCO * row; i += 256) {

@@ -239,6 +239,10 @@ class Engine:
         # 12 0.553, 6 0.554, 30 0.556, 4 0.556, 63 0.568, 0 0.591: the weight repack, the loss bookkeeping and the
         # LSTM weight gradients are better left on the main stream)
         self.side_mask = int(os.environ.get("RBVAE_SIDE", "14"))
+        # Program order at a fork: the main stream's continuation is issued BEFORE the side work (the side stream
+        # already waits on the fork point).  Graph capture hands the forking node's queue to the branch created
+        # first; created second, the main chain paid the cross-queue hand-off (~10 us idle at every fork).
+        self.main_first = os.environ.get("RBVAE_MAIN_FIRST", "1") == "1"
         # RBVAE_STREAM_GEMM=1 sends the K = 64 products of the 3/4-channel ends to the row-streaming kernel
         # (rbvae_stream_gemm) instead of the tiled gather GEMM.  Bit-identical results; measured on the bench shapes
         # (tools/abl_stream.py): conv1 forward 17.5 -> 15.4-16.6 us, last-deconv backward (gate + column sums)
@@ -306,6 +310,9 @@ class Engine:
         return tab
 
     def pack_begin(self, flat: torch.Tensor):
+        if not self._side_on(self.SIDE_PACK) and not self.pack_late_split:
+            self.pack(flat)                 # nothing leaves the main stream: one launch for every copy
+            return
         first, early, _, _ = self._pack_split(flat)
         self._fork(1, self.SIDE_PACK)
         with self._on_side(1, self.SIDE_PACK):
@@ -583,10 +590,14 @@ class Engine:
             else:
                 L.call("rbvae_lstm_fwd", wenc, self.wT_enc, sv.hs_enc, sv.hp_enc, sv.acts_enc, sv.cs_enc, S, T, Ld, nl)
             hs = sv.hs_enc[nl]
+            pending_hs = None
             if after_hs is not None:
                 self._fork(0, self.SIDE_PAIR)
-                with self._on_side(0, self.SIDE_PAIR):
-                    after_hs(hs)
+                if self.main_first and self._side_on(self.SIDE_PAIR):
+                    pending_hs = hs
+                else:
+                    with self._on_side(0, self.SIDE_PAIR):
+                        after_hs(hs)
             sv.z = sv.hs_dec[0].view(N, Ld)
             if defer_losses and kl_p is not None:
                 nkl = L.query("rbvae_binarize_kl_nparts", N, Ld)
@@ -658,6 +669,9 @@ class Engine:
         else:
             L.call("rbvae_col2im_sigmoid", self.dt, Y, self.NY, P(f"decoder_cnn.deconv.{i2}.bias"), N, h1, w1, H, W,
                    self.out_ch, k, k, 1, sv.xr, None, None, None, None, 0.0, None)
+        if not v.simple_order and pending_hs is not None:
+            with self._on_side(0, self.SIDE_PAIR):
+                after_hs(pending_hs)
         return {"xr": sv.xr, "hs": hs, "z": sv.z.view(S, T, Ld), "e": sv.e, "kl": kl, "mse": mse, "sse": sse, "saved": sv}
 
     # ---- backward --------------------------------------------------------------
@@ -737,13 +751,29 @@ class Engine:
             self._wgrad(df, sv.ds_pad, None, N, self.F3, self.Lp, self.F3, self.Lp, 1, G("decoder_cnn.fc.weight"),
                         (c3, g3, Ld), (self.Lp, c3 * self.Lp, 1), tag=(N, "Wdfc"))
 
+        # The gather-index tables both streams' weight-gradient GEMMs read are built here, on the main stream before
+        # the fork (they are cached: built by whichever stream asked first, the other stream could otherwise read
+        # a table whose kernel it never waited for)
+        self._conv_idx(N, h1, w1, h2, w2)
+        self._conv_idx(N, h2, w2, h3, w3)
         self._fork(0, self.SIDE_DEC_WGRAD)
-        with self._on_side(0, self.SIDE_DEC_WGRAD):
-            decoder_wgrads()
-            if self._side_on(self.SIDE_DEC_WGRAD) and self._side_on(self.SIDE_DEC_REDUCE):
-                # the decoder's slab / partial-sum reductions now, beside the LSTM chain, not at the end of the pass
-                self._run_jobs()
-                self._jobs = JobList()
+
+        def issue_decoder_side():
+            early = self._side_on(self.SIDE_DEC_WGRAD) and self._side_on(self.SIDE_DEC_REDUCE)
+            main_jobs, self._jobs = self._jobs, JobList()
+            with self._on_side(0, self.SIDE_DEC_WGRAD):
+                decoder_wgrads()
+                if early:
+                    # the decoder's slab / partial-sum reductions right behind them, not at the end of the pass
+                    self._run_jobs()
+                else:
+                    main_jobs.rows += self._jobs.rows
+                    main_jobs.keep += self._jobs.keep
+            self._jobs = main_jobs
+
+        defer_side = self.main_first and self._side_on(self.SIDE_DEC_WGRAD)
+        if not defer_side:
+            issue_decoder_side()
         if self.fc_split > 1:
             dds = tmp("dds", self.fc_split, N, Ld, dtype=f32)
             L.call("rbvae_skinny_linear_parts", self.dt, df, self.WdfcT, None, dds, N, Ld, self.F3, self.F3, self.F3,
@@ -835,6 +865,8 @@ class Engine:
         # --- conv1 (1-tap GEMM over the saved im2col columns)
         self._wgrad(da1, sv.col1, None, P1, c1, self.K1, c1, self.K1, 1, G(f"encoder_cnn.conv.{i0}.weight"),
                     (c1, self.in_ch, kk), (self.K1, 1, self.in_ch), tag=(N, "W1"))
+        if defer_side:
+            issue_decoder_side()
         # every slab / partial-sum reduction of this pass in one launch, once the side stream has caught up
         self._join()
         self._run_jobs()
