@@ -247,6 +247,19 @@ int rbvae_lstm_fwd_ex(const float* wblk, const float* wT, float* hs_all, float* 
 int rbvae_lstm_bwd_ex(const float* wblk, const float* acts, const float* cs, const float* g_top_parts, int nparts,
                       long part_stride, float* dG, float* dx, void* cast_out, int cast_dtype, int cast_ld, int S, int T,
                       int L, int layers, void* stream);
+/* Encoder stack -> binary_concrete_logits -> decoder stack (percep_RBVAE_model.py:155-163) as ONE wavefront
+ * launch: the arithmetic of rbvae_lstm_fwd(enc) + rbvae_binarize_kl_fwd_parts + rbvae_lstm_fwd(dec), with the same
+ * optional slab input / cast output as the _ex forms.  hs_dec slot 0 receives z; kl_parts[s] (may be NULL) = KL sum
+ * of sequence s (S parts; mean = sum / (S*T)).  rbvae_lstm_pair_fwd_ok tells whether the shape is covered
+ * (L <= 32, L % 4 == 0, 2 * layers * roundup64(4L) <= 1024). */
+int rbvae_lstm_pair_fwd_ok(int T, int L, int layers);
+int rbvae_lstm_pair_fwd(const float* wblk_enc, const float* wT_enc, const float* wblk_dec, const float* wT_dec,
+                        float* hs_enc, float* hprev_enc, float* acts_enc, float* cs_enc, float* hs_dec,
+                        float* hprev_dec, float* acts_dec, float* cs_dec, const float* in_parts, int nparts,
+                        long part_stride, const float* U, float* y_soft, float* kl_parts, float tau, float noise_ratio,
+                        float noise_eps, int hard, float kl_p, float kl_eps, int kl_clamp, unsigned long long seed,
+                        const unsigned long long* seed_dev, void* cast_out, int cast_dtype, int cast_ld, int S, int T,
+                        int L, int layers, void* stream);
 int rbvae_lstm_wgrad(const float* dG, const float* hs_all, const float* hprev, float* gblk, int S, int T, int L,
                      int layers, int accumulate, void* stream);
 /* the same for two stacks of equal shape (the encoder and decoder LSTMs) in one launch */

@@ -67,6 +67,13 @@ __device__ __forceinline__ float block_sum(float v, float* red) {
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 
+// KL(Bernoulli(q) || Bernoulli(p)) per element, q = sigmoid(v) (percep_RBVAE_train.py:59-70); lp = log p, l1p = log(1-p)
+__device__ __forceinline__ float kl_elem(float v, float lp, float l1p, float eps, int clamp) {
+    float q = sigmoidf_(v);
+    if (clamp) q = fminf(fmaxf(q, eps), 1.0f - eps);
+    return q * (logf(q + eps) - lp) + (1.0f - q) * (logf((1.0f - q) + eps) - l1p);
+}
+
 // Counter-based uniform bits for dropout: one 32-bit draw per element index.
 // (squares-style mixing of (seed, index); statistical quality is ample for a keep-mask)
 __device__ __forceinline__ unsigned hash_u32(unsigned long long seed, unsigned long long idx) {

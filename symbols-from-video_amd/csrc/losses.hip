@@ -16,12 +16,7 @@ int fail(int code, const char* fmt, ...) {
 
 constexpr int RED_THREADS = 1024;
 
-// KL(Bernoulli(q) || Bernoulli(p)) per element, q = sigmoid(v) (percep_RBVAE_train.py:59-70)
-__device__ __forceinline__ float kl_elem(float v, float lp, float l1p, float eps, int clamp) {
-    float q = sigmoidf_(v);
-    if (clamp) q = fminf(fmaxf(q, eps), 1.0f - eps);
-    return q * (logf(q + eps) - lp) + (1.0f - q) * (logf((1.0f - q) + eps) - l1p);
-}
+// kl_elem: common.h
 // d kl_elem / d v
 __device__ __forceinline__ float kl_elem_grad(float v, float lp, float l1p, float eps, int clamp) {
     const float s = sigmoidf_(v);

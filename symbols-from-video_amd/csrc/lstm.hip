@@ -325,7 +325,7 @@ __global__ __launch_bounds__(1024) void lstm_fwd_wave_k(const float* __restrict_
             const float* gl = gates + l * 4 * L;
             const float ig = gl[j], fg = gl[L + j], gg = gl[2 * L + j], og = gl[3 * L + j];
             const float hp = t > 0 ? hbuf[((l + 1) * T + t - 1) * L + j] : 0.f;
-            c = fg * c + ig * gg;
+            c = fmaf(fg, c, ig * gg);        // explicit: the same rounding in every kernel that runs this cell
             const float h = og * fast_tanh(c);
             hbuf[((l + 1) * T + t) * L + j] = h;
             const long o = (((long)l * S + s) * T + t);
@@ -341,6 +341,158 @@ __global__ __launch_bounds__(1024) void lstm_fwd_wave_k(const float* __restrict_
             }
         }
         lds_barrier();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Encoder stack -> Binary-Concrete binarise -> decoder stack as ONE wavefront (percep_RBVAE_model.py:155-163):
+// 2*layers thread groups, group q works on time d - q at diagonal d; the encoder's top group turns its h_t into
+// z_t = binarise(h_t, U_t) in the same pointwise phase, so the decoder's bottom group reads it one diagonal later.
+// T + 2*layers - 1 dependent steps and one launch instead of two stacks of T + layers - 1 plus the binarise
+// kernel between them.  Arithmetic per element is that of lstm_fwd_wave_k and binarize_kl_fwd_parts_k (same
+// functions, same order): results are identical to the three-launch path (explicit fma in the cell update, so not even the
+// compiler's contraction choices differ).
+// ---------------------------------------------------------------------------------------------
+struct PairArgs {
+    const float *wblk_e, *wT_e, *wblk_d, *wT_d;
+    float *hs_e, *hp_e, *acts_e, *cs_e;          // encoder stack: hs [layers+1][S][T][L] (slot 0 = input), saved state
+    float *hs_d, *hp_d, *acts_d, *cs_d;          // decoder stack: slot 0 receives z
+    const float* in_parts; int nparts; long part_stride;     // encoder input as K-split slabs (or null)
+    const float* U; float* y_soft; float* kl_parts;          // uniform noise (null: counter hash), y, per-sequence KL sums
+    float tau, ratio, neps, lp, l1p, keps; int hard, clamp;
+    unsigned long long seed; const unsigned long long* seed_dev;
+    void* cast_out; int cast_bf16, cast_ld;                   // decoder top layer once more, cast / padded
+    int S, T, L, layers, G;
+};
+
+template <int LMAX, bool EXACT>
+__global__ __launch_bounds__(1024) void lstm_pair_fwd_k(const PairArgs p) {
+    const int L = EXACT ? LMAX : p.L;
+    const int T = p.T, S = p.S, layers = p.layers, G = p.G;
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* hbuf = sm;                                    // [2][layers+1][T][L]: stack, slot, time
+    float* gates = hbuf + 2 * (layers + 1) * T * L;      // [2*layers][4L] activated gates
+    float* nbuf = gates + 2 * layers * 4 * L;            // [T][L] noise term of the binarisation
+    float* red = nbuf + T * L;                           // [16] block reduction
+    const int q = threadIdx.x / G, j = threadIdx.x - q * G;         // global layer index, gate row
+    const int stack = q >= layers, l = q - (stack ? layers : 0);
+    const int s = blockIdx.x;
+    const bool row = j < 4 * L;
+    const bool is_g = j >= 2 * L && j < 3 * L;
+    float* hs_all = stack ? p.hs_d : p.hs_e;
+    float* hprev = stack ? p.hp_d : p.hp_e;
+    float* acts = stack ? p.acts_d : p.acts_e;
+    float* cs = stack ? p.cs_d : p.cs_e;
+    float* hb = hbuf + stack * (layers + 1) * T * L;     // this stack's slots
+    // ---- encoder input (plain or K-split slabs) and the noise term, staged by all threads
+    for (int i = threadIdx.x; i < T * L; i += blockDim.x) {
+        const long o = ((long)s * T) * L + i;
+        float v;
+        if (p.in_parts) {
+            v = p.in_parts[o];
+            for (int k = 1; k < p.nparts; ++k) v += p.in_parts[k * p.part_stride + o];
+            p.hs_e[o] = v;
+        } else {
+            v = p.hs_e[o];
+        }
+        hbuf[i] = v;
+        unsigned long long seed = p.seed;
+        if (p.seed_dev) seed += p.seed_dev[0] * 0x9E3779B97F4A7C15ull;
+        const float u = p.U ? p.U[o] : (float)(hash_u32(seed, (unsigned long long)o) >> 8) * (1.0f / 16777216.0f);
+        nbuf[i] = p.ratio * (logf(u + p.neps) - logf(1.0f - u + p.neps));
+    }
+    if (p.cast_out) {
+        const int pw = p.cast_ld - L;
+        for (int i = threadIdx.x; i < T * pw; i += blockDim.x) {
+            const long o = ((long)s * T + i / pw) * p.cast_ld + L + i % pw;
+            if (p.cast_bf16) ((bf16_t*)p.cast_out)[o] = 0; else ((float*)p.cast_out)[o] = 0.f;
+        }
+    }
+    const float* wblk = stack ? p.wblk_d : p.wblk_e;
+    const float* wT = stack ? p.wT_d : p.wT_e;
+    const float* wl = wblk + l * lstm_layer_floats(L);
+    float wih[LMAX], whh[LMAX];
+    float bsum = 0.f;
+    {
+        const int jc = row ? j : 0;
+        bsum = wl[8l * L * L + jc] + wl[8l * L * L + 4 * L + jc];
+        const float* pi = wT ? wT + (long)(l * 2) * L * 4 * L + jc : wl + jc * L;
+        const float* ph = wT ? pi + L * 4 * L : pi + 4 * L * L;
+        const int kstride = wT ? 4 * L : 1;
+#pragma unroll
+        for (int k = 0; k < LMAX; ++k) {
+            const int kk = (k < L ? k : L - 1) * kstride;
+            const float a = pi[kk], b = ph[kk];
+            wih[k] = k < L ? a : 0.f;
+            whh[k] = k < L ? b : 0.f;
+        }
+    }
+    float c = 0.f;
+    // every slot but the encoder input is read (times a zero factor) before it is written: keep them finite
+    for (int i = T * L + threadIdx.x; i < 2 * (layers + 1) * T * L; i += blockDim.x) hbuf[i] = 0.f;
+    __syncthreads();
+    const int ndiag = T + 2 * layers - 1;
+    for (int d = 0; d < ndiag; ++d) {
+        const int t = d - q;
+        const bool active = t >= 0 && t < T;
+        if (active && row) {
+            const float* xt = hb + (l * T + t) * L;
+            const float* hp = hb + ((l + 1) * T + (t > 0 ? t - 1 : 0)) * L;
+            const float hscale = t > 0 ? 1.f : 0.f;
+            float a0 = bsum, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+            float b0 = 0.f, b1 = 0.f, b2 = 0.f, b3 = 0.f;
+#pragma unroll
+            for (int k = 0; k < LMAX; k += 4) {
+                if (k < L) {
+                    const float4 xv = *(const float4*)(xt + k), hv = *(const float4*)(hp + k);
+                    a0 = fmaf(wih[k], xv.x, a0); a1 = fmaf(wih[k + 1], xv.y, a1);
+                    a2 = fmaf(wih[k + 2], xv.z, a2); a3 = fmaf(wih[k + 3], xv.w, a3);
+                    b0 = fmaf(whh[k], hv.x, b0); b1 = fmaf(whh[k + 1], hv.y, b1);
+                    b2 = fmaf(whh[k + 2], hv.z, b2); b3 = fmaf(whh[k + 3], hv.w, b3);
+                }
+            }
+            const float pre = ((a0 + a1) + (a2 + a3)) + hscale * ((b0 + b1) + (b2 + b3));
+            const float av = is_g ? fast_tanh(pre) : fast_sigmoid(pre);
+            gates[q * 4 * L + j] = av;
+            if (acts) acts[(((long)l * S + s) * T + t) * 4 * L + j] = av;
+        }
+        lds_barrier();
+        if (active && j < L) {
+            const float* gl = gates + q * 4 * L;
+            const float ig = gl[j], fg = gl[L + j], gg = gl[2 * L + j], og = gl[3 * L + j];
+            const float hpv = t > 0 ? hb[((l + 1) * T + t - 1) * L + j] : 0.f;
+            c = fmaf(fg, c, ig * gg);        // explicit: the same rounding in every kernel that runs this cell
+            const float h = og * fast_tanh(c);
+            hb[((l + 1) * T + t) * L + j] = h;
+            const long o = (((long)l * S + s) * T + t);
+            if (acts) {
+                cs[o * L + j] = c;
+                hprev[o * L + j] = hpv;
+            }
+            hs_all[(((long)(l + 1) * S + s) * T + t) * L + j] = h;
+            if (q == layers - 1) {
+                // binary_concrete_logits on the encoder's output (percep_RBVAE_model.py:17-44): z feeds the decoder stack
+                const long e = ((long)s * T + t) * L + j;
+                const float y = sigmoidf_((h + nbuf[t * L + j]) / p.tau);
+                const float zz = p.hard ? (y > 0.5f ? 1.0f : 0.0f) : y;
+                p.y_soft[e] = y;
+                p.hs_d[e] = zz;
+                hbuf[(layers + 1) * T * L + t * L + j] = zz;          // decoder stack, slot 0
+            }
+            if (p.cast_out && q == 2 * layers - 1) {
+                const long oc = ((long)s * T + t) * p.cast_ld + j;
+                if (p.cast_bf16) ((bf16_t*)p.cast_out)[oc] = f32_to_bf16(h); else ((float*)p.cast_out)[oc] = h;
+            }
+        }
+        lds_barrier();
+    }
+    if (p.kl_parts) {
+        // KL of this sequence's T*L codes (kl_binary_concrete on the sample, percep_RBVAE_train.py:528), off the
+        // dependent chain: one element per thread, fixed-order block sum
+        float a = 0.f;
+        for (int i = threadIdx.x; i < T * L; i += blockDim.x) a += kl_elem(hbuf[(layers + 1) * T * L + i], p.lp, p.l1p, p.keps, p.clamp);
+        const float tot = block_sum(a, red);
+        if (threadIdx.x == 0) p.kl_parts[s] = tot;
     }
 }
 
@@ -676,6 +828,51 @@ int rbvae_lstm_fwd_ex(const float* wblk, const float* wT, float* hs_all, float* 
     RBVAE_CHECK_ARG(!in_parts || (nparts >= 1 && part_stride >= (long)S * T * L), "lstm_fwd_ex: bad slabs");
     return lstm_fwd_impl(wblk, wT, hs_all, hprev, acts, cs, S, T, L, layers, in_parts, nparts, part_stride, cast_out,
                          cast_dtype, cast_ld, stream);
+}
+
+int rbvae_lstm_pair_fwd_ok(int T, int L, int layers) {
+    const int threads = ((4 * L + 63) / 64) * 64;
+    const size_t lds = (size_t)(2 * (layers + 1) * T * L + 2 * layers * 4 * L + T * L + 16) * sizeof(float);
+    return L <= 32 && L % 4 == 0 && 2 * layers * threads <= 1024 && lds <= 64 * 1024;
+}
+
+int rbvae_lstm_pair_fwd(const float* wblk_enc, const float* wT_enc, const float* wblk_dec, const float* wT_dec,
+                        float* hs_enc, float* hprev_enc, float* acts_enc, float* cs_enc, float* hs_dec,
+                        float* hprev_dec, float* acts_dec, float* cs_dec, const float* in_parts, int nparts,
+                        long part_stride, const float* U, float* y_soft, float* kl_parts, float tau, float noise_ratio,
+                        float noise_eps, int hard, float kl_p, float kl_eps, int kl_clamp, unsigned long long seed,
+                        const unsigned long long* seed_dev, void* cast_out, int cast_dtype, int cast_ld, int S, int T,
+                        int L, int layers, void* stream) {
+    RBVAE_CHECK_ARG(wblk_enc && wblk_dec && hs_enc && hs_dec && y_soft && S > 0 && T > 0 && L > 0 && layers > 0,
+                    "lstm_pair_fwd: bad arguments");
+    RBVAE_CHECK_ARG(rbvae_lstm_pair_fwd_ok(T, L, layers), "lstm_pair_fwd: T=%d L=%d layers=%d outside the fused kernel's range "
+                    "(rbvae_lstm_pair_fwd_ok)", T, L, layers);
+    RBVAE_CHECK_ARG((acts_enc == nullptr) == (cs_enc == nullptr) && (acts_enc == nullptr) == (hprev_enc == nullptr) &&
+                    (acts_dec == nullptr) == (acts_enc == nullptr) && (cs_dec == nullptr) == (acts_enc == nullptr) &&
+                    (hprev_dec == nullptr) == (acts_enc == nullptr), "lstm_pair_fwd: saved-state buffers must be given together");
+    RBVAE_CHECK_ARG(tau > 0.f && (!kl_parts || (kl_p > 0.f && kl_p < 1.f)), "lstm_pair_fwd: tau=%g kl_p=%g", tau, kl_p);
+    RBVAE_CHECK_ARG(!in_parts || (nparts >= 1 && part_stride >= (long)S * T * L), "lstm_pair_fwd: bad slabs");
+    RBVAE_CHECK_ARG(!cast_out || ((cast_dtype == RBVAE_F32 || cast_dtype == RBVAE_BF16) && cast_ld >= L),
+                    "lstm_pair_fwd: cast output dtype %d ld %d", cast_dtype, cast_ld);
+    PairArgs a;
+    a.wblk_e = wblk_enc; a.wT_e = wT_enc; a.wblk_d = wblk_dec; a.wT_d = wT_dec;
+    a.hs_e = hs_enc; a.hp_e = hprev_enc; a.acts_e = acts_enc; a.cs_e = cs_enc;
+    a.hs_d = hs_dec; a.hp_d = hprev_dec; a.acts_d = acts_dec; a.cs_d = cs_dec;
+    a.in_parts = in_parts; a.nparts = nparts; a.part_stride = part_stride;
+    a.U = U; a.y_soft = y_soft; a.kl_parts = kl_parts;
+    a.tau = tau; a.ratio = noise_ratio; a.neps = noise_eps; a.lp = kl_parts ? logf(kl_p) : 0.f;
+    a.l1p = kl_parts ? logf(1.0f - kl_p) : 0.f; a.keps = kl_eps; a.hard = hard; a.clamp = kl_clamp;
+    a.seed = seed; a.seed_dev = seed_dev;
+    a.cast_out = cast_out; a.cast_bf16 = cast_dtype == RBVAE_BF16; a.cast_ld = cast_ld;
+    const int threads = ((4 * L + 63) / 64) * 64;
+    a.S = S; a.T = T; a.L = L; a.layers = layers; a.G = threads;
+    const size_t lds = (size_t)(2 * (layers + 1) * T * L + 2 * layers * 4 * L + T * L + 16) * sizeof(float);
+    if (L == 32)
+        hipLaunchKernelGGL((lstm_pair_fwd_k<32, true>), dim3(S), dim3(2 * layers * threads), lds, (hipStream_t)stream, a);
+    else
+        hipLaunchKernelGGL((lstm_pair_fwd_k<32, false>), dim3(S), dim3(2 * layers * threads), lds, (hipStream_t)stream, a);
+    RBVAE_CHECK_LAUNCH("lstm_pair_fwd");
+    return RBVAE_OK;
 }
 
 static int lstm_bwd_impl(const float* wblk, const float* acts, const float* cs, const float* g_top, float* dG, float* dx,

@@ -258,6 +258,8 @@ class Engine:
         self.fc_split = want if (want > 1 and wave_ok and self.F3 % (want * ks_unit) == 0 and self.F3 >= 2048) else 1
         # ... and write the bf16 / padded copy of their output that the next GEMM reads (rbvae_cast_pad otherwise)
         self.lstm_cast = wave_ok and os.environ.get("RBVAE_LSTM_CAST", "1") == "1"
+        # ... and, in forward passes that run both stacks, go as one launch with the binarisation between them
+        self.lstm_pair = wave_ok and os.environ.get("RBVAE_LSTM_PAIR", "1") == "1"
         self._alloc_packed()
 
     # ---- packed weights -------------------------------------------------------
@@ -583,14 +585,38 @@ class Engine:
         r = noise_ratio if v.noise_ratio_arg else 1.0
         kl = self._E(1, dtype=torch.float32) if kl_p is not None else None
         wenc, wdec = P("encoder_rnn.lstm.weight_ih_l0"), P("decoder_rnn.lstm.weight_ih_l0")
-        if not v.simple_order:
+        pending_hs = None
+        fused_pair = (not v.simple_order and not encode_only and self.lstm_pair
+                      and bool(L.query("rbvae_lstm_pair_fwd_ok", T, Ld, nl)))
+        if fused_pair:
+            # encoder stack -> binarise (+ KL sums) -> decoder stack as one wavefront launch
+            hs = sv.hs_enc[nl]
+            sv.z = sv.hs_dec[0].view(N, Ld)
+            parts = None
+            if kl_p is not None:
+                parts = self._E(S, dtype=torch.float32)
+                kl = (parts, S, 1.0 / N) if defer_losses else kl
+            sv.ds_pad = self._E(N, self.Lp)
+            L.call("rbvae_lstm_pair_fwd", wenc, self.wT_enc, wdec, self.wT_dec, sv.hs_enc, sv.hp_enc, sv.acts_enc,
+                   sv.cs_enc, sv.hs_dec, sv.hp_dec, sv.acts_dec, sv.cs_dec, e_parts, self.fc_split, N * Ld, U, sv.y,
+                   parts, float(tau), float(r), v.eps, int(hard), float(kl_p if kl_p is not None else 0.5), 1e-8, 1,
+                   int(seed) * 8 + 5, self.seed_dev, sv.ds_pad, self.dt, self.Lp, S, T, Ld, nl)
+            if kl_p is not None and not defer_losses:
+                kl = (parts.sum() * (1.0 / N)).reshape(1)
+            if after_hs is not None:
+                self._fork(0, self.SIDE_PAIR)
+                if self.main_first and self._side_on(self.SIDE_PAIR):
+                    pending_hs = hs
+                else:
+                    with self._on_side(0, self.SIDE_PAIR):
+                        after_hs(hs)
+        elif not v.simple_order:
             if e_parts is not None:
                 L.call("rbvae_lstm_fwd_ex", wenc, self.wT_enc, sv.hs_enc, sv.hp_enc, sv.acts_enc, sv.cs_enc, S, T, Ld,
                        nl, e_parts, self.fc_split, N * Ld, None, 0, 0)
             else:
                 L.call("rbvae_lstm_fwd", wenc, self.wT_enc, sv.hs_enc, sv.hp_enc, sv.acts_enc, sv.cs_enc, S, T, Ld, nl)
             hs = sv.hs_enc[nl]
-            pending_hs = None
             if after_hs is not None:
                 self._fork(0, self.SIDE_PAIR)
                 if self.main_first and self._side_on(self.SIDE_PAIR):
@@ -628,7 +654,7 @@ class Engine:
             L.call("rbvae_lstm_fwd", wdec, self.wT_dec, sv.hs_dec, sv.hp_dec, sv.acts_dec, sv.cs_dec, S, T, Ld, nl)
         ds = sv.hs_dec[nl]
         # decoder CNN
-        if not (self.lstm_cast and not v.simple_order):
+        if not ((self.lstm_cast or fused_pair) and not v.simple_order):
             sv.ds_pad = self._E(N, self.Lp)
             L.call("rbvae_cast_pad", self.dt, ds, sv.ds_pad, N, Ld, self.Lp)
         if repack:
@@ -669,7 +695,7 @@ class Engine:
         else:
             L.call("rbvae_col2im_sigmoid", self.dt, Y, self.NY, P(f"decoder_cnn.deconv.{i2}.bias"), N, h1, w1, H, W,
                    self.out_ch, k, k, 1, sv.xr, None, None, None, None, 0.0, None)
-        if not v.simple_order and pending_hs is not None:
+        if pending_hs is not None:
             with self._on_side(0, self.SIDE_PAIR):
                 after_hs(pending_hs)
         return {"xr": sv.xr, "hs": hs, "z": sv.z.view(S, T, Ld), "e": sv.e, "kl": kl, "mse": mse, "sse": sse, "saved": sv}

@@ -409,3 +409,54 @@ def test_split_fc_slabs_feed_the_lstm_kernels(sfv):
         hs = torch.zeros(2, 2, 3, 64, device="cuda")
         sfv._lib.call("rbvae_lstm_fwd_ex", torch.zeros(8 * 64 * 64 + 8 * 64, device="cuda"), None, hs, None, None, None, 2, 3,
                       64, 1, torch.zeros(2, 6, 64, device="cuda"), 2, 6 * 64, None, 0, 0)
+
+
+@pytest.mark.parametrize("L,layers,S,T,hard", [(32, 4, 5, 8, 0), (32, 2, 3, 5, 1), (24, 2, 4, 9, 0)])
+def test_lstm_pair_forward_equals_three_launches(sfv, L, layers, S, T, hard):
+    """rbvae_lstm_pair_fwd (encoder stack -> binarise -> decoder stack, one wavefront) against rbvae_lstm_fwd +
+    rbvae_binarize_kl_fwd_parts + rbvae_lstm_fwd: every saved tensor to f32 rounding (2e-6), hard codes equal
+    except where y sits within rounding of 0.5."""
+    assert sfv._lib.query("rbvae_lstm_pair_fwd_ok", T, L, layers)
+    g = torch.Generator().manual_seed(40 + L + layers)
+    N = S * T
+    per = layers * (8 * L * L + 8 * L)
+    we, wd = (torch.randn(per, generator=g) * 0.3).cuda(), (torch.randn(per, generator=g) * 0.3).cuda()
+    x = torch.randn(S, T, L, generator=g).cuda()
+    U = torch.rand(N, L, generator=g).cuda()
+    tau, r, p = 0.6, 0.3, 0.1
+
+    def bufs():
+        hs = torch.zeros(layers + 1, S, T, L, device="cuda")
+        return (hs, torch.empty(layers, S, T, L, device="cuda"), torch.empty(layers, S, T, 4 * L, device="cuda"),
+                torch.empty(layers, S, T, L, device="cuda"))
+    # three launches
+    he, pe, ae, ce = bufs(); hd, pd, ad, cd = bufs()
+    he[0] = x
+    y0 = torch.empty(N, L, device="cuda")
+    nkl = sfv._lib.query("rbvae_binarize_kl_nparts", N, L)
+    parts0 = torch.empty(nkl, device="cuda")
+    sfv._lib.call("rbvae_lstm_fwd", we, None, he, pe, ae, ce, S, T, L, layers)
+    sfv._lib.call("rbvae_binarize_kl_fwd_parts", he[layers].contiguous(), U, y0, hd[0], parts0, N, L, tau, r, 1e-8, hard, p,
+                  1e-8, 1, 0, None)
+    pad0 = torch.zeros(N, 64, dtype=torch.bfloat16, device="cuda")
+    sfv._lib.call("rbvae_lstm_fwd_ex", wd, None, hd, pd, ad, cd, S, T, L, layers, None, 1, 0, pad0, 1, 64)
+    # one launch
+    he1, pe1, ae1, ce1 = bufs(); hd1, pd1, ad1, cd1 = bufs()
+    he1[0] = x
+    y1 = torch.empty(N, L, device="cuda")
+    parts1 = torch.empty(S, device="cuda")
+    pad1 = torch.full((N, 64), 3.0, dtype=torch.bfloat16, device="cuda")
+    sfv._lib.call("rbvae_lstm_pair_fwd", we, None, wd, None, he1, pe1, ae1, ce1, hd1, pd1, ad1, cd1, None, 1, 0, U, y1, parts1,
+                  tau, r, 1e-8, hard, p, 1e-8, 1, 0, None, pad1, 1, 64, S, T, L, layers)
+    names = "hs_enc hprev_enc acts_enc cs_enc hs_dec hprev_dec acts_dec cs_dec y_soft cast".split()
+    pairs = ((he, he1), (pe, pe1), (ae, ae1), (ce, ce1), (hd, hd1), (pd, pd1), (ad, ad1), (cd, cd1), (y0, y1), (pad0, pad1))
+    for nm, (a, b) in zip(names, pairs):
+        if hard and nm in ("hs_dec", "hprev_dec", "acts_dec", "cs_dec", "cast"):
+            continue                    # downstream of the hard codes: compared through the codes below
+        d = (a.float() - b.float()).abs().max().item()
+        assert d <= (1e-2 if nm == "cast" else 2e-6), (nm, d)
+    if hard:
+        assert (hd[0] != hd1[0]).float().mean().item() < 2e-3        # codes: only |y - 0.5| ~ 1e-7 cases may differ
+    assert abs(parts0.sum().item() - parts1.sum().item()) < 1e-4 * max(1.0, abs(parts0.sum().item()))
+    # shapes outside the fused kernel are refused
+    assert not sfv._lib.query("rbvae_lstm_pair_fwd_ok", 8, 64, 2)
