@@ -197,6 +197,9 @@ int rbvae_im2col(int dtype, const float* src, long sn, long sc, long sh, long sw
  * squared error stay in ws for rbvae_combine_losses to finish (one launch fewer per training step). */
 size_t rbvae_col2im_ws_floats(void);
 int rbvae_col2im_nparts(long n_out);
+/* 1 when the call (with target, ws and a 16-byte aligned dpre) also leaves per-block column sums of dpre -- the
+ * last deconv's bias gradient -- at ws[nparts + 4*b + c], b < nparts, c < Cout (Cout <= 4, < 2^31 outputs). */
+int rbvae_col2im_has_dcol(int N, int IH, int IW, int ldy, int OH, int OW, int Cout);
 int rbvae_col2im_sigmoid(int dtype, const void* Y, int ldy, const float* bias, int N, int IH, int IW, int OH,
                          int OW, int Cout, int KH, int KW, int pad, float* xr, const float* target,
                          float* sse_mean, float* ws, float* dpre, float gscale, const float* gscale_dev,

@@ -254,6 +254,7 @@ __global__ __launch_bounds__(256) void col2im_sigmoid_pix_k(
     float gsc = gscale;
     if (gs_dev) gsc *= gs_dev[0];
     const unsigned plane = (unsigned)OH * OW;
+    float dsum[4] = {0.f, 0.f, 0.f, 0.f};
     for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < npix; i += gridDim.x * 256u) {
         const unsigned r = i / (unsigned)OW, ow = i - r * (unsigned)OW;
         const unsigned n = r / (unsigned)OH, oh = r - n * (unsigned)OH;
@@ -293,11 +294,22 @@ __global__ __launch_bounds__(256) void col2im_sigmoid_pix_k(
 #pragma unroll
                 for (int c = 0; c < 4; ++c)
                     if (c < Cout) dp[c] = d4[c];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) dsum[c] += d4[c];
         }
     }
     if (sse_ws) {
         const float tot_b = block_sum(sse, red);
         if (threadIdx.x == 0) sse_ws[blockIdx.x] = tot_b;
+        if (dpre) {
+            // per-block column sums of dpre (the last deconv's bias gradient) behind the gridDim.x squared-error sums:
+            // sse_ws[gridDim.x + 4*block + c]
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const float t = block_sum(dsum[c], red);
+                if (threadIdx.x == 0) sse_ws[gridDim.x + 4 * blockIdx.x + c] = t;
+            }
+        }
     }
 }
 __global__ __launch_bounds__(1024) void sum_partials_k(const float* __restrict__ ws, int n, float scale,
@@ -560,8 +572,21 @@ int rbvae_im2col_frames(int dtype, const float* src, int fd1, int fd2, long fs0,
                        pad, Kpad, col, stream);
 }
 
-size_t rbvae_col2im_ws_floats(void) { return 4096; }
+size_t rbvae_col2im_ws_floats(void) { return 5 * 4096; }
 int rbvae_col2im_nparts(long n_out) { return grid_for(n_out, 256, 4096); }
+
+static bool col2im_pix_ok(bool small, int Cout) {
+    static const int pix_on = getenv("RBVAE_COL2IM_PIX") ? atoi(getenv("RBVAE_COL2IM_PIX")) : 1;
+    return pix_on && small && Cout <= 4;
+}
+
+/* 1 when rbvae_col2im_sigmoid (with target, ws and a 16-byte aligned dpre) also leaves the per-block column sums
+ * of dpre at ws[nparts + 4*b + c] (the pixel-major kernel: Cout <= 4 and fewer than 2^31 outputs). */
+extern "C" int rbvae_col2im_has_dcol(int N, int IH, int IW, int ldy, int OH, int OW, int Cout) {
+    const long tot = (long)N * OH * OW * Cout;
+    const bool small = tot < (1l << 31) - (1l << 20) && (long)N * IH * IW * ldy < (1l << 31);
+    return col2im_pix_ok(small, Cout) ? 1 : 0;
+}
 
 static int col2im_impl(int dtype, const void* Y, int ldy, const float* bias, int N, int IH, int IW, int OH,
                        int OW, int Cout, int KH, int KW, int pad, float* xr, const float* target, FrameMap tfm,
@@ -580,8 +605,7 @@ static int col2im_impl(int dtype, const void* Y, int ldy, const float* bias, int
     hipStream_t st = (hipStream_t)stream;
     const bool small = tot < (1l << 31) - (1l << 20) && (long)N * IH * IW * ldy < (1l << 31) &&
                        frame_span(tfm, N) + (long)Cout * OH * OW < (1l << 31);
-    static const int pix_on = getenv("RBVAE_COL2IM_PIX") ? atoi(getenv("RBVAE_COL2IM_PIX")) : 1;
-    const bool pix = pix_on && small && Cout <= 4 && (!dpre || (uintptr_t)dpre % 16 == 0);
+    const bool pix = col2im_pix_ok(small, Cout) && (!dpre || (uintptr_t)dpre % 16 == 0);
 #define RBVAE_COL2IM(TT, II)                                                                                       \
     hipLaunchKernelGGL((col2im_sigmoid_k<TT, II>), dim3(nb), dim3(256), 0, st, (const TT*)Y, ldy, bias, N, IH, IW, OH, \
                        OW, Cout, KH, KW, pad, xr, target, tfm, sws, dpre, gscale, gscale_dev)

@@ -184,7 +184,7 @@ class Saved:
     """Activations one forward call keeps for its backward."""
     __slots__ = ("N", "S", "T", "hw", "train", "tau", "hard", "col1", "a1", "a2", "a3", "e", "hs_enc", "hp_enc",
                  "acts_enc", "cs_enc", "y", "z", "hs_dec", "hp_dec", "acts_dec", "cs_dec", "ds_pad", "f", "d1", "d2",
-                 "xr", "gate_scale", "dpre3")
+                 "xr", "gate_scale", "dpre3", "b3_parts")
 
 
 class Engine:
@@ -677,14 +677,20 @@ class Engine:
         mse = None
         sse = None
         sv.dpre3 = None
+        sv.b3_parts = None
         if target is not None:
-            ws = self._E(L.query("rbvae_col2im_ws_floats"), dtype=torch.float32)
+            # persistent (one fused forward is in flight at a time): the backward pass's job table points into it
+            ws = self._buf((N, "col2im_ws"), L.query("rbvae_col2im_ws_floats"))
             if defer_losses:    # per-block partial sums stay in ws; rbvae_combine_losses finishes the mean
                 sse = (ws, L.query("rbvae_col2im_nparts", sv.xr.numel()), 1.0 / sv.xr.numel())
             else:
                 mse = self._E(1, dtype=torch.float32)
             if need_grad:
                 sv.dpre3 = self._E(N, H, W, self.out_ch, dtype=torch.float32)
+                if L.query("rbvae_col2im_has_dcol", N, h1, w1, self.NY, H, W, self.out_ch):
+                    # the kernel leaves dpre3's per-block column sums (the last deconv's bias gradient) behind the
+                    # squared-error sums in ws
+                    sv.b3_parts = (ws, L.query("rbvae_col2im_nparts", sv.xr.numel()))
             if frame_map is None:
                 L.call("rbvae_col2im_sigmoid", self.dt, Y, self.NY, P(f"decoder_cnn.deconv.{i2}.bias"), N, h1, w1, H, W,
                        self.out_ch, k, k, 1, sv.xr, target.contiguous(), mse, ws, sv.dpre3, float(recon_gscale), None)
@@ -761,7 +767,12 @@ class Engine:
 
         # ... then its weight / bias gradients, beside the LSTM chain when overlap is on
         def decoder_wgrads():
-            self._colsum(F32, dpre3, N * H * W, oc, oc, G(f"decoder_cnn.deconv.{i2}.bias"), tag=(N, "b3"))
+            if g_xr is None and sv.b3_parts is not None:
+                ws_b3, nb3 = sv.b3_parts
+                self._jobs.add(JOB_ROWS, ws_b3[nb3:], G(f"decoder_cnn.deconv.{i2}.bias"), (1, 1, oc), (0, 0, 1), nslab=nb3,
+                               slab=4)
+            else:
+                self._colsum(F32, dpre3, N * H * W, oc, oc, G(f"decoder_cnn.deconv.{i2}.bias"), tag=(N, "b3"))
             self._wgrad(sv.d2, col3, None, P1, c1, self.K3, c1, self.K3, 1, G(f"decoder_cnn.deconv.{i2}.weight"),
                         (c1, oc, kk), (self.K3, 1, oc), tag=(N, "V3"))
             self._wgrad(sv.d1, dd2, self._conv_idx(N, h1, w1, h2, w2), P2, c2, c1, c2, c1, kk,
