@@ -299,17 +299,27 @@ __global__ __launch_bounds__(256) void col2im_sigmoid_pix_k(
         }
     }
     if (sse_ws) {
-        const float tot_b = block_sum(sse, red);
-        if (threadIdx.x == 0) sse_ws[blockIdx.x] = tot_b;
-        if (dpre) {
-            // per-block column sums of dpre (the last deconv's bias gradient) behind the gridDim.x squared-error sums:
-            // sse_ws[gridDim.x + 4*block + c]
+        // squared-error sum and the four column sums of dpre in ONE pass: wave shuffles, then the four waves' values
+        // meet in LDS in wave order (fixed order: reproducible); five separate block sums cost ten barriers
+        __shared__ float red5[4][5];
+        float vals[5] = {sse, dsum[0], dsum[1], dsum[2], dsum[3]};
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const float t = block_sum(dsum[c], red);
-                if (threadIdx.x == 0) sse_ws[gridDim.x + 4 * blockIdx.x + c] = t;
-            }
+        for (int k = 0; k < 5; ++k) vals[k] = wave_sum(vals[k]);
+        const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+        if (lane == 0) {
+#pragma unroll
+            for (int k = 0; k < 5; ++k) red5[wid][k] = vals[k];
         }
+        __syncthreads();
+        if (threadIdx.x < 5) {
+            const int k = threadIdx.x;
+            const float t = ((red5[0][k] + red5[1][k]) + red5[2][k]) + red5[3][k];
+            // sse_ws[block] = squared-error sum; behind the gridDim.x of those, per-block column sums of dpre (the
+            // last deconv's bias gradient): sse_ws[gridDim.x + 4*block + c]
+            if (k == 0) sse_ws[blockIdx.x] = t;
+            else if (dpre) sse_ws[gridDim.x + 4 * blockIdx.x + (k - 1)] = t;
+        }
+        (void)red;
     }
 }
 __global__ __launch_bounds__(1024) void sum_partials_k(const float* __restrict__ ws, int n, float scale,
