@@ -106,6 +106,10 @@ def roofline_leg(trainer, item, steps, tname):
     eng.overlap = False
     trainer.instrument = True
     try:
+        for _ in range(2):                   # the eager one-stream path's own first-use work (job tables, buffers)
+            trainer.step(item, TAU)
+        torch.cuda.synchronize()
+        timers.clear()
         for _ in range(steps):
             # Hold the stream behind a ~20 ms device-side sleep while the host enqueues the whole step: the GPU then
             # runs the launches and event records back to back, so an event pair brackets the kernel and not the
