@@ -297,6 +297,13 @@ int rbvae_combine_losses(const float* sse_ws, int nparts, float inv_n, const flo
  * latent[n][c][h][w] f32 = scale * (mean + exp(0.5*clamp(logvar,-30,20)) * eps); eps NULL = posterior mode. */
 int rbvae_groupnorm_swish(int dtype, const void* x, void* y, const float* gamma, const float* beta, float* stats_ws,
                           int N, int HW, int C, int ldx, int ldy, int groups, float eps, int swish, void* stream);
+/* The same with a workspace of rbvae_groupnorm_ws_floats(...) floats: statistics then come from whole pixel rows
+ * (16-byte loads, per-block (mean, M2) merged by the parallel-variance formula) instead of one workgroup walking
+ * an (image, group) twice; needs C % 8 == 0 (bf16) / C % 4 == 0 (f32) and 16-byte aligned rows, else falls back. */
+size_t rbvae_groupnorm_ws_floats(int dtype, int N, int HW, int C, int groups);
+int rbvae_groupnorm_swish_ws(int dtype, const void* x, void* y, const float* gamma, const float* beta, float* stats_ws,
+                             size_t ws_floats, int N, int HW, int C, int ldx, int ldy, int groups, float eps, int swish,
+                             void* stream);
 int rbvae_softmax_rows(int dtype, const void* x, void* y, long rows, int n, int ld, void* stream);
 int rbvae_transpose2d(int dtype, const void* in, void* out, int R, int C, int ldi, int ldo, void* stream);
 int rbvae_posterior_sample(int dtype, const void* moments, int ld, const float* eps, float* latent, int N, int Z,

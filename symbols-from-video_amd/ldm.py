@@ -187,8 +187,9 @@ class LDMEncoder(nn.Module):
     def _gn(self, name, x, N, HW, C, swish=True):
         dt = self._packed[1]
         y = torch.empty_like(x)
-        ws = torch.empty(2 * N * 32, dtype=torch.float32, device=x.device)
-        L.call("rbvae_groupnorm_swish", dt, x, y, self._p(f"{name}.weight"), self._p(f"{name}.bias"), ws, N, HW, C,
+        nws = L.query("rbvae_groupnorm_ws_floats", dt, N, HW, C, 32)
+        ws = torch.empty(nws, dtype=torch.float32, device=x.device)
+        L.call("rbvae_groupnorm_swish_ws", dt, x, y, self._p(f"{name}.weight"), self._p(f"{name}.bias"), ws, nws, N, HW, C,
                x.shape[1], y.shape[1], 32, 1e-6, int(swish))
         return y
 
