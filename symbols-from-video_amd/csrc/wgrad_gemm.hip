@@ -44,6 +44,19 @@ template <int RB> __device__ __forceinline__ int tr_swz(int row) {
     else return (((row >> 1) & 1) | (((row >> 3) & 1) << 1)) << 1;                // 128-B rows: 4 pairs
 }
 
+// build-time experiment switches (tools/ab_variants.sh)
+#ifndef WG_SCHED
+#define WG_SCHED 0        // 1: scheduling barriers around the MFMA groups (as gather_gemm_k has them)
+#endif
+#ifndef WG_DEPHASE
+#define WG_DEPHASE 0      // 1: the two waves of a SIMD stage the next K step at different points of the step
+#endif
+#if WG_SCHED
+#define WG_SB() __builtin_amdgcn_sched_barrier(0)
+#else
+#define WG_SB() do {} while (0)
+#endif
+
 constexpr int WG_BM = 128;      // co per workgroup
 constexpr int WG_MAXP = 4096;   // pixels of one K-slice (their gather indices live in LDS)
 
@@ -265,22 +278,28 @@ __global__ __launch_bounds__(512, WG_NS == 2 ? 2 : 1) void wgrad_gemm_k(const Wg
             if (WG_NS - 1 < nsteps) stage_next();
             int cbuf = 0;
             read_half(lds0, 0, a0l, a0h, b0l, b0h);
+            const bool late = WG_DEPHASE && w >= 4;
             for (int s = 0; s < nsteps; ++s) {
                 const unsigned lcur = lds0 + cbuf * STAGE;
                 cbuf = (cbuf + 1 == WG_NS) ? 0 : cbuf + 1;
                 read_half(lcur, 1, a1l, a1h, b1l, b1h);
                 landed(Younger{}, a0l, a0h, b0l, b0h, fa, fb);        // half 0 landed, half 1 in flight
+                WG_SB();
                 mma_half(fa, fb);
+                WG_SB();
                 // half 1 landed (its reads were issued a whole MFMA group ago).  One wait site per register
                 // set keeps the compiler from merging two tied asm statements through register copies that
                 // would read a fragment before its wait.
                 landed(None{}, a1l, a1h, b1l, b1h, fa, fb);
                 if (s + 1 < nsteps) {
                     wait_stage(nsteps - s - 2 >= WG_NS - 2);
-                    if (s + WG_NS < nsteps) stage_next();
+                    if (!late && s + WG_NS < nsteps) stage_next();
                     read_half(lds0 + cbuf * STAGE, 0, a0l, a0h, b0l, b0h);
                 }
+                WG_SB();
                 mma_half(fa, fb);
+                WG_SB();
+                if (late && s + 1 < nsteps && s + WG_NS < nsteps) stage_next();
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // nothing is in flight here; keeps the ISA check linear
         }

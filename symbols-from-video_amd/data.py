@@ -132,11 +132,20 @@ class DeviceStatePairDataset:
     def __len__(self):
         return self.num_items
 
-    def batch(self, item_indices) -> torch.Tensor:
-        """[B,2,T,C,H,W] on the device (one gather; the reference's DataLoader + .to(device), :509-518)."""
+    def batch(self, item_indices, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """[B,2,T,C,H,W] on the device (one gather; the reference's DataLoader + .to(device), :509-518).
+        `out`: gather in place into an existing [B,2,T,C,H,W] tensor -- FusedTrainer.input_buffer(), which the
+        captured training step reads directly, so a step moves the batch exactly once."""
         ii = torch.as_tensor(item_indices, dtype=torch.long, device=self.device)
         rows = self.index[ii]                                    # [B,2,T]
-        return self.table[rows.reshape(-1)].reshape(*rows.shape, *self.table.shape[1:])
+        shape = (*rows.shape, *self.table.shape[1:])
+        if out is None:
+            return self.table[rows.reshape(-1)].reshape(shape)
+        if tuple(out.shape) != shape or out.dtype != self.table.dtype or out.device != self.table.device or \
+                not out.is_contiguous():
+            raise ValueError(f"out must be a contiguous {self.table.dtype} tensor of shape {shape} on {self.table.device}")
+        torch.index_select(self.table, 0, rows.reshape(-1), out=out.view(-1, *self.table.shape[1:]))
+        return out
 
     def __getitem__(self, idx) -> torch.Tensor:
         return self.batch([idx])[0]

@@ -34,3 +34,38 @@ def test_batched_consistency_equals_per_frame_loop():
     assert abs(avg - ravg) < 1e-12 and np.allclose(pct, rpct)
     b = ds.batch([0, 1])
     assert b.is_cuda and b.shape == (2, 2, 3, 4, *hw)
+
+
+def test_batch_gathers_into_the_trainer_input_buffer():
+    """DeviceStatePairDataset.batch(out=trainer.input_buffer(...)) + trainer.step(that buffer): the same step as
+    with a freshly gathered batch (which step() copies into the buffer)."""
+    import random
+    import sfv_amd as sfv
+    from importlib import import_module
+    FusedTrainer = import_module("symbols-from-video_amd.trainer").FusedTrainer
+    data = import_module("symbols-from-video_amd.data")
+    g = torch.Generator().manual_seed(3)
+    emb = torch.randn(60, 4, 16, 16, generator=g)
+    segments = [(0, 20), (20, 40), (40, 60)]
+    random.seed(5)
+    ds = data.DeviceStatePairDataset(emb, segments, mode="train", device="cuda")
+    idx = [0, 2, 3]
+    ref = ds.batch(idx)
+    assert ref.shape == (3, 2, 3, 4, 16, 16)
+    U = torch.rand(2, 3 * 3, 32, generator=g).cuda()
+    res = []
+    for in_place in (False, True):
+        torch.manual_seed(8)
+        m = sfv.Seq2SeqBinaryVAE(4, 4, 32, 32, variant="percep", input_hw=(16, 16), compute_dtype="f32").cuda().eval()
+        tr = FusedTrainer(m, device_noise=False, use_graph=True)
+        if in_place:
+            x = ds.batch(idx, out=tr.input_buffer(3, 3, 4, 16, 16))
+            assert x.data_ptr() == tr.input_buffer(3, 3, 4, 16, 16).data_ptr() and torch.equal(x, ref)
+        else:
+            x = ref
+        for _ in range(2):
+            losses = tr.step(x, 0.8, U=U).clone()
+        res.append((losses, m._flat.clone()))
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+    with pytest.raises(ValueError):
+        ds.batch(idx, out=torch.empty(2, 2, 3, 4, 16, 16, device="cuda"))
