@@ -316,6 +316,7 @@ int rbvae_dbg_mfma_f32(const float* A, const float* B, float* D, void* stream); 
 int rbvae_dbg_glds(const void* src, const int* lane_src_chunk, void* out, void* stream);
 /* every later rbvae_gather_gemm launch writes 8 phase time stamps (100 MHz) per workgroup into buf (NULL = off) */
 int rbvae_dbg_gg_stamps(unsigned long long* buf, void* stream);
+int rbvae_dbg_wg_stamps(unsigned long long* buf, void* stream);   /* same for rbvae_wgrad_gemm (-DWG_STAMPS=1 builds) */
 int rbvae_dbg_tr16(const void* img, const int* rowsel, const int* colsel, void* out, void* stream);
 
 #ifdef __cplusplus

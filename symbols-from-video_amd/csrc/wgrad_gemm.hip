@@ -30,6 +30,7 @@ struct WgArgs {
     const int* idx;            // [taps][P] row of In per (tap, pixel), -1 = zero row; null = identity
     const unsigned char* zero; // >= 16 zero bytes
     int P, Co, Ci, ldy, ldi, taps, ksplit, Pper;
+    unsigned long long* stamps;   // -DWG_STAMPS=1 builds only (rbvae_dbg_wg_stamps): [workgroup][8] phase stamps, 100 MHz
 };
 
 __device__ __forceinline__ void glds16w(const void* g, void* lds) {
@@ -55,6 +56,15 @@ template <int RB> __device__ __forceinline__ int tr_swz(int row) {
 #define WG_SB() __builtin_amdgcn_sched_barrier(0)
 #else
 #define WG_SB() do {} while (0)
+#endif
+
+#ifndef WG_STAMPS
+#define WG_STAMPS 0
+#endif
+#if WG_STAMPS
+#define WG_STAMP(slot) do { if (p.stamps && threadIdx.x == 0) p.stamps[(size_t)blockIdx.x * 8 + (slot)] = wall_clock64(); } while (0)
+#else
+#define WG_STAMP(slot) do {} while (0)
 #endif
 
 constexpr int WG_BM = 128;      // co per workgroup
@@ -90,6 +100,7 @@ __global__ __launch_bounds__(512, WG_NS == 2 ? 2 : 1) void wgrad_gemm_k(const Wg
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);     // provably uniform: scalar LDS addressing
+    WG_STAMP(0);
     int wg = blockIdx.x;
     const int ks = wg % p.ksplit; wg /= p.ksplit;
     const int gx = (p.Co + BM - 1) / BM, gy = (p.Ci + BN - 1) / BN;
@@ -109,6 +120,7 @@ __global__ __launch_bounds__(512, WG_NS == 2 ? 2 : 1) void wgrad_gemm_k(const Wg
         for (int i = tid; i < padded; i += 512) s_idx[i] = i < npix ? (idx ? idx[i] : pbeg + i) : -1;
     }
     __syncthreads();
+    WG_STAMP(1);
 
     // staging roles.  One instruction = 1 KiB = (1024/RB) image rows.
     constexpr int A_LPR = RBA / 16, B_LPR = RBB / 16;     // lanes (chunks) per row
@@ -146,6 +158,17 @@ __global__ __launch_bounds__(512, WG_NS == 2 ? 2 : 1) void wgrad_gemm_k(const Wg
 #pragma unroll
     for (int i = 0; i < B_INSTR; ++i) bbase[i] = p.In + (size_t)ci0 * ES + b_coff[i];
     int pstep = 0, pbuf = 0;
+    // WG_IDX_AHEAD=1 reads the gather index of the NEXT stage's rows one stage ahead instead of at its point of use
+    // (where the LDS read and its wait sit in front of every stage's B loads).  Measured on the bench step, same GPU,
+    // 3 runs each: 0.5378 (off) vs 0.5395 ms (on) -- not what holds the K step at 0.75 us (phase stamps:
+    // tools/wg_stamps.py) -- so it is off.
+#ifndef WG_IDX_AHEAD
+#define WG_IDX_AHEAD 0
+#endif
+    int nsrc[B_INSTR];
+    const int padded_steps = nsteps;
+#pragma unroll
+    for (int i = 0; i < B_INSTR; ++i) nsrc[i] = (b_wave && nsteps > 0) ? s_idx[b_row[i]] : -1;
     auto stage_next = [&]() {
         unsigned char* la = smem + pbuf * STAGE + (w * A_INSTR) * 1024;
         const int base = pstep * WG_BK;
@@ -159,15 +182,25 @@ __global__ __launch_bounds__(512, WG_NS == 2 ? 2 : 1) void wgrad_gemm_k(const Wg
             unsigned char* lb = smem + pbuf * STAGE + A_BYTES + (w * B_INSTR) * 1024;
 #pragma unroll
             for (int i = 0; i < B_INSTR; ++i) {
+#if WG_IDX_AHEAD
+                const int src = nsrc[i];
+#else
                 const int src = s_idx[base + b_row[i]];
+#endif
                 const bool v = b_cval[i] && src >= 0;
                 glds16w(v ? bbase[i] + (size_t)src * ldi_b : p.zero, lb + i * 1024);
             }
+#if WG_IDX_AHEAD
+            if (pstep + 1 < padded_steps) {
+#pragma unroll
+                for (int i = 0; i < B_INSTR; ++i) nsrc[i] = s_idx[base + WG_BK + b_row[i]];
+            }
+#endif
         }
         ++pstep;
         pbuf = (pbuf + 1 == WG_NS) ? 0 : pbuf + 1;
     };
-
+    WG_STAMP(2);
     const int wr = w >> 2, wc = w & 3;
     const int fi = lane & 15, fg = lane >> 4;
     f32x4_t acc[MT][NT];
@@ -331,6 +364,7 @@ __global__ __launch_bounds__(512, WG_NS == 2 ? 2 : 1) void wgrad_gemm_k(const Wg
         }
     }
 
+    WG_STAMP(3);
     // D[row = ci 4g+r][col = co i]: lane owns 4 consecutive ci of one co -> one 16-B store
     float* slab = p.dW + (size_t)ks * p.Co * p.taps * p.Ci;
 #pragma unroll
@@ -344,6 +378,10 @@ __global__ __launch_bounds__(512, WG_NS == 2 ? 2 : 1) void wgrad_gemm_k(const Wg
             *(f32x4_t*)(slab + ((size_t)co * p.taps + tap) * p.Ci + ci) = acc[mt][nt];
         }
     }
+#if WG_STAMPS
+    WG_STAMP(4);
+    if (p.stamps) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); WG_STAMP(5); }
+#endif
 }
 
 // idx[t][p] for a strided convolution: the In pixel row tap t reads at output pixel p.
@@ -397,7 +435,16 @@ static int launch_wg(const WgArgs& a, hipStream_t st) {
 
 using namespace rbvae;
 
+static unsigned long long* g_wg_stamps = nullptr;
+
 extern "C" {
+
+/* debug (stamped builds only: -DWG_STAMPS=1): later rbvae_wgrad_gemm launches write phase stamps into buf */
+int rbvae_dbg_wg_stamps(unsigned long long* buf, void* stream) {
+    (void)stream;
+    g_wg_stamps = buf;
+    return RBVAE_OK;
+}
 
 int rbvae_conv_gather_index(int* idx, int Nimg, int IH, int IW, int OH, int OW, int KH, int KW, int stride,
                             int pad, void* stream) {
@@ -428,6 +475,7 @@ int rbvae_wgrad_gemm(int dtype, const void* Dy, const void* In, float* dW_slabs,
     a.zero = (const unsigned char*)zero_page;
     a.P = P; a.Co = Co; a.Ci = Ci; a.ldy = ldy; a.ldi = ldi; a.taps = taps; a.ksplit = ksplit;
     a.Pper = ((cdiv(P, ksplit) + 63) / 64) * 64;
+    a.stamps = g_wg_stamps;
     RBVAE_CHECK_ARG(a.Pper <= WG_MAXP, "wgrad_gemm: %d pixels per K-slice exceed %d: raise ksplit (>= %d)", a.Pper,
                     WG_MAXP, cdiv(P, WG_MAXP));
     hipStream_t st = (hipStream_t)stream;
