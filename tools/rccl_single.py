@@ -1,0 +1,31 @@
+"""One-rank RCCL rehearsal of the multi-GPU step: an initialised "nccl" process group (communicator, watchdog
+thread) while the trainer captures its two HIP graphs, and a real all_reduce call on the flat gradient buffer
+between their replays.  (The N > 1 path proper needs N GPUs; this covers its runtime interplay on one.)"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+os.environ.setdefault("MASTER_PORT", "29533")
+import torch
+import torch.distributed as dist
+import sfv_amd as sfv
+from importlib import import_module
+FusedTrainer = import_module("symbols-from-video_amd.trainer").FusedTrainer
+
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1)
+torch.manual_seed(1)
+m = sfv.Seq2SeqBinaryVAE(4, 4, 32, 32, variant="percep", input_hw=(32, 32), compute_dtype="bf16").cuda().train()
+tr = FusedTrainer(m, alpha=1.0, beta_kl=1.0, bernoulli_p=0.1)
+tr.world = 2                       # take the two-graph path with the all_reduce between the replays
+tr.one_graph = False
+item = torch.randn(16, 2, 8, 4, 32, 32, device="cuda")
+for _ in range(5):
+    tr.step(item, 0.7)
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(100):
+    tr.step(item, 0.7)
+torch.cuda.synchronize()
+dt = (time.perf_counter() - t0) / 100
+print(f"two graphs + RCCL all_reduce (1 rank): {dt * 1e3:.3f} ms/step, losses {[round(v, 4) for v in tr.losses.tolist()]}")
+dist.destroy_process_group()
