@@ -243,6 +243,7 @@ class Engine:
         # already waits on the fork point).  Graph capture hands the forking node's queue to the branch created
         # first; created second, the main chain paid the cross-queue hand-off (~10 us idle at every fork).
         self.main_first = os.environ.get("RBVAE_MAIN_FIRST", "1") == "1"
+        self._ks_force = int(os.environ.get("RBVAE_WG_KS", "0"))
         # RBVAE_STREAM_GEMM=1 sends the K = 64 products of the 3/4-channel ends to the row-streaming kernel
         # (rbvae_stream_gemm) instead of the tiled gather GEMM.  Bit-identical results; measured on the bench shapes
         # (tools/abl_stream.py): conv1 forward 17.5 -> 15.4-16.6 us, last-deconv backward (gate + column sums)
@@ -434,6 +435,8 @@ class Engine:
         # slabs to reduce afterwards
         ks = max(1, min(256 // max(blocks, 1), P // 256 if P >= 256 else 1,
                         max(1, (4 << 20) // (Co * taps * Ci))))
+        if self._ks_force and blocks >= 8:
+            ks = self._ks_force                 # RBVAE_WG_KS: experiment switch (K-slices of the multi-tile weight gradients)
         ks = max(ks, -(-P // 4096))            # the kernel keeps a K-slice's gather indices in LDS (<= 4096)
         slabs = self._buf(("slabs", tag), ks * Co * taps * Ci)
         L.call("rbvae_wgrad_gemm", self.dt, Dy, In, slabs, idx, self.zero, P, Co, Ci, ldy, ldi, taps, ks)
