@@ -101,8 +101,18 @@ __global__ __launch_bounds__(256) void run_jobs_k(const Job* __restrict__ jobs) 
         float* out = (float*)j.dst;
         const unsigned ns = (unsigned)j.nslab, slab = (unsigned)j.slab;
         for (unsigned c = wave; c < n; c += nw) {
+            // eight loads in flight per lane (fixed order of additions: reproducible); one per iteration was a
+            // memory round trip each, 64 of them for the 4096 partial rows of a 4-channel bias gradient
             float a = 0.f;
-            for (unsigned k = lane; k < ns; k += 64) a += j.src[(size_t)k * slab + c];
+            unsigned k = lane;
+            for (; k + 7 * 64 < ns; k += 8 * 64) {
+                float v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = j.src[(size_t)(k + u * 64) * slab + c];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) a += v[u];
+            }
+            for (; k < ns; k += 64) a += j.src[(size_t)k * slab + c];
             a = wave_sum(a) * j.scale;
             if (lane == 0) out[c] = j.accumulate ? out[c] + a : a;
         }
@@ -180,6 +190,13 @@ __global__ __launch_bounds__(256) void run_jobs_k(const Job* __restrict__ jobs) 
             float a = 0.f;
             const unsigned ns = (unsigned)j.nslab;
             unsigned k = 0;
+            for (; k + 16 <= ns; k += 16) {         // 16 independent loads in flight, fixed summation order
+                float v[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) v[u] = p[(size_t)(k + u) * j.slab];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) a += v[u];
+            }
             for (; k + 4 <= ns; k += 4) {           // 4 independent loads in flight, fixed summation order
                 const float v0 = p[(size_t)k * j.slab], v1 = p[(size_t)(k + 1) * j.slab];
                 const float v2 = p[(size_t)(k + 2) * j.slab], v3 = p[(size_t)(k + 3) * j.slab];

@@ -18,19 +18,24 @@ torch.cuda.synchronize()
 eng = list(model._engines.values())[0]
 names = {0: "pack", 1: "permute_reduce", 2: "reduce_rows", 3: "conv_pack"}
 def time_tab(label, tab, n, jl):
-    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    def t(ptr, cnt):
-        for _ in range(3):
-            L.call("rbvae_run_jobs", ptr, cnt, 256)
-        a.record()
-        for _ in range(20):
-            L.call("rbvae_run_jobs", ptr, cnt, 256)
-        b.record(); torch.cuda.synchronize()
-        return a.elapsed_time(b) / 20 * 1e3
-    print(f"{label}: {n} jobs, all together {t(tab, n):.1f} us")
+    """GPU-side duration of the whole table and of every job alone: the launches are queued behind a device-side
+    sleep, so the event pairs bracket kernels, not host launch latency."""
+    def timed(calls):
+        torch.cuda.synchronize()
+        torch.cuda._sleep(40_000_000)
+        evs = []
+        for ptr, cnt in calls:
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record(); L.call("rbvae_run_jobs", ptr, cnt, 256); b.record()
+            evs.append((a, b))
+        torch.cuda.synchronize()
+        return [a.elapsed_time(b) * 1e3 for a, b in evs]
+    timed([(tab, n)])
+    whole = timed([(tab, n)] * 3)
+    each = timed([(tab[i:], 1) for i in range(n)])
+    print(f"{label}: {n} jobs, all together {min(whole):.1f} us (event pair overhead ~4.8 us included)")
     for i, r in enumerate(jl.rows):
-        us = t(tab[i:], 1)
-        print(f"  job {i:2d} {names[r[0]]:15s} dims=({r[3]},{r[4]},{r[5]}) strides=({r[6]},{r[7]},{r[8]}) nslab={r[9]} fast={r[13] >> 32} inner={r[14]}: {us:6.1f} us")
+        print(f"  job {i:2d} {names[r[0]]:15s} dims=({r[3]},{r[4]},{r[5]}) strides=({r[6]},{r[7]},{r[8]}) nslab={r[9]} fast={r[13] >> 32} inner={r[14]}: {each[i]:6.1f} us")
 eng.pack(model._flat)
 for key, val in eng._pack_tab.items():
     if len(val) == 3:
