@@ -22,7 +22,7 @@ if len(marks) < 12:
     marks = [i for i, n in enumerate(names) if "pack3" in n or "cast_pad_k" in n and False]
 if len(marks) < 12:
     marks = [i for i, n in enumerate(names) if "adam_k" in n]
-a, b = marks[-12], marks[-2]          # 10 steps
+a, b = marks[-16], marks[-6]          # 10 graph-replayed steps (the last few before the cut are the eager warm-ups of the instrumented leg)
 steps = 10
 agg = collections.OrderedDict()
 for r in rows[a:b]:
@@ -42,7 +42,7 @@ try:
 except BrokenPipeError:
     pass
 if len(sys.argv) > 2:
-    a, b = marks[-3], marks[-2]
+    a, b = marks[-7], marks[-6]
     for r in rows[a:b]:
         n = r["Kernel_Name"]
         if "gemm" in n:
@@ -50,7 +50,7 @@ if len(sys.argv) > 2:
             print(f"    {n.replace('void rbvae::', '')[:44]:44s} grid=({int(r['Grid_Size_X']) // int(r['Workgroup_Size_X'])},{r['Grid_Size_Y']},{r['Grid_Size_Z']}) {t:7.1f} us")
 if len(sys.argv) > 3:
     # timeline of one step: start offset, duration, queue/stream of every kernel (shows side-stream overlap)
-    a, b = marks[-3], marks[-2]
+    a, b = marks[-7], marks[-6]
     t0 = int(rows[a]["Start_Timestamp"])
     for r in rows[a:b]:
         n = r["Kernel_Name"].replace("void rbvae::", "").replace("rbvae::", "").split("(")[0][:44]
