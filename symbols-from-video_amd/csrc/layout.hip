@@ -424,6 +424,7 @@ __global__ __launch_bounds__(512) void skinny_linear_k(const T* __restrict__ A, 
     constexpr int ES = sizeof(T);
     constexpr int KS = (ES == 2) ? 32 : 16;      // k per step (16 B per lane per operand)
     constexpr int EC = 16 / ES;
+    __builtin_amdgcn_s_setprio(3);               // latency-bound link of the fc / LSTM chain: issue before the side stream's GEMM waves
     __shared__ float part[8][256];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int i = lane & 15, g = lane >> 4;

@@ -101,6 +101,7 @@ __global__ void binarize_kl_bwd_k(const float* __restrict__ g_z, const float* __
                                   const float* __restrict__ z, float* __restrict__ dh, int accumulate,
                                   int n, int rows, float tau, float klw, const float* __restrict__ gs,
                                   float lp, float l1p, float keps, int clamp) {
+    __builtin_amdgcn_s_setprio(3);               // sits between the two LSTM backward launches of the chain
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     float w = klw / (float)rows;

@@ -12,6 +12,18 @@
 #include "common.h"
 #include <stdlib.h>
 
+// Wave priority of the latency-bound kernels that share the chip with full-grid GEMMs on the side stream (the LSTM
+// backward chain ran 18 + 25 us beside the decoder weight gradients against 14 + 14 us alone): s_setprio 3 gives
+// their few waves the issue slots first.  -DLSTM_PRIO=0 builds without it (tools/ab_variants.sh).
+#ifndef LSTM_PRIO
+#define LSTM_PRIO 3
+#endif
+#if LSTM_PRIO
+#define RBVAE_RAISE_PRIO() __builtin_amdgcn_s_setprio(LSTM_PRIO)
+#else
+#define RBVAE_RAISE_PRIO() do {} while (0)
+#endif
+
 namespace rbvae {
 
 __device__ __forceinline__ long lstm_layer_floats(int L) { return 8l * L * L + 8l * L; }
@@ -237,6 +249,7 @@ __global__ __launch_bounds__(1024) void lstm_fwd_wave_k(const float* __restrict_
                                                         int G, const float* __restrict__ in_parts, int nparts,
                                                         long part_stride, void* __restrict__ cast_out, int cast_bf16,
                                                         int cast_ld) {
+    RBVAE_RAISE_PRIO();
     const int L = EXACT ? LMAX : L_;
     extern __shared__ __attribute__((aligned(16))) float sm[];
     float* hbuf = sm;                               // [layers+1][T][L]
@@ -367,6 +380,7 @@ struct PairArgs {
 
 template <int LMAX, bool EXACT>
 __global__ __launch_bounds__(1024) void lstm_pair_fwd_k(const PairArgs p) {
+    RBVAE_RAISE_PRIO();
     const int L = EXACT ? LMAX : p.L;
     const int T = p.T, S = p.S, layers = p.layers, G = p.G;
     extern __shared__ __attribute__((aligned(16))) float sm[];
@@ -502,6 +516,7 @@ __global__ __launch_bounds__(1024) void lstm_bwd_wave_k(const float* __restrict_
                                                         float* __restrict__ dG, float* __restrict__ dx, int S, int T,
                                                         int L_, int layers, int G, int nparts, long part_stride,
                                                         void* __restrict__ cast_out, int cast_bf16, int cast_ld) {
+    RBVAE_RAISE_PRIO();
     const int L = EXACT ? LMAX : L_;
     extern __shared__ float sm[];
     float* gtop = sm;                              // [T][L]
@@ -723,6 +738,7 @@ __global__ __launch_bounds__(256) void lstm_wgrad_mfma_k(const float* __restrict
                                                          const float* __restrict__ hprev2, float* __restrict__ gblk2,
                                                          int S, int T, int L, int layers, int accumulate) {
     typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+    RBVAE_RAISE_PRIO();
     __shared__ float part[4][256];
     int l = blockIdx.z;
     if (l >= layers) { l -= layers; dG = dG2; hs_all = hs_all2; hprev = hprev2; gblk = gblk2; }
