@@ -172,6 +172,14 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void gather_gemm_k(const GgArgs p)
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave id, provably uniform (scalar LDS addressing)
+#ifndef GG_SMALL_PRIO
+#define GG_SMALL_PRIO 0      // measured 0.516 (off) vs 0.522 ms/step (on), same GPU: off
+#endif
+#if GG_SMALL_PRIO
+    // a launch of a few dozen workgroups is a latency-bound link of the main chain (the fc products); beside a
+    // full-grid kernel of the side stream its waves take the issue slots first
+    if (gridDim.x * gridDim.y * gridDim.z <= 64) __builtin_amdgcn_s_setprio(2);
+#endif
     GG_STAMP(0);
     const TapClass& tc = p.cls[blockIdx.z];
     const int Mc = p.Nimg * p.TH * p.TW;

@@ -102,6 +102,12 @@ __global__ __launch_bounds__(512, WG_NS == 2 ? 2 : 1) void wgrad_gemm_k(const Wg
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);     // provably uniform: scalar LDS addressing
     WG_STAMP(0);
+#ifndef WG_SMALL_PRIO
+#define WG_SMALL_PRIO 0      // measured 0.516 (off) vs 0.522 ms/step (on), same GPU: off
+#endif
+#if WG_SMALL_PRIO
+    if (gridDim.x <= 64) __builtin_amdgcn_s_setprio(2);        // few-workgroup launches (the fc weight gradients): see gather_gemm_k
+#endif
     const int gx = (p.Co + BM - 1) / BM, gy = (p.Ci + BN - 1) / BN;
     int ks, wg;
     if (p.xcd_order) {
