@@ -95,6 +95,12 @@ int rbvae_pairdist_bwd(const float* x1, const float* x2, long stride1, long stri
 int rbvae_contrast_term_fwd(const float* h0, const float* h1, int B, int T, int L, float* out, void* stream);
 int rbvae_contrast_term_bwd(const float* h0, const float* h1, int B, int T, int L, float scale,
                             const float* gscale_dev, float* dh0, float* dh1, void* stream);
+/* Value and gradient of that term in ONE many-workgroup launch: parts[2k], parts[2k+1] (k < contrast_term_nparts)
+ * = per-block sums of d(h0,h1)^2 and of max(1 - d(h0[:,s],h0[:,s+1]),0)^2; the term is
+ * sum(parts[2k])/(B*T) + sum(parts[2k+1])/(B*(T-1)) (rbvae_combine_losses finishes it); dh0/dh1 as the _bwd form. */
+int rbvae_contrast_term_nparts(int B, int T);
+int rbvae_contrast_term_fused(const float* h0, const float* h1, int B, int T, int L, float scale,
+                              const float* gscale_dev, float* parts, float* dh0, float* dh1, void* stream);
 /* F.triplet_margin_loss(p=2, eps, swap) (triplet_RBVAE_train.py:82-96) on strided rows. */
 int rbvae_triplet_fwd(const float* a, const float* p, const float* n, long sa, long sp, long sn, int rows, int L,
                       float margin, float eps, int swap, float* out_mean, void* stream);
@@ -280,13 +286,14 @@ int rbvae_adam_step(float* w, const float* g, float* m, float* v, long n, double
 /* The trainer's scalar bookkeeping in one launch (percep_RBVAE_train.py:531-549):
  * out4 = [recon + beta*kl + alpha*pair, recon, kl, pair]; recon from `recon` or, when sse_ws != NULL,
  * finished here as inv_n * sum(sse_ws[0..nparts)) (the col2im kernel's partial sums); kl = kl[0] or, when
- * kl_parts > 0, kl_scale * sum(kl[0..kl_parts)) (rbvae_binarize_kl_fwd_parts' per-block sums).
+ * kl_parts > 0, kl_scale * sum(kl[0..kl_parts)) (rbvae_binarize_kl_fwd_parts' per-block sums); pair = pair[0]
+ * or, when pair_parts > 0, w_sim * sum(pair[2i]) + w_dis * sum(pair[2i+1]) (rbvae_contrast_term_fused).
  * step_dev != NULL: also advances the device step counter and leaves Adam's bias-correction terms for that step
  * in hyper_ws (2 floats); rbvae_adam_step(step_dev = NULL, hyper_ws) then uses them without a launch of its own. */
 int rbvae_combine_losses(const float* sse_ws, int nparts, float inv_n, const float* recon, const float* kl,
-                         int kl_parts, float kl_scale, const float* pair, float beta, float alpha, float* out4,
-                         unsigned long long* step_dev, double lr, double beta1, double beta2, float* hyper_ws,
-                         void* stream);
+                         int kl_parts, float kl_scale, const float* pair, int pair_parts, float w_sim, float w_dis,
+                         float beta, float alpha, float* out4, unsigned long long* step_dev, double lr, double beta1,
+                         double beta2, float* hyper_ws, void* stream);
 
 /* ---- frozen LDM / Stable-Diffusion VAE encoder (cfg 5: on-the-fly latents) ------------------------
  * The convolutions, 1x1 projections and both attention products run on rbvae_gather_gemm (stride-1 and

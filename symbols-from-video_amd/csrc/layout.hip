@@ -728,7 +728,8 @@ int rbvae_col2im_sigmoid_frames(int dtype, const void* Y, int ldy, const float* 
 __global__ __launch_bounds__(1024) void combine_losses_k(const float* __restrict__ sse_ws, int nparts, float inv_n,
                                                          const float* __restrict__ recon_in,
                                                          const float* __restrict__ kl, int kl_parts, float kl_scale,
-                                                         const float* __restrict__ pair,
+                                                         const float* __restrict__ pair, int pair_parts,
+                                                         float w_sim, float w_dis,
                                                          float beta, float alpha, float* __restrict__ out4,
                                                          unsigned long long* __restrict__ step_dev, double lr,
                                                          double b1, double b2, float* __restrict__ hyper) {
@@ -757,8 +758,18 @@ __global__ __launch_bounds__(1024) void combine_losses_k(const float* __restrict
     } else {
         k = kl[0];
     }
+    float pr;
+    if (pair_parts > 0) {
+        // rbvae_contrast_term_fused's per-block (sum d^2, sum max(1-d,0)^2) pairs
+        float a0 = 0.f, a1 = 0.f;
+        for (int i = threadIdx.x; i < pair_parts; i += 1024) { a0 += pair[2 * i]; a1 += pair[2 * i + 1]; }
+        const float s0 = block_sum(a0, red);
+        const float s1 = block_sum(a1, red);
+        pr = w_sim * s0 + w_dis * s1;
+    } else {
+        pr = pair[0];
+    }
     if (threadIdx.x == 0) {
-        const float pr = pair[0];
         out4[0] = recon + beta * k + alpha * pr;
         out4[1] = recon;
         out4[2] = k;
@@ -767,13 +778,14 @@ __global__ __launch_bounds__(1024) void combine_losses_k(const float* __restrict
 }
 
 int rbvae_combine_losses(const float* sse_ws, int nparts, float inv_n, const float* recon, const float* kl,
-                         int kl_parts, float kl_scale, const float* pair, float beta, float alpha, float* out4,
-                         unsigned long long* step_dev, double lr, double beta1, double beta2, float* hyper_ws,
-                         void* stream) {
-    RBVAE_CHECK_ARG(kl && pair && out4 && (sse_ws || recon) && kl_parts >= 0, "combine_losses: bad arguments");
+                         int kl_parts, float kl_scale, const float* pair, int pair_parts, float w_sim, float w_dis,
+                         float beta, float alpha, float* out4, unsigned long long* step_dev, double lr, double beta1,
+                         double beta2, float* hyper_ws, void* stream) {
+    RBVAE_CHECK_ARG(kl && pair && out4 && (sse_ws || recon) && kl_parts >= 0 && pair_parts >= 0, "combine_losses: bad arguments");
     RBVAE_CHECK_ARG(!step_dev || hyper_ws, "combine_losses: step_dev needs hyper_ws");
     hipLaunchKernelGGL(combine_losses_k, dim3(1), dim3(1024), 0, (hipStream_t)stream, sse_ws, nparts, inv_n, recon, kl,
-                       kl_parts, kl_scale, pair, beta, alpha, out4, step_dev, lr, beta1, beta2, hyper_ws);
+                       kl_parts, kl_scale, pair, pair_parts, w_sim, w_dis, beta, alpha, out4, step_dev, lr, beta1, beta2,
+                       hyper_ws);
     RBVAE_CHECK_LAUNCH("combine_losses");
     return RBVAE_OK;
 }

@@ -246,6 +246,56 @@ __global__ void contrast_term_bwd_k(const float* __restrict__ h0, const float* _
     }
 }
 
+// Forward value (as per-block partial sums) and gradient of the contrastive term in ONE many-workgroup launch:
+// one wave per (b, t) row.  parts[2*block] = sum of d(h0,h1)^2 over the block's rows, parts[2*block+1] = sum of
+// max(1 - d(h0[t], h0[t+1]), 0)^2; rbvae_combine_losses finishes  sum0/(B*T) + sum1/(B*(T-1)).  The two-launch
+// form above runs its forward in a single workgroup (10-12 us); this one is ~4 us and needs no side stream.
+__global__ __launch_bounds__(256) void contrast_term_fused_k(const float* __restrict__ h0, const float* __restrict__ h1,
+                                                             int B, int T, int L, float scale,
+                                                             const float* __restrict__ gs, float* __restrict__ parts,
+                                                             float* __restrict__ dh0, float* __restrict__ dh1) {
+    __shared__ float red[4][2];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int r = blockIdx.x * 4 + wid;
+    const float eps = 1e-6f;
+    float sim = 0.f, dis = 0.f;
+    if (r < B * T) {
+        float w = scale;
+        if (gs) w *= gs[0];
+        const float wsim = 2.f * w / (float)(B * T);
+        const float wdis = w / ((float)B * (float)(T - 1));
+        const int t = r % T;
+        const float* a = h0 + (long)r * L;
+        const float* b = h1 + (long)r * L;
+        const float d = sqrtf(row_sqdist(a, b, L, eps, lane));
+        sim = d * d;
+        float cn = 0.f, cp = 0.f;
+        if (t < T - 1) {
+            const float d2 = sqrtf(row_sqdist(a, a + L, L, eps, lane));
+            const float m = fmaxf(1.0f - d2, 0.f);
+            dis = m * m;
+            cn = (m > 0.f && d2 > 0.f) ? -2.f * wdis * m / d2 : 0.f;
+        }
+        if (t > 0) {
+            const float d2 = sqrtf(row_sqdist(a - L, a, L, eps, lane));
+            const float m = fmaxf(1.0f - d2, 0.f);
+            cp = (m > 0.f && d2 > 0.f) ? -2.f * wdis * m / d2 : 0.f;
+        }
+        for (int k = lane; k < L; k += 64) {
+            const float gsim = wsim * (a[k] - b[k] + eps);
+            float g0 = gsim;
+            if (t < T - 1) g0 += cn * (a[k] - a[k + L] + eps);
+            if (t > 0) g0 -= cp * (a[k - L] - a[k] + eps);
+            dh0[(long)r * L + k] = g0;
+            dh1[(long)r * L + k] = -gsim;
+        }
+    }
+    if (lane == 0) { red[wid][0] = sim; red[wid][1] = dis; }
+    __syncthreads();
+    if (threadIdx.x < 2)
+        parts[2 * blockIdx.x + threadIdx.x] = ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
+}
+
 // ---- triplet ---------------------------------------------------------------
 __global__ __launch_bounds__(RED_THREADS) void triplet_fwd_k(
     const float* __restrict__ a, const float* __restrict__ p, const float* __restrict__ n, long sa, long sp,
@@ -498,6 +548,18 @@ int rbvae_contrast_term_bwd(const float* h0, const float* h1, int B, int T, int 
     hipLaunchKernelGGL(contrast_term_bwd_k, dim3(cdiv(B * T, 4)), dim3(256), 0, (hipStream_t)stream, h0, h1, B,
                        T, L, scale, gscale_dev, dh0, dh1);
     RBVAE_CHECK_LAUNCH("contrast_term_bwd");
+    return RBVAE_OK;
+}
+
+int rbvae_contrast_term_nparts(int B, int T) { return cdiv((long)B * T, 4); }
+
+int rbvae_contrast_term_fused(const float* h0, const float* h1, int B, int T, int L, float scale,
+                              const float* gscale_dev, float* parts, float* dh0, float* dh1, void* stream) {
+    RBVAE_CHECK_ARG(h0 && h1 && parts && dh0 && dh1 && B > 0 && L > 0, "contrast_term_fused: bad arguments");
+    RBVAE_CHECK_ARG(T >= 2, "contrast_term_fused: needs T >= 2 states (got %d)", T);
+    hipLaunchKernelGGL(contrast_term_fused_k, dim3(cdiv(B * T, 4)), dim3(256), 0, (hipStream_t)stream, h0, h1, B, T, L,
+                       scale, gscale_dev, parts, dh0, dh1);
+    RBVAE_CHECK_LAUNCH("contrast_term_fused");
     return RBVAE_OK;
 }
 

@@ -55,6 +55,7 @@ class FusedTrainer:
         self.instrument = None       # optional callable(name, flops) -> context manager (bench roofline leg)
         import os
         self.one_graph = os.environ.get("RBVAE_ONE_GRAPH", "1") == "1"
+        self.fused_pair = os.environ.get("RBVAE_FUSED_PAIR", "1") == "1"
 
     # ---- the two halves of a step (plain launches; captured below) ------------------
     def _fwd_bwd(self, x, U, tau, B, T):
@@ -64,12 +65,19 @@ class FusedTrainer:
         g_hs = torch.empty(2 * B, T, Ld, device=self.dev)
         pair = self._pair
 
-        def pair_term(hs):                   # [2B, T, L]; runs beside the decoder (engine side stream)
+        fused_pair = self.fused_pair and self.model.variant != "triplet"
+        pair_parts = torch.empty(2 * L.query("rbvae_contrast_term_nparts", B, T), device=self.dev) if fused_pair else None
+
+        def pair_term(hs):                   # [2B, T, L]
             h0, h1 = hs[:B], hs[B:]
             if self.model.variant == "triplet":
                 L.call("rbvae_triplet_term_fwd", h0, h1, B, T, Ld, float(self.margin), pair)
                 L.call("rbvae_triplet_term_bwd", h0, h1, B, T, Ld, float(self.margin), float(self.alpha), None,
                        g_hs[:B], g_hs[B:])
+            elif fused_pair:
+                # value (as per-block sums for the bookkeeping kernel) and gradient in one many-workgroup launch
+                L.call("rbvae_contrast_term_fused", h0, h1, B, T, Ld, float(self.alpha), None, pair_parts, g_hs[:B],
+                       g_hs[B:])
             else:
                 L.call("rbvae_contrast_term_fwd", h0, h1, B, T, Ld, pair)
                 L.call("rbvae_contrast_term_bwd", h0, h1, B, T, Ld, float(self.alpha), None, g_hs[:B], g_hs[B:])
@@ -87,7 +95,11 @@ class FusedTrainer:
         def bookkeeping():
             # [total, recon, kl, pair] from the partial sums; also advances the device step counter and prepares
             # Adam's bias corrections for _update().  Runs on the side stream beside the backward pass.
-            L.call("rbvae_combine_losses", sse_ws, nparts, inv_n, None, kl_parts, nkl, kl_scale, self._pair,
+            if fused_pair:
+                pargs = (pair_parts, pair_parts.numel() // 2, 1.0 / (B * T), 1.0 / (B * (T - 1)))
+            else:
+                pargs = (self._pair, 0, 0.0, 0.0)
+            L.call("rbvae_combine_losses", sse_ws, nparts, inv_n, None, kl_parts, nkl, kl_scale, *pargs,
                    float(self.beta_kl), float(self.alpha), self.losses, self.step_dev, float(self.lr), float(b1),
                    float(b2), self.hyper)
 

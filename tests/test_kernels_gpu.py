@@ -313,8 +313,8 @@ def test_binarize_parts_and_combine(sfv):
     out4 = torch.empty(4, device="cuda")
     step = torch.tensor([4], dtype=torch.int64, device="cuda")
     hyper = torch.zeros(2, device="cuda")
-    sfv._lib.call("rbvae_combine_losses", sse, 37, 1.0 / 1000, None, parts, nparts, 1.0 / rows, pair, 0.5, 2.0, out4,
-                  step, 1e-3, 0.9, 0.999, hyper)
+    sfv._lib.call("rbvae_combine_losses", sse, 37, 1.0 / 1000, None, parts, nparts, 1.0 / rows, pair, 0, 0.0, 0.0, 0.5, 2.0,
+                  out4, step, 1e-3, 0.9, 0.999, hyper)
     recon, kl = float(sse.sum()) / 1000, kl0.item()
     got = out4.cpu().tolist()
     assert abs(got[1] - recon) < 1e-6 and abs(got[2] - kl) < 1e-5 * max(1.0, abs(kl)) and got[3] == 0.375

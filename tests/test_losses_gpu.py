@@ -150,3 +150,27 @@ def test_mse(L):
     da = torch.empty(x.numel(), device="cuda")
     L.call("rbvae_mse_bwd", x.cuda(), y.cuda(), x.numel(), 0.5, None, da)
     np.testing.assert_allclose(da.cpu().numpy(), (0.5 * 2 * (x - y) / x.numel()).numpy(), atol=1e-12, rtol=1e-5)
+
+
+def test_contrast_term_fused_matches_two_launch_form(L):
+    """rbvae_contrast_term_fused (value as per-block sums + gradient, one launch) against rbvae_contrast_term_fwd /
+    _bwd: same gradient bit for bit, same value to f32 rounding -- also through rbvae_combine_losses."""
+    g = torch.Generator().manual_seed(33)
+    for B, T, Ld in ((16, 8, 32), (3, 5, 25), (2, 2, 100)):
+        h0 = (torch.randn(B, T, Ld, generator=g) * 0.3).cuda()
+        h1 = (h0.cpu() + torch.randn(B, T, Ld, generator=g) * 0.2).cuda()
+        ref = torch.empty(1, device="cuda")
+        d0r, d1r, d0, d1 = (torch.empty(B, T, Ld, device="cuda") for _ in range(4))
+        L.call("rbvae_contrast_term_fwd", h0, h1, B, T, Ld, ref)
+        L.call("rbvae_contrast_term_bwd", h0, h1, B, T, Ld, 0.7, None, d0r, d1r)
+        n = L.query("rbvae_contrast_term_nparts", B, T)
+        parts = torch.empty(2 * n, device="cuda")
+        L.call("rbvae_contrast_term_fused", h0, h1, B, T, Ld, 0.7, None, parts, d0, d1)
+        assert torch.equal(d0, d0r) and torch.equal(d1, d1r)
+        val = parts[0::2].sum().item() / (B * T) + parts[1::2].sum().item() / (B * (T - 1))
+        assert abs(val - ref.item()) < 1e-5 * max(1.0, abs(ref.item()))
+        out4 = torch.empty(4, device="cuda")
+        one = torch.tensor([0.25], device="cuda")
+        L.call("rbvae_combine_losses", None, 0, 0.0, one, one, 0, 0.0, parts, n, 1.0 / (B * T), 1.0 / (B * (T - 1)), 1.0, 1.0,
+               out4, None, 0.0, 0.0, 0.0, None)
+        assert abs(out4[3].item() - ref.item()) < 1e-5 * max(1.0, abs(ref.item()))
