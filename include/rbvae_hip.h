@@ -249,13 +249,15 @@ int rbvae_lstm_bwd(const float* wblk, const float* acts, const float* cs, const 
  *    order in the kernel's prologue; the forward also writes the sum to slot 0 of hs_all.  in_parts NULL /
  *    nparts 1: plain input as in rbvae_lstm_fwd / _bwd;
  *  - cast_out (may be NULL): the top layer's outputs (forward) / the input gradient dx (backward) once more as
- *    [S*T][cast_ld] rows of cast_dtype, zero padded -- the operand of the GEMM that follows (rbvae_cast_pad). */
+ *    [S*T][cast_ld] rows of cast_dtype, zero padded -- the operand of the GEMM that follows (rbvae_cast_pad);
+ *  - dx_colsum (backward, may be NULL): [S][L] per-sequence sums over t of dx -- summed over S they are the bias
+ *    gradient of the Linear that feeds the stack (percep_RBVAE_model.py:61). */
 int rbvae_lstm_fwd_ex(const float* wblk, const float* wT, float* hs_all, float* hprev, float* acts, float* cs, int S,
                       int T, int L, int layers, const float* in_parts, int nparts, long part_stride, void* cast_out,
                       int cast_dtype, int cast_ld, void* stream);
 int rbvae_lstm_bwd_ex(const float* wblk, const float* acts, const float* cs, const float* g_top_parts, int nparts,
-                      long part_stride, float* dG, float* dx, void* cast_out, int cast_dtype, int cast_ld, int S, int T,
-                      int L, int layers, void* stream);
+                      long part_stride, float* dG, float* dx, void* cast_out, int cast_dtype, int cast_ld,
+                      float* dx_colsum, int S, int T, int L, int layers, void* stream);
 /* Encoder stack -> binary_concrete_logits -> decoder stack (percep_RBVAE_model.py:155-163) as ONE wavefront
  * launch: the arithmetic of rbvae_lstm_fwd(enc) + rbvae_binarize_kl_fwd_parts + rbvae_lstm_fwd(dec), with the same
  * optional slab input / cast output as the _ex forms.  hs_dec slot 0 receives z; kl_parts[s] (may be NULL) = KL sum

@@ -515,7 +515,8 @@ __global__ __launch_bounds__(1024) void lstm_bwd_wave_k(const float* __restrict_
                                                         const float* __restrict__ cs, const float* __restrict__ g_top,
                                                         float* __restrict__ dG, float* __restrict__ dx, int S, int T,
                                                         int L_, int layers, int G, int nparts, long part_stride,
-                                                        void* __restrict__ cast_out, int cast_bf16, int cast_ld) {
+                                                        void* __restrict__ cast_out, int cast_bf16, int cast_ld,
+                                                        float* __restrict__ dx_colsum) {
     RBVAE_RAISE_PRIO();
     const int L = EXACT ? LMAX : L_;
     extern __shared__ float sm[];
@@ -582,6 +583,7 @@ __global__ __launch_bounds__(1024) void lstm_bwd_wave_k(const float* __restrict_
         }
     }
     float dc_next = 0.f;
+    float dx_sum = 0.f;                  // layer 0, j < L: sum over t of this sequence's input gradient (dx_colsum)
     __syncthreads();
     const int top = layers - 1;
     const int ndiag = T + layers - 1;
@@ -595,6 +597,7 @@ __global__ __launch_bounds__(1024) void lstm_bwd_wave_k(const float* __restrict_
                 const float* p0 = part;
                 const float dv = p0[0 * L + j] + p0[2 * L + j] + p0[4 * L + j] + p0[6 * L + j];
                 dx[((long)s * T + t + 1) * L + j] = dv;
+                dx_sum += dv;
                 if (cast_out) {
                     const long o = ((long)s * T + t + 1) * cast_ld + j;
                     if (cast_bf16) ((bf16_t*)cast_out)[o] = f32_to_bf16(dv); else ((float*)cast_out)[o] = dv;
@@ -651,10 +654,13 @@ __global__ __launch_bounds__(1024) void lstm_bwd_wave_k(const float* __restrict_
     if (l == 0 && j < L) {
         const float dv = part[0 * L + j] + part[2 * L + j] + part[4 * L + j] + part[6 * L + j];
         dx[((long)s * T) * L + j] = dv;
+        dx_sum += dv;
         if (cast_out) {
             const long o = ((long)s * T) * cast_ld + j;
             if (cast_bf16) ((bf16_t*)cast_out)[o] = f32_to_bf16(dv); else ((float*)cast_out)[o] = dv;
         }
+        // per-sequence column sums of dx: the bias gradient of the Linear that feeds this stack, minus one launch
+        if (dx_colsum) dx_colsum[(long)s * L + j] = dx_sum;
     }
 }
 
@@ -893,7 +899,7 @@ int rbvae_lstm_pair_fwd(const float* wblk_enc, const float* wT_enc, const float*
 
 static int lstm_bwd_impl(const float* wblk, const float* acts, const float* cs, const float* g_top, float* dG, float* dx,
                          int S, int T, int L, int layers, int nparts, long part_stride, void* cast_out, int cast_dtype,
-                         int cast_ld, void* stream) {
+                         int cast_ld, float* dx_colsum, void* stream) {
     RBVAE_CHECK_ARG(wblk && acts && cs && g_top && dG && dx && S > 0 && T > 0 && L > 0 && layers > 0,
                     "lstm_bwd: bad arguments");
     RBVAE_CHECK_ARG(!cast_out || ((cast_dtype == RBVAE_F32 || cast_dtype == RBVAE_BF16) && cast_ld >= L),
@@ -908,14 +914,16 @@ static int lstm_bwd_impl(const float* wblk, const float* acts, const float* cs, 
     if (L <= 32 && layers * threads <= 1024 && wlds <= 64 * 1024) {
         if (L == 32)
             hipLaunchKernelGGL((lstm_bwd_wave_k<32, true>), dim3(S), dim3(layers * threads), wlds, st, wblk, acts, cs,
-                               g_top, dG, dx, S, T, L, layers, threads, nparts, part_stride, cast_out, cast_bf16, cast_ld);
+                               g_top, dG, dx, S, T, L, layers, threads, nparts, part_stride, cast_out, cast_bf16, cast_ld,
+                               dx_colsum);
         else
             hipLaunchKernelGGL((lstm_bwd_wave_k<32, false>), dim3(S), dim3(layers * threads), wlds, st, wblk, acts, cs,
-                               g_top, dG, dx, S, T, L, layers, threads, nparts, part_stride, cast_out, cast_bf16, cast_ld);
+                               g_top, dG, dx, S, T, L, layers, threads, nparts, part_stride, cast_out, cast_bf16, cast_ld,
+                               dx_colsum);
         RBVAE_CHECK_LAUNCH("lstm_bwd_wave");
         return RBVAE_OK;
     }
-    RBVAE_CHECK_ARG(nparts == 1 && !cast_out, "lstm_bwd_ex: only the wavefront kernel (L <= 32, layers * roundup64(4L) <= 1024) sums gradient slabs / writes a cast copy");
+    RBVAE_CHECK_ARG(nparts == 1 && !cast_out && !dx_colsum, "lstm_bwd_ex: only the wavefront kernel (L <= 32, layers * roundup64(4L) <= 1024) sums gradient slabs / writes a cast copy");
     if (L <= 32)
         hipLaunchKernelGGL(lstm_bwd_k<32>, dim3(S), dim3(threads), lds, st, wblk, acts, cs, g_top, dG, dx, S, T, L, layers);
     else if (L <= 64)
@@ -928,15 +936,15 @@ static int lstm_bwd_impl(const float* wblk, const float* acts, const float* cs, 
 
 int rbvae_lstm_bwd(const float* wblk, const float* acts, const float* cs, const float* g_top, float* dG, float* dx,
                    int S, int T, int L, int layers, void* stream) {
-    return lstm_bwd_impl(wblk, acts, cs, g_top, dG, dx, S, T, L, layers, 1, 0, nullptr, 0, 0, stream);
+    return lstm_bwd_impl(wblk, acts, cs, g_top, dG, dx, S, T, L, layers, 1, 0, nullptr, 0, 0, nullptr, stream);
 }
 
 int rbvae_lstm_bwd_ex(const float* wblk, const float* acts, const float* cs, const float* g_top_parts, int nparts,
-                      long part_stride, float* dG, float* dx, void* cast_out, int cast_dtype, int cast_ld, int S, int T,
-                      int L, int layers, void* stream) {
+                      long part_stride, float* dG, float* dx, void* cast_out, int cast_dtype, int cast_ld,
+                      float* dx_colsum, int S, int T, int L, int layers, void* stream) {
     RBVAE_CHECK_ARG(nparts >= 1 && (nparts == 1 || part_stride >= (long)S * T * L), "lstm_bwd_ex: bad slabs");
     return lstm_bwd_impl(wblk, acts, cs, g_top_parts, dG, dx, S, T, L, layers, nparts, part_stride, cast_out, cast_dtype,
-                         cast_ld, stream);
+                         cast_ld, dx_colsum, stream);
 }
 
 static int launch_lstm_wgrad(const float* dG, const float* hs_all, const float* hprev, float* gblk, const float* dG2,

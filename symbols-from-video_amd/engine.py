@@ -244,6 +244,7 @@ class Engine:
         # first; created second, the main chain paid the cross-queue hand-off (~10 us idle at every fork).
         self.main_first = os.environ.get("RBVAE_MAIN_FIRST", "1") == "1"
         self._ks_force = int(os.environ.get("RBVAE_WG_KS", "0"))
+        self.book_with_dec = os.environ.get("RBVAE_BOOK_WITH_DEC", "1") == "1"
         # RBVAE_STREAM_GEMM=1 sends the K = 64 products of the 3/4-channel ends to the row-streaming kernel
         # (rbvae_stream_gemm) instead of the tiled gather GEMM.  Bit-identical results; measured on the bench shapes
         # (tools/abl_stream.py): conv1 forward 17.5 -> 15.4-16.6 us, last-deconv backward (gate + column sums)
@@ -722,7 +723,9 @@ class Engine:
         side_first: optional callable issued on the side stream before anything else of this pass (the trainer's
         loss bookkeeping: everything it reads exists once forward() is done)."""
         self._join()                       # side-stream work of forward() (after_hs)
-        if side_first is not None:
+        book_with_decoder = (side_first is not None and self.book_with_dec and self._side_on(self.SIDE_DEC_WGRAD)
+                             and not self._side_on(self.SIDE_BOOK))
+        if side_first is not None and not book_with_decoder:
             self._fork(0, self.SIDE_BOOK)
             with self._on_side(0, self.SIDE_BOOK):
                 side_first()
@@ -802,6 +805,8 @@ class Engine:
             early = self._side_on(self.SIDE_DEC_WGRAD) and self._side_on(self.SIDE_DEC_REDUCE)
             main_jobs, self._jobs = self._jobs, JobList()
             with self._on_side(0, self.SIDE_DEC_WGRAD):
+                if book_with_decoder:
+                    side_first()        # the loss bookkeeping rides the side stream's existing fork: no edge of its own
                 decoder_wgrads()
                 if early:
                     # the decoder's slab / partial-sum reductions right behind them, not at the end of the pass
@@ -828,7 +833,7 @@ class Engine:
         d_in_dec = tmp("d_in_dec", N, Ld, dtype=f32)
         if self.fc_split > 1:
             L.call("rbvae_lstm_bwd_ex", wdec, sv.acts_dec, sv.cs_dec, dds, self.fc_split, N * Ld, dG, d_in_dec, None, 0, 0,
-                   S, T, Ld, nl)
+                   None, S, T, Ld, nl)
         else:
             L.call("rbvae_lstm_bwd", wdec, sv.acts_dec, sv.cs_dec, dds, dG, d_in_dec, S, T, Ld, nl)
         de = tmp("de", N, Ld, dtype=f32)
@@ -848,14 +853,17 @@ class Engine:
                 if g_hs is not None:
                     dh = dh + g_hs.reshape(N, Ld)
             de_pad = None
+            de_sums = None
             if self.lstm_cast:
                 de_pad = tmp("de_pad", N, self.Lp)
-                L.call("rbvae_lstm_bwd_ex", wenc, sv.acts_enc, sv.cs_enc, dh, 1, 0, dGe, de, de_pad, self.dt, self.Lp, S, T,
-                       Ld, nl)
+                de_sums = self._buf((N, "de_sums"), S * Ld)        # per-sequence column sums of de: fc bias gradient
+                L.call("rbvae_lstm_bwd_ex", wenc, sv.acts_enc, sv.cs_enc, dh, 1, 0, dGe, de, de_pad, self.dt, self.Lp,
+                       de_sums, S, T, Ld, nl)
             else:
                 L.call("rbvae_lstm_bwd", wenc, sv.acts_enc, sv.cs_enc, dh, dGe, de, S, T, Ld, nl)
         else:
             de_pad = None
+            de_sums = None
             # decoder stack input = encoder stack output
             dz = tmp("dz", N, Ld, dtype=f32)
             L.call("rbvae_lstm_bwd", wenc, sv.acts_enc, sv.cs_enc, d_in_dec, dGe, dz, S, T, Ld, nl)
@@ -867,7 +875,10 @@ class Engine:
         with self._on_side(0, self.SIDE_LSTM_WGRAD):
             L.call("rbvae_lstm_wgrad_pair", dG, sv.hs_dec, sv.hp_dec, G("decoder_rnn.lstm.weight_ih_l0"),
                    dGe, sv.hs_enc, sv.hp_enc, G("encoder_rnn.lstm.weight_ih_l0"), S, T, Ld, nl, 0)
-            self._colsum(F32, de, N, Ld, Ld, G("encoder_cnn.fc.bias"), tag=(N, "bfc"))
+            if de_sums is not None and g_e is None:
+                self._jobs.add(JOB_ROWS, de_sums, G("encoder_cnn.fc.bias"), (1, 1, Ld), (0, 0, 1), nslab=S, slab=Ld)
+            else:
+                self._colsum(F32, de, N, Ld, Ld, G("encoder_cnn.fc.bias"), tag=(N, "bfc"))
         # --- encoder fc
         if de_pad is None:
             de_pad = tmp("de_pad", N, self.Lp)

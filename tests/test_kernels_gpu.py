@@ -397,8 +397,10 @@ def test_split_fc_slabs_feed_the_lstm_kernels(sfv):
         dG, dx = torch.empty(layers, S, T, 4 * L, device="cuda"), torch.empty(N, L, device="cuda")
         if use_parts:
             pad = torch.full((N, 32), 9.0, device="cuda")
-            sfv._lib.call("rbvae_lstm_bwd_ex", wblk, a0, c0, gparts, ks, N * L, dG, dx, pad, 0, 32, S, T, L, layers)
+            sums = torch.empty(S, L, device="cuda")
+            sfv._lib.call("rbvae_lstm_bwd_ex", wblk, a0, c0, gparts, ks, N * L, dG, dx, pad, 0, 32, sums, S, T, L, layers)
             assert torch.equal(pad, dx)
+            np.testing.assert_allclose(sums.cpu().numpy(), dx.view(S, T, L).sum(1).cpu().numpy(), atol=1e-5)
         else:
             sfv._lib.call("rbvae_lstm_bwd", wblk, a0, c0, gparts.sum(0).contiguous(), dG, dx, S, T, L, layers)
         outs.append((dG, dx))
