@@ -271,6 +271,13 @@ int rbvae_lstm_pair_fwd(const float* wblk_enc, const float* wT_enc, const float*
                         float noise_eps, int hard, float kl_p, float kl_eps, int kl_clamp, unsigned long long seed,
                         const unsigned long long* seed_dev, void* cast_out, int cast_dtype, int cast_ld, int S, int T,
                         int L, int layers, void* stream);
+/* The encoder stack's BPTT with rbvae_binarize_kl_bwd fused into its prologue (wavefront kernel only):
+ *   g_top = g_hs + (g_z + kl_weight/(S*T) * dKL/dz(z)) * y_soft*(1-y_soft)/tau,   g_hs may be NULL;
+ * cast_out / dx_colsum as in rbvae_lstm_bwd_ex. */
+int rbvae_lstm_bwd_bin(const float* wblk, const float* acts, const float* cs, const float* g_z, const float* y_soft,
+                       const float* z, const float* g_hs, float tau, float kl_weight, float kl_p, float kl_eps,
+                       int kl_clamp, float* dG, float* dx, void* cast_out, int cast_dtype, int cast_ld, float* dx_colsum,
+                       int S, int T, int L, int layers, void* stream);
 int rbvae_lstm_wgrad(const float* dG, const float* hs_all, const float* hprev, float* gblk, int S, int T, int L,
                      int layers, int accumulate, void* stream);
 /* the same for two stacks of equal shape (the encoder and decoder LSTMs) in one launch */

@@ -74,6 +74,21 @@ __device__ __forceinline__ float kl_elem(float v, float lp, float l1p, float eps
     return q * (logf(q + eps) - lp) + (1.0f - q) * (logf((1.0f - q) + eps) - l1p);
 }
 
+// d kl_elem / d v
+__device__ __forceinline__ float kl_elem_grad(float v, float lp, float l1p, float eps, int clamp) {
+    const float s = sigmoidf_(v);
+    float q = s;
+    bool pass = true;
+    if (clamp) {
+        pass = (s >= eps) && (s <= 1.0f - eps);
+        q = fminf(fmaxf(s, eps), 1.0f - eps);
+    }
+    if (!pass) return 0.f;
+    const float omq = 1.0f - q;
+    const float dq = (logf(q + eps) - lp) + q / (q + eps) - (logf(omq + eps) - l1p) - omq / (omq + eps);
+    return dq * s * (1.0f - s);
+}
+
 // Counter-based uniform bits for dropout: one 32-bit draw per element index.
 // (squares-style mixing of (seed, index); statistical quality is ample for a keep-mask)
 __device__ __forceinline__ unsigned hash_u32(unsigned long long seed, unsigned long long idx) {

@@ -17,20 +17,7 @@ int fail(int code, const char* fmt, ...) {
 constexpr int RED_THREADS = 1024;
 
 // kl_elem: common.h
-// d kl_elem / d v
-__device__ __forceinline__ float kl_elem_grad(float v, float lp, float l1p, float eps, int clamp) {
-    const float s = sigmoidf_(v);
-    float q = s;
-    bool pass = true;
-    if (clamp) {
-        pass = (s >= eps) && (s <= 1.0f - eps);
-        q = fminf(fmaxf(s, eps), 1.0f - eps);
-    }
-    if (!pass) return 0.f;
-    const float omq = 1.0f - q;
-    const float dq = (logf(q + eps) - lp) + q / (q + eps) - (logf(omq + eps) - l1p) - omq / (omq + eps);
-    return dq * s * (1.0f - s);
-}
+// kl_elem_grad: common.h
 
 __global__ __launch_bounds__(RED_THREADS) void binarize_kl_fwd_k(
     const float* __restrict__ h, const float* __restrict__ U, float* __restrict__ y_soft,

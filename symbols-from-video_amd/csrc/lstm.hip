@@ -510,13 +510,21 @@ __global__ __launch_bounds__(1024) void lstm_pair_fwd_k(const PairArgs p) {
     }
 }
 
+// Optional binarise backward in the prologue of the ENCODER stack's BPTT launch (rbvae_binarize_kl_bwd fused):
+//   g_top = g_hs + (gz + klw * dKL/dz(z)) * y (1 - y) / tau      (straight-through: the same with hard codes)
+struct BinBwd {
+    const float *gz, *y, *z, *g_hs;      // gz: gradient of the codes (decoder stack's input gradient); g_hs may be null
+    float tau, klw, lp, l1p, keps;
+    int clamp, on;
+};
+
 template <int LMAX, bool EXACT>
 __global__ __launch_bounds__(1024) void lstm_bwd_wave_k(const float* __restrict__ wblk, const float* __restrict__ acts,
                                                         const float* __restrict__ cs, const float* __restrict__ g_top,
                                                         float* __restrict__ dG, float* __restrict__ dx, int S, int T,
                                                         int L_, int layers, int G, int nparts, long part_stride,
                                                         void* __restrict__ cast_out, int cast_bf16, int cast_ld,
-                                                        float* __restrict__ dx_colsum) {
+                                                        float* __restrict__ dx_colsum, const BinBwd bb) {
     RBVAE_RAISE_PRIO();
     const int L = EXACT ? LMAX : L_;
     extern __shared__ float sm[];
@@ -542,6 +550,16 @@ __global__ __launch_bounds__(1024) void lstm_bwd_wave_k(const float* __restrict_
                 int i = base + u * blockDim.x;
                 i = i < ntot ? i : ntot - 1;
                 const float* src;
+                if (i < n0 && bb.on) {
+                    const long e = ((long)s * T) * L + i;
+                    float g = bb.gz[e];
+                    if (bb.klw != 0.f) g += bb.klw * kl_elem_grad(bb.z[e], bb.lp, bb.l1p, bb.keps, bb.clamp);
+                    const float yv = bb.y[e];
+                    float gt = g * yv * (1.0f - yv) / bb.tau;
+                    if (bb.g_hs) gt = bb.g_hs[e] + gt;
+                    v[u] = gt;
+                    continue;
+                }
                 if (i < n0 && nparts > 1) {
                     // g_top as K-split slabs (rbvae_skinny_linear_parts): summed in slab order
                     const float* gp = g_top + ((long)s * T) * L + i;
@@ -899,7 +917,7 @@ int rbvae_lstm_pair_fwd(const float* wblk_enc, const float* wT_enc, const float*
 
 static int lstm_bwd_impl(const float* wblk, const float* acts, const float* cs, const float* g_top, float* dG, float* dx,
                          int S, int T, int L, int layers, int nparts, long part_stride, void* cast_out, int cast_dtype,
-                         int cast_ld, float* dx_colsum, void* stream) {
+                         int cast_ld, float* dx_colsum, const BinBwd& bb, void* stream) {
     RBVAE_CHECK_ARG(wblk && acts && cs && g_top && dG && dx && S > 0 && T > 0 && L > 0 && layers > 0,
                     "lstm_bwd: bad arguments");
     RBVAE_CHECK_ARG(!cast_out || ((cast_dtype == RBVAE_F32 || cast_dtype == RBVAE_BF16) && cast_ld >= L),
@@ -915,15 +933,15 @@ static int lstm_bwd_impl(const float* wblk, const float* acts, const float* cs, 
         if (L == 32)
             hipLaunchKernelGGL((lstm_bwd_wave_k<32, true>), dim3(S), dim3(layers * threads), wlds, st, wblk, acts, cs,
                                g_top, dG, dx, S, T, L, layers, threads, nparts, part_stride, cast_out, cast_bf16, cast_ld,
-                               dx_colsum);
+                               dx_colsum, bb);
         else
             hipLaunchKernelGGL((lstm_bwd_wave_k<32, false>), dim3(S), dim3(layers * threads), wlds, st, wblk, acts, cs,
                                g_top, dG, dx, S, T, L, layers, threads, nparts, part_stride, cast_out, cast_bf16, cast_ld,
-                               dx_colsum);
+                               dx_colsum, bb);
         RBVAE_CHECK_LAUNCH("lstm_bwd_wave");
         return RBVAE_OK;
     }
-    RBVAE_CHECK_ARG(nparts == 1 && !cast_out && !dx_colsum, "lstm_bwd_ex: only the wavefront kernel (L <= 32, layers * roundup64(4L) <= 1024) sums gradient slabs / writes a cast copy");
+    RBVAE_CHECK_ARG(nparts == 1 && !cast_out && !dx_colsum && !bb.on, "lstm_bwd_ex: only the wavefront kernel (L <= 32, layers * roundup64(4L) <= 1024) sums gradient slabs / writes a cast copy");
     if (L <= 32)
         hipLaunchKernelGGL(lstm_bwd_k<32>, dim3(S), dim3(threads), lds, st, wblk, acts, cs, g_top, dG, dx, S, T, L, layers);
     else if (L <= 64)
@@ -936,7 +954,7 @@ static int lstm_bwd_impl(const float* wblk, const float* acts, const float* cs, 
 
 int rbvae_lstm_bwd(const float* wblk, const float* acts, const float* cs, const float* g_top, float* dG, float* dx,
                    int S, int T, int L, int layers, void* stream) {
-    return lstm_bwd_impl(wblk, acts, cs, g_top, dG, dx, S, T, L, layers, 1, 0, nullptr, 0, 0, nullptr, stream);
+    return lstm_bwd_impl(wblk, acts, cs, g_top, dG, dx, S, T, L, layers, 1, 0, nullptr, 0, 0, nullptr, BinBwd{}, stream);
 }
 
 int rbvae_lstm_bwd_ex(const float* wblk, const float* acts, const float* cs, const float* g_top_parts, int nparts,
@@ -944,7 +962,22 @@ int rbvae_lstm_bwd_ex(const float* wblk, const float* acts, const float* cs, con
                       float* dx_colsum, int S, int T, int L, int layers, void* stream) {
     RBVAE_CHECK_ARG(nparts >= 1 && (nparts == 1 || part_stride >= (long)S * T * L), "lstm_bwd_ex: bad slabs");
     return lstm_bwd_impl(wblk, acts, cs, g_top_parts, dG, dx, S, T, L, layers, nparts, part_stride, cast_out, cast_dtype,
-                         cast_ld, dx_colsum, stream);
+                         cast_ld, dx_colsum, BinBwd{}, stream);
+}
+
+int rbvae_lstm_bwd_bin(const float* wblk, const float* acts, const float* cs, const float* g_z, const float* y_soft,
+                       const float* z, const float* g_hs, float tau, float kl_weight, float kl_p, float kl_eps,
+                       int kl_clamp, float* dG, float* dx, void* cast_out, int cast_dtype, int cast_ld, float* dx_colsum,
+                       int S, int T, int L, int layers, void* stream) {
+    RBVAE_CHECK_ARG(g_z && y_soft && z && tau > 0.f, "lstm_bwd_bin: bad arguments");
+    RBVAE_CHECK_ARG(kl_weight == 0.f || (kl_p > 0.f && kl_p < 1.f), "lstm_bwd_bin: kl_p=%g outside (0,1)", kl_p);
+    BinBwd bb;
+    bb.gz = g_z; bb.y = y_soft; bb.z = z; bb.g_hs = g_hs; bb.tau = tau;
+    bb.klw = kl_weight / (float)((long)S * T);
+    bb.lp = kl_weight != 0.f ? logf(kl_p) : 0.f; bb.l1p = kl_weight != 0.f ? logf(1.0f - kl_p) : 0.f;
+    bb.keps = kl_eps; bb.clamp = kl_clamp; bb.on = 1;
+    return lstm_bwd_impl(wblk, acts, cs, g_z, dG, dx, S, T, L, layers, 1, 0, cast_out, cast_dtype, cast_ld, dx_colsum, bb,
+                         stream);
 }
 
 static int launch_lstm_wgrad(const float* dG, const float* hs_all, const float* hprev, float* gblk, const float* dG2,

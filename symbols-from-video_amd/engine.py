@@ -262,6 +262,7 @@ class Engine:
         self.lstm_cast = wave_ok and os.environ.get("RBVAE_LSTM_CAST", "1") == "1"
         # ... and, in forward passes that run both stacks, go as one launch with the binarisation between them
         self.lstm_pair = wave_ok and os.environ.get("RBVAE_LSTM_PAIR", "1") == "1"
+        self.bin_bwd_fused = wave_ok and os.environ.get("RBVAE_BIN_BWD_FUSED", "1") == "1"
         self._alloc_packed()
 
     # ---- packed weights -------------------------------------------------------
@@ -842,25 +843,33 @@ class Engine:
             gz = d_in_dec
             if g_z is not None:
                 gz = gz + g_z.reshape(N, Ld)
-            if g_hs is not None and g_hs_inplace and g_hs.is_contiguous():
-                dh = g_hs.view(N, Ld)
-                L.call("rbvae_binarize_kl_bwd", gz, sv.y, sv.z, dh, 1, N, Ld, float(sv.tau), float(kl_weight), None,
-                       float(kl_p), 1e-8, 1)
-            else:
-                dh = tmp("dh", N, Ld, dtype=f32)
-                L.call("rbvae_binarize_kl_bwd", gz, sv.y, sv.z, dh, 0, N, Ld, float(sv.tau), float(kl_weight), None,
-                       float(kl_p), 1e-8, 1)
-                if g_hs is not None:
-                    dh = dh + g_hs.reshape(N, Ld)
             de_pad = None
             de_sums = None
-            if self.lstm_cast:
+            if self.lstm_cast and self.bin_bwd_fused:
+                # binarise backward (+ fused KL) in the prologue of the encoder stack's BPTT launch
                 de_pad = tmp("de_pad", N, self.Lp)
-                de_sums = self._buf((N, "de_sums"), S * Ld)        # per-sequence column sums of de: fc bias gradient
-                L.call("rbvae_lstm_bwd_ex", wenc, sv.acts_enc, sv.cs_enc, dh, 1, 0, dGe, de, de_pad, self.dt, self.Lp,
-                       de_sums, S, T, Ld, nl)
+                de_sums = self._buf((N, "de_sums"), S * Ld)
+                L.call("rbvae_lstm_bwd_bin", wenc, sv.acts_enc, sv.cs_enc, gz, sv.y, sv.z,
+                       None if g_hs is None else g_hs.reshape(N, Ld).contiguous(), float(sv.tau), float(kl_weight),
+                       float(kl_p), 1e-8, 1, dGe, de, de_pad, self.dt, self.Lp, de_sums, S, T, Ld, nl)
             else:
-                L.call("rbvae_lstm_bwd", wenc, sv.acts_enc, sv.cs_enc, dh, dGe, de, S, T, Ld, nl)
+                if g_hs is not None and g_hs_inplace and g_hs.is_contiguous():
+                    dh = g_hs.view(N, Ld)
+                    L.call("rbvae_binarize_kl_bwd", gz, sv.y, sv.z, dh, 1, N, Ld, float(sv.tau), float(kl_weight), None,
+                           float(kl_p), 1e-8, 1)
+                else:
+                    dh = tmp("dh", N, Ld, dtype=f32)
+                    L.call("rbvae_binarize_kl_bwd", gz, sv.y, sv.z, dh, 0, N, Ld, float(sv.tau), float(kl_weight), None,
+                           float(kl_p), 1e-8, 1)
+                    if g_hs is not None:
+                        dh = dh + g_hs.reshape(N, Ld)
+                if self.lstm_cast:
+                    de_pad = tmp("de_pad", N, self.Lp)
+                    de_sums = self._buf((N, "de_sums"), S * Ld)        # per-sequence column sums of de: fc bias gradient
+                    L.call("rbvae_lstm_bwd_ex", wenc, sv.acts_enc, sv.cs_enc, dh, 1, 0, dGe, de, de_pad, self.dt, self.Lp,
+                           de_sums, S, T, Ld, nl)
+                else:
+                    L.call("rbvae_lstm_bwd", wenc, sv.acts_enc, sv.cs_enc, dh, dGe, de, S, T, Ld, nl)
         else:
             de_pad = None
             de_sums = None
