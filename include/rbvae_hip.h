@@ -222,6 +222,15 @@ int rbvae_col2im_sigmoid_frames(int dtype, const void* Y, int ldy, const float* 
                                 int OW, int Cout, int KH, int KW, int pad, float* xr, const float* target, int fd1,
                                 int fd2, long fs0, long fs1, long fs2, float* sse_mean, float* ws, float* dpre,
                                 float gscale, const float* gscale_dev, void* stream);
+/* The same layer as ONE kernel (bf16, Cout <= 4, C1 % 64 == 0): per-tap products on the matrix cores from an
+ * LDS-resident 9x17-pixel block of D2 [N*IH*IW][C1] and V [NYP][C1] (row = tap*Cout + co), f32 products kept in LDS,
+ * then the gather / bias / sigmoid / squared error / d(loss)/d(pre) of rbvae_col2im_sigmoid_frames.  ws receives
+ * `parts` squared-error sums and, behind them, parts x 4 column sums of dpre (parts = rbvae_deconv_last_fused_parts,
+ * 0 = shape not covered: use rbvae_gather_gemm + rbvae_col2im_sigmoid_frames).  fd1 == 0: frames at n*fs2. */
+int rbvae_deconv_last_fused_parts(int dtype, int N, int IH, int IW, int C1, int Cout);
+int rbvae_deconv_last_fused(int dtype, const void* D2, const void* V, int NYP, const float* bias, const void* zero_page,
+                            int N, int IH, int IW, int C1, int Cout, float* xr, const float* target, int fd1, int fd2,
+                            long fs0, long fs1, long fs2, float* ws, float* dpre, float gscale, void* stream);
 int rbvae_sigmoid_bwd_nhwc(const float* g_nchw, const float* xr_nchw, float* dpre_nhwc, int N, int C, int H, int W,
                            void* stream);
 /* Linear with few outputs (percep_RBVAE_model.py:61 forward; :74 backward-data):

@@ -1,0 +1,258 @@
+// The last ConvTranspose2d(C1 -> Cout <= 4, k3 s2 p1 op1) + Sigmoid + recon_loss of the decoder
+// (percep_RBVAE_model.py:82-83, percep_RBVAE_train.py:32-33) as ONE kernel, bf16 storage:
+//
+//   a workgroup takes an 8 x 16 block of INPUT pixels plus a one-pixel halo below / to the right (9 x 17), stages
+//   their C1-channel rows and the per-tap product matrix V[(tap, co)][C1] in LDS (LDS-DMA, swizzled 128-byte
+//   slices), forms Y[pixel][(tap, co)] on the matrix cores (f32, kept in LDS), and gathers the 16 x 32 block of
+//   OUTPUT pixels from it: + bias, sigmoid, x_recon (NCHW f32), squared error against the target, d(loss)/d(pre)
+//   (NHWC f32) and their per-workgroup sums.
+//
+// It replaces the product GEMM (Y to HBM as bf16) + the col2im pass of the two-kernel path; same sums in the same
+// tap order, with Y in f32 instead of bf16.
+#include "common.h"
+#include <stdlib.h>
+
+namespace rbvae {
+
+typedef __attribute__((ext_vector_type(8))) short bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
+
+struct DlFrameMap { int d1, d2; long s0, s1, s2; };
+__device__ __forceinline__ long dl_frame_off(const DlFrameMap& f, long n) {
+    if (f.d1 == 0) return n * f.s2;
+    const long a = n / f.d1, r = n - a * f.d1;
+    const long b = r / f.d2, c = r - b * f.d2;
+    return a * f.s0 + b * f.s1 + c * f.s2;
+}
+
+struct DlArgs {
+    const unsigned char* D2;     // [N*IH*IW][C1] bf16
+    const unsigned char* V;      // [NYP][C1] bf16, row = tap*Cout + co
+    const float* bias;           // [Cout]
+    const unsigned char* zero;   // >= 16 zero bytes
+    float* xr;                   // [N][Cout][OH][OW]
+    const float* target;         // frames through tfm (or null)
+    DlFrameMap tfm;
+    float* ws;                   // [gridDim.x] squared-error sums, then [gridDim.x][4] column sums of dpre (or null)
+    float* dpre;                 // [N][OH][OW][Cout] or null
+    float gscale;
+    int N, IH, IW, C1, NYP, Cout;
+};
+
+#ifndef DL_SL
+#define DL_SL 2          // 128-byte channel slices resident at a time (build switch: 1 -> three workgroups per CU)
+#endif
+constexpr int DL_TA = 8, DL_TB = 16;                 // input block
+constexpr int DL_HA = DL_TA + 1, DL_HB = DL_TB + 1;  // with halo
+constexpr int DL_PIX = DL_HA * DL_HB;                // 153
+constexpr int DL_MROWS = 160;                        // padded to MFMA tiles
+constexpr int DL_WROWS = 48;
+constexpr int DL_YP = 37;                            // Y row pitch (floats)
+
+__device__ __forceinline__ void dl_glds16(const void* g, void* lds) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                     (__attribute__((address_space(3))) void*)lds, 16, 0, 0);
+}
+
+__global__ __launch_bounds__(256, (DL_SL == 1 ? 3 : 2)) void deconv_last_fused_k(const DlArgs p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int KS = p.C1 >> 6;                                        // 128-byte slices per row
+    // Two slices (128 channels) are resident at a time: 40 KB of pixel rows + 12 KB of the product matrix + 24 KB of
+    // products keep a workgroup under 80 KB, so two share a CU and one's loads run under the other's MFMAs and
+    // gather phase (with all of C1 resident it was one workgroup per CU, every phase exposed, and slower than the
+    // two-kernel path).
+    constexpr int SL = DL_SL;
+    unsigned char* s_pix = smem;                                     // [SL][DL_MROWS][128]
+    unsigned char* s_wts = s_pix + (size_t)SL * DL_MROWS * 128;      // [SL][DL_WROWS][128]
+    float* s_y = (float*)(s_wts + (size_t)SL * DL_WROWS * 128);      // [DL_MROWS][DL_YP]
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int OH = 2 * p.IH, OW = 2 * p.IW;
+    const int tb_n = (p.IW + DL_TB - 1) / DL_TB, ta_n = (p.IH + DL_TA - 1) / DL_TA;
+    int blk = blockIdx.x;
+    const int tbi = blk % tb_n; blk /= tb_n;
+    const int tai = blk % ta_n;
+    const int n = blk / ta_n;
+    const int a0 = tai * DL_TA, b0 = tbi * DL_TB;
+
+    const int srow = lane >> 3, schunk = lane & 7;
+    const int fi = lane & 15, fg = lane >> 4;
+    const int fsw = (fi >> 1) & 7;
+    f32x4_t acc[3][3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int b = 0; b < 3; ++b) acc[a][b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    for (int s0 = 0; s0 < KS; s0 += SL) {
+        const int ns = min(SL, KS - s0);
+        if (s0) __syncthreads();                                     // everyone is done reading the previous slices
+        // ---- stage: one LDS-DMA instruction = 8 rows x 128 B of one slice
+        const int pix_instr = (DL_MROWS / 8) * ns, wts_instr = (DL_WROWS / 8) * ns;
+        for (int q = w; q < pix_instr + wts_instr; q += 4) {
+            const bool is_w = q >= pix_instr;
+            const int qq = is_w ? q - pix_instr : q;
+            const int rows8 = is_w ? DL_WROWS / 8 : DL_MROWS / 8;
+            const int sl = qq / rows8, r = (qq - sl * rows8) * 8 + srow;
+            const int s = s0 + sl;
+            const int sw = (schunk ^ ((r >> 1) & 7)) * 16;
+            const unsigned char* src = p.zero;
+            if (is_w) {
+                if (r < p.NYP) src = p.V + ((size_t)r * p.C1) * 2 + s * 128 + sw;
+            } else if (r < DL_PIX) {
+                const int la = r / DL_HB, lb = r - la * DL_HB;
+                const int a = a0 + la, b = b0 + lb;
+                if (a < p.IH && b < p.IW) src = p.D2 + ((size_t)((n * p.IH + a) * p.IW + b) * p.C1) * 2 + s * 128 + sw;
+            }
+            unsigned char* dst = (is_w ? s_wts + (size_t)sl * DL_WROWS * 128 : s_pix + (size_t)sl * DL_MROWS * 128) +
+                                 (size_t)(r - srow) * 128;
+            dl_glds16(src, dst);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        // ---- Y += pixels x V^T: wave w takes pixel tiles w, w+4, w+8 and all three (tap, co) tiles
+        for (int sl = 0; sl < ns; ++sl) {
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                const int ch = ((4 * kk + fg) ^ fsw) * 16;
+                u32x4_t wf[3];
+#pragma unroll
+                for (int rt = 0; rt < 3; ++rt)
+                    wf[rt] = *(const u32x4_t*)(s_wts + ((size_t)sl * DL_WROWS + rt * 16 + fi) * 128 + ch);
+#pragma unroll
+                for (int pi = 0; pi < 3; ++pi) {
+                    const int pt = w + 4 * pi;
+                    if (pt < DL_MROWS / 16) {
+                        const u32x4_t pf = *(const u32x4_t*)(s_pix + ((size_t)sl * DL_MROWS + pt * 16 + fi) * 128 + ch);
+#pragma unroll
+                        for (int rt = 0; rt < 3; ++rt)
+                            acc[pi][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8_t*)&wf[rt],
+                                                                                  *(const bf16x8_t*)&pf, acc[pi][rt], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    }
+    // D[(tap,co) row 4g + r][pixel i]
+#pragma unroll
+    for (int pi = 0; pi < 3; ++pi) {
+        const int pt = w + 4 * pi;
+        if (pt < DL_MROWS / 16) {
+#pragma unroll
+            for (int rt = 0; rt < 3; ++rt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int wr = rt * 16 + 4 * fg + r;
+                    if (wr < 36) s_y[(pt * 16 + fi) * DL_YP + wr] = acc[pi][rt][r];
+                }
+        }
+    }
+    __syncthreads();
+
+    // ---- output block 16 x 32: gather the taps, bias, sigmoid, losses
+    __shared__ float red5[4][5];
+    const int Cout = p.Cout;
+    const long plane = (long)OH * OW;
+    float sse = 0.f, dsum[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int q = tid; q < 2 * DL_TA * 2 * DL_TB; q += 256) {
+        const int oy = q / (2 * DL_TB), ox = q - oy * (2 * DL_TB);
+        const int oh = 2 * a0 + oy, ow = 2 * b0 + ox;
+        if (oh >= OH || ow >= OW) continue;
+        float v[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) v[c] = (p.bias && c < Cout) ? p.bias[c] : 0.f;
+        for (int kh = (oh + 1) & 1; kh < 3; kh += 2) {
+            const int a = (oh + 1 - kh) >> 1;
+            if (a < 0 || a >= p.IH) continue;
+            for (int kw = (ow + 1) & 1; kw < 3; kw += 2) {
+                const int b = (ow + 1 - kw) >> 1;
+                if (b < 0 || b >= p.IW) continue;
+                const float* yp = s_y + ((a - a0) * DL_HB + (b - b0)) * DL_YP + (kh * 3 + kw) * Cout;
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+                    if (c < Cout) v[c] += yp[c];
+            }
+        }
+        const size_t xo = (size_t)n * Cout * plane + (size_t)oh * OW + ow;
+        const float* tp = p.target ? p.target + dl_frame_off(p.tfm, n) + (size_t)oh * OW + ow : nullptr;
+        float d4[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            if (c >= Cout) break;
+            const float sg = sigmoidf_(v[c]);
+            p.xr[xo + (size_t)c * plane] = sg;
+            if (tp) {
+                const float d = sg - tp[(size_t)c * plane];
+                sse += d * d;
+                d4[c] = p.gscale * d * sg * (1.f - sg);
+            }
+        }
+        if (tp && p.dpre) {
+            float* dp = p.dpre + ((size_t)(n * OH + oh) * OW + ow) * Cout;
+            if (Cout == 4) *(float4*)dp = make_float4(d4[0], d4[1], d4[2], d4[3]);
+            else
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+                    if (c < Cout) dp[c] = d4[c];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) dsum[c] += d4[c];
+        }
+    }
+    if (p.ws) {
+        float vals[5] = {sse, dsum[0], dsum[1], dsum[2], dsum[3]};
+#pragma unroll
+        for (int k = 0; k < 5; ++k) vals[k] = wave_sum(vals[k]);
+        if (lane == 0) {
+#pragma unroll
+            for (int k = 0; k < 5; ++k) red5[w][k] = vals[k];
+        }
+        __syncthreads();
+        if (tid < 5) {
+            const float t = ((red5[0][tid] + red5[1][tid]) + red5[2][tid]) + red5[3][tid];
+            if (tid == 0) p.ws[blockIdx.x] = t;
+            else if (p.dpre) p.ws[gridDim.x + 4 * blockIdx.x + (tid - 1)] = t;
+        }
+    }
+}
+
+static int dl_blocks(int N, int IH, int IW) { return N * cdiv(IH, DL_TA) * cdiv(IW, DL_TB); }
+static size_t dl_lds(int C1) { (void)C1; return (size_t)DL_SL * (DL_MROWS + DL_WROWS) * 128 + (size_t)DL_MROWS * DL_YP * 4; }
+
+}  // namespace rbvae
+
+using namespace rbvae;
+
+/* workgroups of the launch (= partial sums in ws) when the fused kernel covers the shape, else 0 */
+extern "C" int rbvae_deconv_last_fused_parts(int dtype, int N, int IH, int IW, int C1, int Cout) {
+    if (dtype != RBVAE_BF16 || Cout < 1 || Cout > 4 || C1 % 64 || C1 < 64 || dl_lds(C1) > 160 * 1024 - 256) return 0;
+    if ((long)N * 2 * IH * 2 * IW * Cout >= (1l << 31) || (long)N * IH * IW * C1 >= (1l << 31)) return 0;
+    return dl_blocks(N, IH, IW);
+}
+
+extern "C" int rbvae_deconv_last_fused(int dtype, const void* D2, const void* V, int NYP, const float* bias,
+                                       const void* zero_page, int N, int IH, int IW, int C1, int Cout, float* xr,
+                                       const float* target, int fd1, int fd2, long fs0, long fs1, long fs2, float* ws,
+                                       float* dpre, float gscale, void* stream) {
+    RBVAE_CHECK_ARG(D2 && V && zero_page && xr, "deconv_last_fused: null pointer");
+    RBVAE_CHECK_ARG(rbvae_deconv_last_fused_parts(dtype, N, IH, IW, C1, Cout) > 0,
+                    "deconv_last_fused: shape outside the fused kernel (bf16, Cout <= 4, C1 %% 64 == 0): N=%d %dx%d C1=%d Cout=%d",
+                    N, IH, IW, C1, Cout);
+    RBVAE_CHECK_ARG(NYP >= 9 * Cout && NYP <= DL_WROWS, "deconv_last_fused: NYP=%d", NYP);
+    RBVAE_CHECK_ARG(!dpre || (target && ws), "deconv_last_fused: dpre needs target and ws");
+    RBVAE_CHECK_ARG(((uintptr_t)D2 | (uintptr_t)V | (uintptr_t)zero_page | (uintptr_t)dpre) % 16 == 0,
+                    "deconv_last_fused: pointers must be 16-byte aligned");
+    DlArgs a;
+    a.D2 = (const unsigned char*)D2; a.V = (const unsigned char*)V; a.bias = bias; a.zero = (const unsigned char*)zero_page;
+    a.xr = xr; a.target = target; a.tfm = DlFrameMap{fd1, fd2, fs0, fs1, fs2}; a.ws = target ? ws : nullptr; a.dpre = dpre;
+    a.gscale = gscale; a.N = N; a.IH = IH; a.IW = IW; a.C1 = C1; a.NYP = NYP; a.Cout = Cout;
+    const size_t lds = dl_lds(C1);
+    static size_t attr_lds = 0;
+    if (lds > attr_lds) {               // dynamic + the kernel's 80 static bytes must stay within the 160 KB of a CU
+        hipError_t e = hipFuncSetAttribute((const void*)deconv_last_fused_k, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)lds);
+        if (e != hipSuccess) return fail(RBVAE_E_LAUNCH, "deconv_last_fused: %s (dynamic LDS %zu)", hipGetErrorString(e), lds);
+        attr_lds = lds;
+    }
+    hipLaunchKernelGGL(deconv_last_fused_k, dim3(dl_blocks(N, IH, IW)), dim3(256), lds, (hipStream_t)stream, a);
+    RBVAE_CHECK_LAUNCH("deconv_last_fused");
+    return RBVAE_OK;
+}

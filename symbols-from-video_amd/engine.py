@@ -263,6 +263,7 @@ class Engine:
         # ... and, in forward passes that run both stacks, go as one launch with the binarisation between them
         self.lstm_pair = wave_ok and os.environ.get("RBVAE_LSTM_PAIR", "1") == "1"
         self.bin_bwd_fused = wave_ok and os.environ.get("RBVAE_BIN_BWD_FUSED", "1") == "1"
+        self.deconv_fused = os.environ.get("RBVAE_DECONV_FUSED", "1") == "1"
         self._alloc_packed()
 
     # ---- packed weights -------------------------------------------------------
@@ -675,37 +676,54 @@ class Engine:
         m, mk = dm(3)
         self._gemm(sv.d1, self.V2d, sv.d2, P(f"decoder_cnn.deconv.{i1}.bias"), None, mk, N, h2, w2, h2, w2, 1, h1, w1,
                    2, c2, c1, c2, c1, kk, "dgrad", relu=1, drop_mode=m, drop_p=drop, scale=dscale, seed=seed * 8 + 4)
-        Y = self._E(N * h1 * w1, self.NY)
-        self._gemm(sv.d2, self.V3p, Y, None, None, None, N * h1 * w1, 1, 1, 1, 1, 1, 1, 1, 1, c1, self.NY, c1,
-                   self.NY, 1, "one")
         sv.xr = self._E(S, T, self.out_ch, H, W, dtype=torch.float32)
         mse = None
         sse = None
         sv.dpre3 = None
         sv.b3_parts = None
-        if target is not None:
-            # persistent (one fused forward is in flight at a time): the backward pass's job table points into it
-            ws = self._buf((N, "col2im_ws"), L.query("rbvae_col2im_ws_floats"))
-            if defer_losses:    # per-block partial sums stay in ws; rbvae_combine_losses finishes the mean
-                sse = (ws, L.query("rbvae_col2im_nparts", sv.xr.numel()), 1.0 / sv.xr.numel())
-            else:
-                mse = self._E(1, dtype=torch.float32)
-            if need_grad:
-                sv.dpre3 = self._E(N, H, W, self.out_ch, dtype=torch.float32)
-                if L.query("rbvae_col2im_has_dcol", N, h1, w1, self.NY, H, W, self.out_ch):
-                    # the kernel leaves dpre3's per-block column sums (the last deconv's bias gradient) behind the
-                    # squared-error sums in ws
-                    sv.b3_parts = (ws, L.query("rbvae_col2im_nparts", sv.xr.numel()))
-            if frame_map is None:
-                L.call("rbvae_col2im_sigmoid", self.dt, Y, self.NY, P(f"decoder_cnn.deconv.{i2}.bias"), N, h1, w1, H, W,
-                       self.out_ch, k, k, 1, sv.xr, target.contiguous(), mse, ws, sv.dpre3, float(recon_gscale), None)
-            else:
-                L.call("rbvae_col2im_sigmoid_frames", self.dt, Y, self.NY, P(f"decoder_cnn.deconv.{i2}.bias"), N, h1,
-                       w1, H, W, self.out_ch, k, k, 1, sv.xr, target.contiguous(), *frame_map, mse, ws, sv.dpre3,
-                       float(recon_gscale), None)
+        fparts = L.query("rbvae_deconv_last_fused_parts", self.dt, N, h1, w1, c1, self.out_ch) if (
+            self.deconv_fused and k == 3 and (target is None or defer_losses)) else 0
+        if fparts:
+            # last deconv + sigmoid + recon loss as one kernel (products on the matrix cores from an LDS-resident pixel
+            # block, kept in f32): no product matrix in HBM, no separate col2im pass
+            ws = None
+            fm = frame_map if frame_map is not None else (0, 0, 0, 0, self.out_ch * H * W)
+            if target is not None:
+                ws = self._buf((N, "col2im_ws"), max(L.query("rbvae_col2im_ws_floats"), 5 * fparts))
+                sse = (ws, fparts, 1.0 / sv.xr.numel())
+                if need_grad:
+                    sv.dpre3 = self._E(N, H, W, self.out_ch, dtype=torch.float32)
+                    sv.b3_parts = (ws, fparts)
+            L.call("rbvae_deconv_last_fused", self.dt, sv.d2, self.V3p, self.NY, P(f"decoder_cnn.deconv.{i2}.bias"),
+                   self.zero, N, h1, w1, c1, self.out_ch, sv.xr, None if target is None else target.contiguous(), *fm, ws,
+                   sv.dpre3, float(recon_gscale))
         else:
-            L.call("rbvae_col2im_sigmoid", self.dt, Y, self.NY, P(f"decoder_cnn.deconv.{i2}.bias"), N, h1, w1, H, W,
-                   self.out_ch, k, k, 1, sv.xr, None, None, None, None, 0.0, None)
+            Y = self._E(N * h1 * w1, self.NY)
+            self._gemm(sv.d2, self.V3p, Y, None, None, None, N * h1 * w1, 1, 1, 1, 1, 1, 1, 1, 1, c1, self.NY, c1,
+                       self.NY, 1, "one")
+            if target is not None:
+                # persistent (one fused forward is in flight at a time): the backward pass's job table points into it
+                ws = self._buf((N, "col2im_ws"), L.query("rbvae_col2im_ws_floats"))
+                if defer_losses:    # per-block partial sums stay in ws; rbvae_combine_losses finishes the mean
+                    sse = (ws, L.query("rbvae_col2im_nparts", sv.xr.numel()), 1.0 / sv.xr.numel())
+                else:
+                    mse = self._E(1, dtype=torch.float32)
+                if need_grad:
+                    sv.dpre3 = self._E(N, H, W, self.out_ch, dtype=torch.float32)
+                    if L.query("rbvae_col2im_has_dcol", N, h1, w1, self.NY, H, W, self.out_ch):
+                        # the kernel leaves dpre3's per-block column sums (the last deconv's bias gradient) behind the
+                        # squared-error sums in ws
+                        sv.b3_parts = (ws, L.query("rbvae_col2im_nparts", sv.xr.numel()))
+                if frame_map is None:
+                    L.call("rbvae_col2im_sigmoid", self.dt, Y, self.NY, P(f"decoder_cnn.deconv.{i2}.bias"), N, h1, w1, H, W,
+                           self.out_ch, k, k, 1, sv.xr, target.contiguous(), mse, ws, sv.dpre3, float(recon_gscale), None)
+                else:
+                    L.call("rbvae_col2im_sigmoid_frames", self.dt, Y, self.NY, P(f"decoder_cnn.deconv.{i2}.bias"), N, h1,
+                           w1, H, W, self.out_ch, k, k, 1, sv.xr, target.contiguous(), *frame_map, mse, ws, sv.dpre3,
+                           float(recon_gscale), None)
+            else:
+                L.call("rbvae_col2im_sigmoid", self.dt, Y, self.NY, P(f"decoder_cnn.deconv.{i2}.bias"), N, h1, w1, H, W,
+                       self.out_ch, k, k, 1, sv.xr, None, None, None, None, 0.0, None)
         if pending_hs is not None:
             with self._on_side(0, self.SIDE_PAIR):
                 after_hs(pending_hs)

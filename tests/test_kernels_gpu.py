@@ -462,3 +462,42 @@ def test_lstm_pair_forward_equals_three_launches(sfv, L, layers, S, T, hard):
     assert abs(parts0.sum().item() - parts1.sum().item()) < 1e-4 * max(1.0, abs(parts0.sum().item()))
     # shapes outside the fused kernel are refused
     assert not sfv._lib.query("rbvae_lstm_pair_fwd_ok", 8, 64, 2)
+
+
+@pytest.mark.parametrize("N,IH,IW,C1,Cout", [(3, 16, 16, 256, 4), (2, 11, 20, 256, 4), (2, 8, 8, 64, 3), (1, 5, 37, 128, 4)])
+def test_deconv_last_fused(sfv, N, IH, IW, C1, Cout):
+    """rbvae_deconv_last_fused (per-tap products on the MFMA from an LDS-resident pixel block + gather + sigmoid +
+    squared error + d(loss)/d(pre) + their sums) against F.conv_transpose2d on the bf16-rounded operands, incl.
+    blocks that stick out of the image (11x20, 5x37) and a frame-mapped target."""
+    L = sfv._lib
+    g = torch.Generator().manual_seed(60 + IH + C1)
+    a = (torch.randn(N, C1, IH, IW, generator=g) * 0.5).bfloat16()
+    V = (torch.randn(C1, Cout, 3, 3, generator=g) * 0.1).bfloat16()
+    b = torch.randn(Cout, generator=g)
+    OH, OW = 2 * IH, 2 * IW
+    tgt = torch.rand(N, Cout, OH, OW, generator=g)
+    ref = torch.sigmoid(F.conv_transpose2d(a.float(), V.float(), b, stride=2, padding=1, output_padding=1))
+    parts = L.query("rbvae_deconv_last_fused_parts", 1, N, IH, IW, C1, Cout)
+    assert parts == N * -(-IH // 8) * -(-IW // 16)
+    NY = -(-9 * Cout // 8) * 8
+    Vp = torch.zeros(NY, C1, dtype=torch.bfloat16)
+    Vp[:9 * Cout] = V.float().permute(2, 3, 1, 0).reshape(9 * Cout, C1).bfloat16()        # row = (kh*3+kw)*Cout + co
+    rows = a.permute(0, 2, 3, 1).reshape(N * IH * IW, C1).contiguous().cuda()
+    zero = torch.zeros(256, dtype=torch.uint8, device="cuda")
+    xr = torch.empty(N, Cout, OH, OW, device="cuda")
+    ws = torch.zeros(5 * parts, device="cuda")
+    dpre = torch.empty(N, OH, OW, Cout, device="cuda")
+    L.call("rbvae_deconv_last_fused", 1, rows, Vp.cuda(), NY, b.cuda(), zero, N, IH, IW, C1, Cout, xr, tgt.cuda(), 0, 0, 0,
+           0, Cout * OH * OW, ws, dpre, 0.5)
+    np.testing.assert_allclose(xr.cpu().numpy(), ref.numpy(), atol=2e-5)
+    assert abs(ws[:parts].sum().item() / tgt.numel() - ((ref - tgt) ** 2).mean().item()) < 1e-5
+    dref = 0.5 * (ref - tgt) * ref * (1 - ref)
+    np.testing.assert_allclose(dpre.cpu().permute(0, 3, 1, 2).numpy(), dref.numpy(), atol=1e-5)
+    np.testing.assert_allclose(ws[parts:].view(parts, 4).sum(0)[:Cout].cpu().numpy(), dref.sum((0, 2, 3)).numpy(), rtol=1e-4,
+                               atol=1e-4)
+    # without a target: x_recon only
+    xr2 = torch.empty_like(xr)
+    L.call("rbvae_deconv_last_fused", 1, rows, Vp.cuda(), NY, b.cuda(), zero, N, IH, IW, C1, Cout, xr2, None, 0, 0, 0, 0,
+           Cout * OH * OW, None, None, 0.0)
+    assert torch.equal(xr2, xr)
+    assert L.query("rbvae_deconv_last_fused_parts", 0, N, IH, IW, C1, Cout) == 0            # f32 mode: two-kernel path
