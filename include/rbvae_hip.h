@@ -195,6 +195,16 @@ int rbvae_run_jobs(const void* jobs_dev, int njobs, int blocks_per_job, void* st
  * ConvTranspose2d's backward run as plain GEMMs on it. */
 int rbvae_im2col(int dtype, const float* src, long sn, long sc, long sh, long sw, int N, int C, int IH, int IW,
                  int OH, int OW, int KH, int KW, int stride, int pad, int Kpad, void* col, void* stream);
+/* The first Conv2d(3x3, stride 2, pad 1; Cin <= 4 -> Nout <= 256) + bias + ReLU + Dropout (percep_RBVAE_model.py:51-53)
+ * as ONE kernel, bf16: rbvae_im2col_frames (col [N*OH*OW][64] is still written: the weight gradient reads it) + the
+ * single-slice rbvae_gather_gemm, with the patch gathered in LDS and results stored from the accumulators.  W is the
+ * packed [Nout][64] im2col-order weight; x frames f32 [Cin][IH][IW] through the frame map (fd1 == 0: frame n at
+ * n*fs2); drop_mode 0 / 1 with rbvae_gather_gemm's key and element indices. */
+int rbvae_conv_first_fused_ok(int dtype, int Cin, int IH, int IW, int Nout, int N);
+int rbvae_conv_first_fused(int dtype, const float* x, int fd1, int fd2, long fs0, long fs1, long fs2, const void* W,
+                           const float* bias, const void* zero_page, void* col, void* out, int N, int Cin, int IH, int IW,
+                           int Nout, int ldo, int relu, int drop_mode, float drop_p, float scale, unsigned long long seed,
+                           const unsigned long long* seed_dev, void* stream);
 /* Last ConvTranspose2d + Sigmoid (percep_RBVAE_model.py:82-83) fused with recon_loss
  * (percep_RBVAE_train.py:32-33): Y[(n,a,b)][t*Cout+co] = per-tap products; gathers them (col2im),
  * adds bias, applies sigmoid, writes x_recon NCHW f32; with target: sse_mean[0] = mse and

@@ -139,5 +139,29 @@ __device__ __forceinline__ unsigned drop_chunk_mask(unsigned run, unsigned thres
     }
     return drop;
 }
+// The same decisions applied in place, without the detour through a bit mask (compare + select per element):
+// x[0..EC) are f32 values / w[0..EC/2) are words of two packed 16-bit elements.
+template <int EC>
+__device__ __forceinline__ void drop_chunk_zero_f32(unsigned run, unsigned thresh16, float* x) {
+    unsigned s = drop_bits(run, 0);
+#pragma unroll
+    for (int e = 0; e < EC; e += 2) {
+        x[e] = (s & 0xffffu) < thresh16 ? 0.f : x[e];
+        x[e + 1] = (s >> 16) < thresh16 ? 0.f : x[e + 1];
+        if (e + 2 < EC) { s ^= s << 13; s ^= s >> 17; s ^= s << 5; }
+    }
+}
+template <int EC>
+__device__ __forceinline__ void drop_chunk_zero_b16(unsigned run, unsigned thresh16, unsigned* w) {
+    unsigned s = drop_bits(run, 0);
+#pragma unroll
+    for (int e = 0; e < EC; e += 2) {
+        unsigned v = w[e >> 1];
+        v = (s & 0xffffu) < thresh16 ? (v & 0xffff0000u) : v;
+        v = (s >> 16) < thresh16 ? (v & 0x0000ffffu) : v;
+        w[e >> 1] = v;
+        if (e + 2 < EC) { s ^= s << 13; s ^= s >> 17; s ^= s << 5; }
+    }
+}
 
 }  // namespace rbvae

@@ -488,10 +488,8 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void gather_gemm_k(const GgArgs p)
             T* ev = (T*)&val;
             if (p.drop_mode == 1) {
                 const unsigned run = drop_run(dkey, (unsigned long long)orow * p.Nout + col);
-                const unsigned dm = drop_chunk_mask<EC>(run, p.drop_thresh >> 16);
-#pragma unroll
-                for (int e = 0; e < EC; ++e)
-                    if ((dm >> e) & 1u) ev[e] = 0;
+                if constexpr (sizeof(T) == 2) drop_chunk_zero_b16<EC>(run, p.drop_thresh >> 16, (unsigned*)&val);
+                else drop_chunk_zero_f32<EC>(run, p.drop_thresh >> 16, (float*)&val);
             } else if (p.drop_mode == 2) {
                 const unsigned char* mk = p.mask + (size_t)orow * p.Nout + col;
 #pragma unroll

@@ -264,6 +264,7 @@ class Engine:
         self.lstm_pair = wave_ok and os.environ.get("RBVAE_LSTM_PAIR", "1") == "1"
         self.bin_bwd_fused = wave_ok and os.environ.get("RBVAE_BIN_BWD_FUSED", "1") == "1"
         self.deconv_fused = os.environ.get("RBVAE_DECONV_FUSED", "1") == "1"
+        self.conv_first_fused = os.environ.get("RBVAE_CONV_FIRST_FUSED", "1") == "1"
         self._alloc_packed()
 
     # ---- packed weights -------------------------------------------------------
@@ -544,16 +545,19 @@ class Engine:
         if repack:
             self.pack_begin(flat)
         sv.col1 = self._E(N * h1 * w1, self.K1)
-        if frame_map is None:
-            L.call("rbvae_im2col", self.dt, x, C * H * W, H * W, W, 1, N, C, H, W, h1, w1, k, k, 2, 1, self.K1, sv.col1)
-        else:
-            L.call("rbvae_im2col_frames", self.dt, x, *frame_map, H * W, W, 1, N, C, H, W, h1, w1, k, k, 2, 1, self.K1,
-                   sv.col1)
         sv.a1 = self._E(N * h1 * w1, c1)
         m, mk = dm(0)
-        self._gemm(sv.col1, self.W1p, sv.a1, P(f"encoder_cnn.conv.{i0}.bias"), None, mk, N * h1 * w1, 1, 1, 1, 1, 1,
-                   1, 1, 1, self.K1, c1, self.K1, c1, 1, "one", relu=1, drop_mode=m, drop_p=drop, scale=dscale,
-                   seed=seed * 8 + 1)
+        fm = frame_map if frame_map is not None else (0, 0, 0, 0, C * H * W)
+        if (self.conv_first_fused and k == 3 and self.K1 == 64 and m != 2
+                and L.query("rbvae_conv_first_fused_ok", self.dt, C, H, W, c1, N)):
+            # im2col + GEMM + bias/ReLU/dropout of the first conv in one kernel (csrc/conv_first.hip)
+            L.call("rbvae_conv_first_fused", self.dt, x, *fm, self.W1p, P(f"encoder_cnn.conv.{i0}.bias"), self.zero,
+                   sv.col1, sv.a1, N, C, H, W, c1, c1, 1, m, float(drop), float(dscale), int(seed * 8 + 1), self.seed_dev)
+        else:
+            L.call("rbvae_im2col_frames", self.dt, x, *fm, H * W, W, 1, N, C, H, W, h1, w1, k, k, 2, 1, self.K1, sv.col1)
+            self._gemm(sv.col1, self.W1p, sv.a1, P(f"encoder_cnn.conv.{i0}.bias"), None, mk, N * h1 * w1, 1, 1, 1, 1, 1,
+                       1, 1, 1, self.K1, c1, self.K1, c1, 1, "one", relu=1, drop_mode=m, drop_p=drop, scale=dscale,
+                       seed=seed * 8 + 1)
         if repack:
             self.pack_end()
         sv.a2 = self._E(N * h2 * w2, c2)

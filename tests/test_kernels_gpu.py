@@ -501,3 +501,59 @@ def test_deconv_last_fused(sfv, N, IH, IW, C1, Cout):
            Cout * OH * OW, None, None, 0.0)
     assert torch.equal(xr2, xr)
     assert L.query("rbvae_deconv_last_fused_parts", 0, N, IH, IW, C1, Cout) == 0            # f32 mode: two-kernel path
+
+
+@pytest.mark.parametrize("N,Cin,IH,IW,Nout,drop", [(3, 4, 32, 32, 256, 0.1), (2, 3, 21, 40, 64, 0.0), (2, 4, 7, 70, 200, 0.3),
+                                                    (5, 1, 16, 16, 32, 0.1)])
+def test_conv_first_fused(sfv, N, Cin, IH, IW, Nout, drop):
+    """rbvae_conv_first_fused (patch gather in LDS + MFMA + bias/ReLU/dropout from the accumulators) is bit-identical
+    to rbvae_im2col_frames + the single-slice rbvae_gather_gemm it replaces -- col rows, outputs and dropout pattern
+    (same key and element indices) -- incl. blocks that stick out of the image, odd sizes, Nout % 32 != 0 and a
+    frame-mapped input; and agrees with F.conv2d on the bf16-rounded operands."""
+    L = sfv._lib
+    g = torch.Generator().manual_seed(70 + IH + Nout)
+    OH, OW = (IH - 1) // 2 + 1, (IW - 1) // 2 + 1
+    P = N * OH * OW
+    x = torch.randn(N, Cin, IH, IW, generator=g).cuda()
+    Wt = (torch.randn(Nout, Cin, 3, 3, generator=g) * 0.2)
+    b = torch.randn(Nout, generator=g).cuda()
+    Wp = torch.zeros(Nout, 64, dtype=torch.bfloat16)
+    Wp[:, :9 * Cin] = Wt.permute(0, 2, 3, 1).reshape(Nout, 9 * Cin).bfloat16()               # column = (kh*3+kw)*Cin + ci
+    Wp = Wp.cuda()
+    zero = torch.zeros(256, dtype=torch.uint8, device="cuda")
+    scale = 1.0 / (1.0 - drop)
+    mode = 1 if drop > 0 else 0
+    assert L.query("rbvae_conv_first_fused_ok", 1, Cin, IH, IW, Nout, N) == 1
+    assert L.query("rbvae_conv_first_fused_ok", 0, Cin, IH, IW, Nout, N) == 0                  # f32 mode: two-kernel path
+    assert L.query("rbvae_conv_first_fused_ok", 1, 8, IH, IW, Nout, N) == 0
+    col_a = torch.empty(P, 64, dtype=torch.bfloat16, device="cuda")
+    out_a = torch.empty(P, Nout, dtype=torch.bfloat16, device="cuda")
+    L.call("rbvae_im2col_frames", 1, x, 0, 0, 0, 0, Cin * IH * IW, IH * IW, IW, 1, N, Cin, IH, IW, OH, OW, 3, 3, 2, 1, 64, col_a)
+    gemm(sfv, 1, col_a, Wp, out_a, b, None, None, (P, 1, 1, 1, 1, 1, 1, 1, 1), 64, Nout, 1, [1, 0, 0, 0, 0, 0], 1, relu=1,
+         drop_mode=mode, drop_p=float(drop), scale=float(scale), seed=77)
+    col_b = torch.empty_like(col_a)
+    out_b = torch.empty_like(out_a)
+    L.call("rbvae_conv_first_fused", 1, x, 0, 0, 0, 0, Cin * IH * IW, Wp, b, zero, col_b, out_b, N, Cin, IH, IW, Nout, Nout, 1,
+           mode, float(drop), float(scale), 77, None)
+    assert torch.equal(col_a.view(torch.int16), col_b.view(torch.int16))
+    assert torch.equal(out_a.view(torch.int16), out_b.view(torch.int16))
+    ref = F.relu(F.conv2d(x.cpu().bfloat16().float(), Wt.bfloat16().float(), b.cpu(), stride=2, padding=1)) * scale
+    got = out_b.float().cpu().view(N, OH, OW, Nout).permute(0, 3, 1, 2)
+    kept = got != 0
+    np.testing.assert_allclose(got[kept].numpy(), ref[kept].numpy(), rtol=1e-2, atol=1e-2)
+    if drop > 0:
+        frac = 1.0 - kept.sum().item() / (ref != 0).sum().item()
+        assert abs(frac - drop) < 0.02
+    # frame-mapped input: frame n = (s, t) of an item buffer [S][2][T] taken at view 1 -> s*s0 + t*s2 from the view's base
+    S, T = 2, N
+    buf = torch.randn(S, 2, T, Cin, IH, IW, generator=g).cuda()
+    fsz = Cin * IH * IW
+    dense = buf[:, 1].contiguous()
+    L.call("rbvae_conv_first_fused", 1, dense, 0, 0, 0, 0, fsz, Wp, b, zero, col_a[:0].new_empty(S * T * OH * OW, 64),
+           (o1 := torch.empty(S * T * OH * OW, Nout, dtype=torch.bfloat16, device="cuda")), S * T, Cin, IH, IW, Nout, Nout, 1, 0,
+           0.0, 1.0, 0, None)
+    L.call("rbvae_conv_first_fused", 1, buf[:, 1], T, T, 2 * T * fsz, 0, fsz, Wp, b, zero,
+           col_a[:0].new_empty(S * T * OH * OW, 64),
+           (o2 := torch.empty(S * T * OH * OW, Nout, dtype=torch.bfloat16, device="cuda")), S * T, Cin, IH, IW, Nout, Nout, 1, 0,
+           0.0, 1.0, 0, None)
+    assert torch.equal(o1.view(torch.int16), o2.view(torch.int16))
