@@ -205,6 +205,17 @@ int rbvae_conv_first_fused(int dtype, const float* x, int fd1, int fd2, long fs0
                            const float* bias, const void* zero_page, void* col, void* out, int N, int Cin, int IH, int IW,
                            int Nout, int ldo, int relu, int drop_mode, float drop_p, float scale, unsigned long long seed,
                            const unsigned long long* seed_dev, void* stream);
+/* Input gradient of the last ConvTranspose2d (autograd of percep_RBVAE_model.py:82; k3 s2 p1) as ONE kernel, bf16: the
+ * 3x3 stride-2 convolution of dpre [N][OH][OW][Cout] f32 (rbvae_deconv_last_fused's d(loss)/d(pre-sigmoid)) with the packed
+ * weight W [C1][64] (column (kh*3+kw)*Cout + co), times scale, kept where gate [rows][ldo] (the stored ReLU/dropout output
+ * of the layer below) is > 0 -- rbvae_im2col + the single-slice rbvae_gather_gemm, bit-identical stored values.  col
+ * [rows][64] receives the im2col rows (the last deconv's weight gradient reads them); colsum_ws
+ * [rbvae_deconv_last_dgrad_blocks][C1] (optional) the per-workgroup column sums of the stored output (bias gradient of
+ * the layer below).  rows = N * ceil(OH/2) * ceil(OW/2). */
+int rbvae_deconv_last_dgrad_blocks(int dtype, int Cout, int OH, int OW, int C1, int N);
+int rbvae_deconv_last_dgrad_fused(int dtype, const float* dpre, const void* W, const void* zero_page, void* col,
+                                  const void* gate, void* out, int N, int Cout, int OH, int OW, int C1, int ldo, float scale,
+                                  float* colsum_ws, void* stream);
 /* Last ConvTranspose2d + Sigmoid (percep_RBVAE_model.py:82-83) fused with recon_loss
  * (percep_RBVAE_train.py:32-33): Y[(n,a,b)][t*Cout+co] = per-tap products; gathers them (col2im),
  * adds bias, applies sigmoid, writes x_recon NCHW f32; with target: sse_mean[0] = mse and

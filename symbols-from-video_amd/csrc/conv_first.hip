@@ -1,14 +1,18 @@
-// The first Conv2d(Cin <= 4 -> Nout <= 256, k3 s2 p1) + bias + ReLU + Dropout of the encoder
-// (percep_RBVAE_model.py:51-53) as ONE kernel, bf16 storage:
+// The two HBM-bound 3x3 stride-2 convolutions at the 3/4-channel ends of the CNNs, each as ONE kernel (bf16 storage):
 //
-//   a workgroup takes an 8 x 16 block of OUTPUT pixels of one frame, loads the 17 x 33 input patch of every channel
-//   with coalesced loads (f32 NCHW, frames through the frame map), builds the im2col rows [128][64] (column
-//   (kh*3+kw)*Cin + ci, zero padded) as the swizzled LDS image the MFMA fragments read -- and writes them to
-//   col1, which the weight gradient reads later -- stages W [Nout][64] by LDS-DMA, multiplies on the matrix cores
-//   and stores bias / ReLU / scale / keyed-dropout results straight from the accumulators as 16-byte chunks.
+//   MODE 0  the encoder's first Conv2d(Cin <= 4 -> Nout <= 256) + bias + ReLU + Dropout (percep_RBVAE_model.py:51-53),
+//           input frames f32 NCHW through the frame map;
+//   MODE 1  the input gradient of the decoder's last ConvTranspose2d (autograd of :82) = the same convolution of
+//           d(loss)/d(pre-sigmoid) [N][H][W][Cin] f32 (NHWC, as rbvae_deconv_last_fused leaves it) with the deconv weight,
+//           gated by the stored ReLU/dropout output of the layer below and column-summed for that layer's bias gradient.
 //
-// It replaces rbvae_im2col + the single-slice gather GEMM of the two-kernel path (same arithmetic per element:
-// one 64-deep MFMA chain; same dropout key and chunk indices).
+// A workgroup takes an 8 x 16 block of OUTPUT pixels of one frame, loads the 17 x 33 input patch with coalesced loads,
+// builds the im2col rows [128][64] (column (kh*3+kw)*Cin + ci, zero padded) as the swizzled LDS image the MFMA fragments
+// read -- and writes them to `col`, which the weight gradient reads later -- stages W [Nout][64] by LDS-DMA, multiplies on
+// the matrix cores and stores the epilogue's results straight from the accumulators, 32 bytes per lane and pixel.
+//
+// They replace rbvae_im2col(_frames) + the single-slice rbvae_gather_gemm (same arithmetic per element: one 64-deep MFMA
+// chain; same dropout key and chunk indices; stored values are bit-identical).
 #include "common.h"
 #include <stdlib.h>
 
@@ -31,13 +35,15 @@ __device__ __forceinline__ long cf_frame_off(const CfFrameMap& f, unsigned n) {
 }
 
 struct CfArgs {
-    const float* x;              // frames [Cin][IH][IW] f32 at cf_frame_off(fm, n)
+    const float* x;              // MODE 0: frames [Cin][IH][IW] f32 at cf_frame_off(fm, n); MODE 1: [N][IH][IW][Cin] f32
     CfFrameMap fm;
     const unsigned char* W;      // [Nout][64] bf16 (im2col column order, zero padded)
-    const float* bias;           // [Nout] or null
+    const float* bias;           // [Nout] or null (MODE 0)
     const unsigned char* zero;   // >= 16 zero bytes
     unsigned char* col;          // [N*OH*OW][64] bf16 out
     unsigned char* out;          // [N*OH*OW][ldo] bf16 out
+    const unsigned char* gate;   // MODE 1: [N*OH*OW][ldo] bf16, output kept where gate > 0
+    float* colsum_ws;            // MODE 1: [blocks][Nout] column sums of the stored output, or null
     int N, Cin, IH, IW, OH, OW, Nout, ldo, relu, drop_mode;
     float scale;
     unsigned drop_thresh;
@@ -47,15 +53,16 @@ struct CfArgs {
 
 constexpr int CF_TA = 8, CF_TB = 16;                          // output block
 constexpr int CF_PA = 2 * CF_TA + 1, CF_PB = 2 * CF_TB + 1;   // input patch 17 x 33
-constexpr int CF_PP = CF_PB + 1;                              // patch row pitch (floats)
+constexpr int CF_PP = CF_PB + 1;                              // patch row pitch (pixels)
 
-// patch offset of im2col column k = (kh*3+kw)*CIN + ci, relative to the pixel's corner (2*oy)*CF_PP + 2*ox; -1 = padding
-template <int CIN> struct CfOff {
+// patch offset of im2col column k = (kh*3+kw)*CIN + ci relative to the output pixel's corner; -1 = padding column.
+// MODE 0 keeps the patch as [ci][row][col], MODE 1 as [row][col][ci] (the order the input arrives in).
+template <int CIN, int MODE> struct CfOff {
     int v[64];
     constexpr CfOff() : v{} {
         for (int k = 0; k < 64; ++k) {
             const int t = k / CIN, ci = k % CIN, kh = t / 3, kw = t % 3;
-            v[k] = k < 9 * CIN ? (ci * CF_PA + kh) * CF_PP + kw : -1;
+            v[k] = k >= 9 * CIN ? -1 : MODE == 0 ? (ci * CF_PA + kh) * CF_PP + kw : (kh * CF_PP + kw) * CIN + ci;
         }
     }
 };
@@ -64,8 +71,20 @@ __device__ __forceinline__ void cf_glds16(const void* g, void* lds) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
                                      (__attribute__((address_space(3))) void*)lds, 16, 0, 0);
 }
+template <int CTRL> __device__ __forceinline__ float cf_dpp(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, false));
+}
+// sum over the 16 lanes of a DPP row (lane & 15), every lane gets the total
+__device__ __forceinline__ float cf_row_sum(float v) {
+    v += cf_dpp<0x128>(v);     // row_ror:8
+    v += cf_dpp<0x124>(v);     // row_ror:4
+    v += cf_dpp<0x4E>(v);      // quad_perm [2,3,0,1]
+    v += cf_dpp<0xB1>(v);      // quad_perm [1,0,3,2]
+    return v;
+}
+__device__ __forceinline__ bool cf_bf16_pos(unsigned v16) { return (v16 - 1u) < 0x7f80u; }    // 0 < v <= +inf, NaN excluded
 
-template <int CIN> __global__ __launch_bounds__(512, 4) void conv_first_fused_k(const CfArgs p) {
+template <int CIN, int MODE> __global__ __launch_bounds__(512, 4) void conv_first_fused_k(const CfArgs p) {
     __shared__ __attribute__((aligned(16))) unsigned char s_a[128 * 128];        // im2col rows, swizzled chunks
     __shared__ __attribute__((aligned(16))) unsigned char s_b[256 * 128];        // weights in fragment-row order
     __shared__ float s_patch[4 * CF_PA * CF_PP];
@@ -94,21 +113,21 @@ template <int CIN> __global__ __launch_bounds__(512, 4) void conv_first_fused_k(
     const int fi = lane & 15, fg = lane >> 4;
     const int wq = w & 3, wm = w >> 2;
     const int col = 64 * wq + 16 * fg;
-    const bool second = col + 8 < p.Nout;
+    const bool first = col < p.Nout, second = col + 8 < p.Nout;
     f32x4_t bz4[4];
 #pragma unroll
     for (int h = 0; h < 4; ++h) {
         bz4[h] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-        if (p.bias && col + 4 * h < p.Nout) bz4[h] = *(const f32x4_t*)(p.bias + col + 4 * h);
+        if (MODE == 0 && p.bias && col + 4 * h < p.Nout) bz4[h] = *(const f32x4_t*)(p.bias + col + 4 * h);
     }
     DropKey dkey{0u, 0u};
     int koff[8];
-    // ---- input patch, coalesced along iw
-    const float* xf = p.x + cf_frame_off(p.fm, n);
-    // s_patch row c*17 + r, column 0 = the halo column 2*ow0 - 1, columns 1 .. 32 = the 128-byte run from 2*ow0: one
-    // instruction loads two rows (32 lanes each)
-    {
-        static constexpr CfOff<CIN> otab{};
+    static constexpr CfOff<CIN, MODE> otab{};
+    // ---- input patch
+    if constexpr (MODE == 0) {
+        // s_patch row c*17 + r, column 0 = the halo column 2*ow0 - 1, columns 1 .. 32 = the 128-byte run from 2*ow0: one
+        // instruction loads two rows (32 lanes each)
+        const float* xf = p.x + cf_frame_off(p.fm, n);
         constexpr int R = CIN * CF_PA, PAIRS = (R + 1) / 2, PIT = (PAIRS + 7) / 8;
         float pv[PIT], hv = 0.f;
 #pragma unroll
@@ -124,9 +143,8 @@ template <int CIN> __global__ __launch_bounds__(512, 4) void conv_first_fused_k(
             const int ih = ih0 + r;
             if (CF_DBG != 4 && ih >= 0 && ih < p.IH && iw0 >= 0) hv = xf[((size_t)c * p.IH + ih) * p.IW + iw0];
         }
-        const int cchunk = tid & 7;
 #pragma unroll
-        for (int k8 = 0; k8 < 8; ++k8) koff[k8] = otab.v[cchunk * 8 + k8];
+        for (int k8 = 0; k8 < 8; ++k8) koff[k8] = otab.v[(tid & 7) * 8 + k8];
         if (p.drop_mode == 1) dkey = drop_key(p.seed + (p.seed_dev ? p.seed_dev[0] * 0x9E3779B97F4A7C15ull : 0ull));
 #pragma unroll
         for (int it = 0; it < PIT; ++it) {
@@ -134,6 +152,28 @@ template <int CIN> __global__ __launch_bounds__(512, 4) void conv_first_fused_k(
             if (row < R) s_patch[row * CF_PP + 1 + (lane & 31)] = pv[it];
         }
         if (tid < R) s_patch[tid * CF_PP] = hv;
+    } else {
+        // [row][col][ci]: a patch row is one run of 33*CIN floats
+        const float* xf = p.x + (size_t)n * p.IH * p.IW * CIN;
+        constexpr int RUN = CF_PB * CIN, PN = CF_PA * RUN, PIT = (PN + 511) / 512;
+        float pv[PIT];
+#pragma unroll
+        for (int it = 0; it < PIT; ++it) {
+            const int i = it * 512 + tid;
+            const int r = i / RUN, j = i - r * RUN;
+            const int ih = ih0 + r, iw = iw0 + j / CIN;
+            pv[it] = 0.f;
+            if (CF_DBG != 4 && i < PN && ih >= 0 && ih < p.IH && iw >= 0 && iw < p.IW)
+                pv[it] = xf[((long)ih * p.IW + iw0) * CIN + j];
+        }
+#pragma unroll
+        for (int k8 = 0; k8 < 8; ++k8) koff[k8] = otab.v[(tid & 7) * 8 + k8];
+#pragma unroll
+        for (int it = 0; it < PIT; ++it) {
+            const int i = it * 512 + tid;
+            const int r = i / RUN, j = i - r * RUN;
+            if (i < PN) s_patch[r * (CF_PP * CIN) + j] = pv[it];
+        }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // weights (LDS-DMA), bias, key: everything this wave asked for
 #pragma unroll
@@ -141,13 +181,13 @@ template <int CIN> __global__ __launch_bounds__(512, 4) void conv_first_fused_k(
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     asm volatile("" : "+v"(dkey.k0), "+v"(dkey.k1));
     __syncthreads();
-    // ---- im2col rows: 128 rows x 8 chunks of 8 columns; column k = (kh*3+kw)*Cin + ci
+    // ---- im2col rows: 128 rows x 8 chunks of 8 columns (a thread keeps its chunk index over both rounds)
 #pragma unroll
     for (int i0 = 0; i0 < 128 * 8; i0 += 512) {
         const int i = i0 + tid;
         const int r = i >> 3, c = i & 7;
         const int oy = r >> 4, ox = r & 15;
-        const int corner = 2 * oy * CF_PP + 2 * ox;
+        const int corner = (2 * oy * CF_PP + 2 * ox) * (MODE == 0 ? 1 : CIN);
         unsigned short e[8];
 #pragma unroll
         for (int k8 = 0; k8 < 8; ++k8) {
@@ -188,28 +228,79 @@ template <int CIN> __global__ __launch_bounds__(512, 4) void conv_first_fused_k(
                                                                      acc[mt][h], 0, 0, 0);
     }
     // ---- epilogue from registers: lane = pixel fi of tile mt, channels 64*wq + 16*fg .. +15 (two 16-byte chunks)
-    if (col >= p.Nout) return;
+    if (MODE == 0 && !first) return;
     const float floor_ = p.relu ? 0.f : -3.0e38f;
+    float csum[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) csum[e] = 0.f;
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) {
         const int r = (4 * wm + mt) * 16 + fi;
         const int oh = oh0 + (r >> 4), ow = ow0 + (r & 15);
-        if (oh >= p.OH || ow >= p.OW) continue;
+        if (oh >= p.OH || ow >= p.OW || !first) continue;
         const size_t orow = (size_t)(n * p.OH + oh) * p.OW + ow;
+        u32x4_t g4[2];
+        if constexpr (MODE == 1) {
+            g4[0] = *(const u32x4_t*)(p.gate + (orow * p.ldo + col) * 2);
+            g4[1] = second ? *(const u32x4_t*)(p.gate + (orow * p.ldo + col + 8) * 2) : u32x4_t{0u, 0u, 0u, 0u};
+        }
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
             if (half == 1 && !second) break;
             float xv[8];
+            if constexpr (MODE == 0) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e)
-                xv[e] = fmaxf(acc[mt][2 * half + (e >> 2)][e & 3] + bz4[2 * half + (e >> 2)][e & 3], floor_) * p.scale;
-            if (p.drop_mode == 1)
-                drop_chunk_zero_f32<8>(drop_run(dkey, (unsigned long long)orow * p.Nout + col + 8 * half), p.drop_thresh >> 16, xv);
+                for (int e = 0; e < 8; ++e)
+                    xv[e] = fmaxf(acc[mt][2 * half + (e >> 2)][e & 3] + bz4[2 * half + (e >> 2)][e & 3], floor_) * p.scale;
+                if (p.drop_mode == 1)
+                    drop_chunk_zero_f32<8>(drop_run(dkey, (unsigned long long)orow * p.Nout + col + 8 * half), p.drop_thresh >> 16, xv);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const unsigned g16 = (e & 1) ? (g4[half][e >> 1] >> 16) : (g4[half][e >> 1] & 0xffffu);
+                    xv[e] = cf_bf16_pos(g16) ? acc[mt][2 * half + (e >> 2)][e & 3] * p.scale : 0.f;
+                }
+            }
             u32x4_t val;
 #pragma unroll
             for (int e = 0; e < 4; ++e) val[e] = (unsigned)f32_to_bf16(xv[2 * e]) | ((unsigned)f32_to_bf16(xv[2 * e + 1]) << 16);
             if (CF_DBG != 1 || val[0] == 0x12345678u) *(u32x4_t*)(p.out + (orow * p.ldo + col + 8 * half) * 2) = val;
+            if constexpr (MODE == 1) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    csum[8 * half + e] += __uint_as_float((e & 1) ? (val[e >> 1] & 0xffff0000u) : (val[e >> 1] << 16));
+            }
         }
+    }
+    if constexpr (MODE == 1) {
+        if (p.colsum_ws) {
+            // bias gradient of the layer below: column sums of this block's stored values, pixels then wave halves
+            float* red = s_patch;                              // [2][256]; the patch is dead since the second barrier
+#pragma unroll
+            for (int e = 0; e < 16; ++e) csum[e] = cf_row_sum(csum[e]);
+            if (fi == 0) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) red[wm * 256 + col + e] = csum[e];
+            }
+            __syncthreads();
+            if (tid < p.Nout) p.colsum_ws[(size_t)blockIdx.x * p.Nout + tid] = red[tid] + red[256 + tid];
+        }
+    }
+}
+
+static int cf_shape_ok(int dtype, int Cin, int IH, int IW, int Nout, int N) {
+    const int OH = (IH + 2 - 3) / 2 + 1, OW = (IW + 2 - 3) / 2 + 1;
+    return dtype == RBVAE_BF16 && Cin >= 1 && Cin <= 4 && Nout >= 8 && Nout <= 256 && Nout % 8 == 0 && N >= 1 && IH >= 1 &&
+           IW >= 1 && (long)N * OH * OW * 256 < (1l << 31) && (long)N * Cin * IH * IW < (1l << 40);
+}
+
+template <int MODE> static void cf_launch(const CfArgs& a, hipStream_t st) {
+    const int blocks = a.N * cdiv(a.OH, CF_TA) * cdiv(a.OW, CF_TB);
+    switch (a.Cin) {
+        case 1: hipLaunchKernelGGL((conv_first_fused_k<1, MODE>), dim3(blocks), dim3(512), 0, st, a); break;
+        case 2: hipLaunchKernelGGL((conv_first_fused_k<2, MODE>), dim3(blocks), dim3(512), 0, st, a); break;
+        case 3: hipLaunchKernelGGL((conv_first_fused_k<3, MODE>), dim3(blocks), dim3(512), 0, st, a); break;
+        default: hipLaunchKernelGGL((conv_first_fused_k<4, MODE>), dim3(blocks), dim3(512), 0, st, a); break;
     }
 }
 
@@ -219,9 +310,7 @@ using namespace rbvae;
 
 /* 1 when rbvae_conv_first_fused covers the shape (bf16, 3x3 stride 2 pad 1, Cin <= 4, Nout <= 256, Nout % 8 == 0) */
 extern "C" int rbvae_conv_first_fused_ok(int dtype, int Cin, int IH, int IW, int Nout, int N) {
-    const int OH = (IH + 2 - 3) / 2 + 1, OW = (IW + 2 - 3) / 2 + 1;
-    return dtype == RBVAE_BF16 && Cin >= 1 && Cin <= 4 && Nout >= 8 && Nout <= 256 && Nout % 8 == 0 &&
-           (long)N * OH * OW * 256 < (1l << 31) && (long)N * Cin * IH * IW < (1l << 40);
+    return cf_shape_ok(dtype, Cin, IH, IW, Nout, N);
 }
 
 extern "C" int rbvae_conv_first_fused(int dtype, const float* x, int fd1, int fd2, long fs0, long fs1, long fs2, const void* W,
@@ -229,25 +318,46 @@ extern "C" int rbvae_conv_first_fused(int dtype, const float* x, int fd1, int fd
                                       int IW, int Nout, int ldo, int relu, int drop_mode, float drop_p, float scale,
                                       unsigned long long seed, const unsigned long long* seed_dev, void* stream) {
     RBVAE_CHECK_ARG(x && W && zero_page && col && out, "conv_first_fused: null pointer");
-    RBVAE_CHECK_ARG(rbvae_conv_first_fused_ok(dtype, Cin, IH, IW, Nout, N), "conv_first_fused: shape outside the fused kernel "
+    RBVAE_CHECK_ARG(cf_shape_ok(dtype, Cin, IH, IW, Nout, N), "conv_first_fused: shape outside the fused kernel "
                     "(bf16, Cin <= 4, Nout <= 256): Cin=%d %dx%d Nout=%d", Cin, IH, IW, Nout);
     RBVAE_CHECK_ARG(ldo >= Nout && ldo % 8 == 0, "conv_first_fused: ldo=%d", ldo);
     RBVAE_CHECK_ARG(drop_mode == 0 || drop_mode == 1, "conv_first_fused: drop_mode %d (explicit masks: two-kernel path)", drop_mode);
-    RBVAE_CHECK_ARG(((uintptr_t)W | (uintptr_t)zero_page | (uintptr_t)col | (uintptr_t)out) % 16 == 0,
-                    "conv_first_fused: pointers must be 16-byte aligned");
+    RBVAE_CHECK_ARG(((uintptr_t)W | (uintptr_t)zero_page | (uintptr_t)col | (uintptr_t)out) % 16 == 0 &&
+                    (!bias || (uintptr_t)bias % 16 == 0), "conv_first_fused: pointers must be 16-byte aligned");
     CfArgs a;
     a.x = x; a.fm = CfFrameMap{fd1, fd2, fs0, fs1, fs2}; a.W = (const unsigned char*)W; a.bias = bias;
     a.zero = (const unsigned char*)zero_page; a.col = (unsigned char*)col; a.out = (unsigned char*)out;
+    a.gate = nullptr; a.colsum_ws = nullptr;
     a.N = N; a.Cin = Cin; a.IH = IH; a.IW = IW; a.OH = (IH + 2 - 3) / 2 + 1; a.OW = (IW + 2 - 3) / 2 + 1;
     a.Nout = Nout; a.ldo = ldo; a.relu = relu; a.drop_mode = drop_mode; a.scale = scale;
     a.drop_thresh = (unsigned)((double)drop_p * 4294967296.0); a.seed = seed; a.seed_dev = seed_dev;
-    const int blocks = N * cdiv(a.OH, CF_TA) * cdiv(a.OW, CF_TB);
-    switch (Cin) {
-        case 1: hipLaunchKernelGGL(conv_first_fused_k<1>, dim3(blocks), dim3(512), 0, (hipStream_t)stream, a); break;
-        case 2: hipLaunchKernelGGL(conv_first_fused_k<2>, dim3(blocks), dim3(512), 0, (hipStream_t)stream, a); break;
-        case 3: hipLaunchKernelGGL(conv_first_fused_k<3>, dim3(blocks), dim3(512), 0, (hipStream_t)stream, a); break;
-        default: hipLaunchKernelGGL(conv_first_fused_k<4>, dim3(blocks), dim3(512), 0, (hipStream_t)stream, a); break;
-    }
+    cf_launch<0>(a, (hipStream_t)stream);
     RBVAE_CHECK_LAUNCH("conv_first_fused");
+    return RBVAE_OK;
+}
+
+/* workgroups (= rows of colsum_ws) of rbvae_deconv_last_dgrad_fused; 0 when the shape is outside the fused kernel */
+extern "C" int rbvae_deconv_last_dgrad_blocks(int dtype, int Cout, int OH, int OW, int C1, int N) {
+    if (!cf_shape_ok(dtype, Cout, OH, OW, C1, N)) return 0;
+    return N * cdiv((OH + 2 - 3) / 2 + 1, CF_TA) * cdiv((OW + 2 - 3) / 2 + 1, CF_TB);
+}
+
+extern "C" int rbvae_deconv_last_dgrad_fused(int dtype, const float* dpre, const void* W, const void* zero_page, void* col,
+                                             const void* gate, void* out, int N, int Cout, int OH, int OW, int C1, int ldo,
+                                             float scale, float* colsum_ws, void* stream) {
+    RBVAE_CHECK_ARG(dpre && W && zero_page && col && gate && out, "deconv_last_dgrad_fused: null pointer");
+    RBVAE_CHECK_ARG(cf_shape_ok(dtype, Cout, OH, OW, C1, N), "deconv_last_dgrad_fused: shape outside the fused kernel "
+                    "(bf16, Cout <= 4, C1 <= 256): Cout=%d %dx%d C1=%d", Cout, OH, OW, C1);
+    RBVAE_CHECK_ARG(ldo >= C1 && ldo % 8 == 0, "deconv_last_dgrad_fused: ldo=%d", ldo);
+    RBVAE_CHECK_ARG(((uintptr_t)W | (uintptr_t)zero_page | (uintptr_t)col | (uintptr_t)out | (uintptr_t)gate) % 16 == 0,
+                    "deconv_last_dgrad_fused: pointers must be 16-byte aligned");
+    CfArgs a;
+    a.x = dpre; a.fm = CfFrameMap{0, 0, 0, 0, 0}; a.W = (const unsigned char*)W; a.bias = nullptr;
+    a.zero = (const unsigned char*)zero_page; a.col = (unsigned char*)col; a.out = (unsigned char*)out;
+    a.gate = (const unsigned char*)gate; a.colsum_ws = colsum_ws;
+    a.N = N; a.Cin = Cout; a.IH = OH; a.IW = OW; a.OH = (OH + 2 - 3) / 2 + 1; a.OW = (OW + 2 - 3) / 2 + 1;
+    a.Nout = C1; a.ldo = ldo; a.relu = 0; a.drop_mode = 0; a.scale = scale; a.drop_thresh = 0; a.seed = 0; a.seed_dev = nullptr;
+    cf_launch<1>(a, (hipStream_t)stream);
+    RBVAE_CHECK_LAUNCH("deconv_last_dgrad_fused");
     return RBVAE_OK;
 }

@@ -782,10 +782,19 @@ class Engine:
             if dpre3 is None:
                 raise RuntimeError("backward without g_xr needs forward(target=..., need_grad=True)")
         col3 = tmp("col3", P1, self.K3)
-        L.call("rbvae_im2col", self.dt, dpre3, H * W * oc, 1, W * oc, oc, N, oc, H, W, h1, w1, k, k, 2, 1, self.K3, col3)
         dd2 = tmp("dd2", P1, c1)
-        self._gemm(col3, self.V3f, dd2, None, sv.d2, None, P1, 1, 1, 1, 1, 1, 1, 1, 1, self.K3, c1, self.K3, c1, 1,
-                   "one", scale=gs, bias_grad=G(f"decoder_cnn.deconv.{i1}.bias"), tag=(N, "dd2"))
+        nb = (L.query("rbvae_deconv_last_dgrad_blocks", self.dt, oc, H, W, c1, N)
+              if self.conv_first_fused and k == 3 and self.K3 == 64 else 0)
+        if nb:
+            # im2col + GEMM + gate + bias-gradient partial sums in one kernel (csrc/conv_first.hip, MODE 1)
+            ws = self._buf((N, "colsum_dd2f"), nb * c1)
+            L.call("rbvae_deconv_last_dgrad_fused", self.dt, dpre3, self.V3f, self.zero, col3, sv.d2, dd2, N, oc, H, W, c1,
+                   c1, float(gs), ws)
+            self._jobs.add(JOB_ROWS, ws, G(f"decoder_cnn.deconv.{i1}.bias"), (1, 1, c1), (0, 0, 1), nslab=nb, slab=c1)
+        else:
+            L.call("rbvae_im2col", self.dt, dpre3, H * W * oc, 1, W * oc, oc, N, oc, H, W, h1, w1, k, k, 2, 1, self.K3, col3)
+            self._gemm(col3, self.V3f, dd2, None, sv.d2, None, P1, 1, 1, 1, 1, 1, 1, 1, 1, self.K3, c1, self.K3, c1, 1,
+                       "one", scale=gs, bias_grad=G(f"decoder_cnn.deconv.{i1}.bias"), tag=(N, "dd2"))
         # deconv1 (c2 -> c1): input grad = conv forward of dd2 with the same weights
         dd1 = tmp("dd1", P2, c2)
         self._gemm(dd2, self.V2f, dd1, None, sv.d1, None, N, h1, w1, h2, w2, 2, h2, w2, 1, c1, c2, c1, c2, kk, "conv",

@@ -557,3 +557,43 @@ def test_conv_first_fused(sfv, N, Cin, IH, IW, Nout, drop):
            (o2 := torch.empty(S * T * OH * OW, Nout, dtype=torch.bfloat16, device="cuda")), S * T, Cin, IH, IW, Nout, Nout, 1, 0,
            0.0, 1.0, 0, None)
     assert torch.equal(o1.view(torch.int16), o2.view(torch.int16))
+
+
+@pytest.mark.parametrize("N,Cout,OH,OW,C1", [(3, 4, 32, 32, 256), (2, 3, 21, 40, 64), (2, 4, 7, 70, 200)])
+def test_deconv_last_dgrad_fused(sfv, N, Cout, OH, OW, C1):
+    """rbvae_deconv_last_dgrad_fused (MODE 1 of csrc/conv_first.hip) stores exactly what rbvae_im2col + the gated
+    single-slice rbvae_gather_gemm store (col rows and outputs bit-identical); its per-workgroup column sums add up to
+    the column sums of the stored output; and it agrees with autograd of F.conv_transpose2d on bf16-rounded operands."""
+    L = sfv._lib
+    g = torch.Generator().manual_seed(90 + OH + C1)
+    IH, IW = (OH - 1) // 2 + 1, (OW - 1) // 2 + 1
+    P = N * IH * IW
+    dpre = (torch.randn(N, OH, OW, Cout, generator=g) * 0.1).cuda()
+    V = torch.randn(C1, Cout, 3, 3, generator=g) * 0.2                       # ConvTranspose2d weight [in=C1][out=Cout][kh][kw]
+    Wp = torch.zeros(C1, 64, dtype=torch.bfloat16)
+    Wp[:, :9 * Cout] = V.permute(0, 2, 3, 1).reshape(C1, 9 * Cout).bfloat16()
+    Wp = Wp.cuda()
+    gate = torch.relu(torch.randn(P, C1, generator=g)).bfloat16().cuda()      # ~half zeros
+    zero = torch.zeros(256, dtype=torch.uint8, device="cuda")
+    col_a = torch.empty(P, 64, dtype=torch.bfloat16, device="cuda")
+    out_a = torch.empty(P, C1, dtype=torch.bfloat16, device="cuda")
+    L.call("rbvae_im2col", 1, dpre, OH * OW * Cout, 1, OW * Cout, Cout, N, Cout, OH, OW, IH, IW, 3, 3, 2, 1, 64, col_a)
+    gemm(sfv, 1, col_a, Wp, out_a, None, gate, None, (P, 1, 1, 1, 1, 1, 1, 1, 1), 64, C1, 1, [1, 0, 0, 0, 0, 0], 1, scale=1.25)
+    nb = L.query("rbvae_deconv_last_dgrad_blocks", 1, Cout, OH, OW, C1, N)
+    assert nb == N * -(-IH // 8) * -(-IW // 16)
+    assert L.query("rbvae_deconv_last_dgrad_blocks", 0, Cout, OH, OW, C1, N) == 0
+    col_b = torch.empty_like(col_a)
+    out_b = torch.empty_like(out_a)
+    ws = torch.full((nb, C1), float("nan"), device="cuda")
+    L.call("rbvae_deconv_last_dgrad_fused", 1, dpre, Wp, zero, col_b, gate, out_b, N, Cout, OH, OW, C1, C1, 1.25, ws)
+    assert torch.equal(col_a.view(torch.int16), col_b.view(torch.int16))
+    assert torch.equal(out_a.view(torch.int16), out_b.view(torch.int16))
+    np.testing.assert_allclose(ws.sum(0).cpu().numpy(), out_b.float().sum(0).cpu().numpy(), rtol=2e-4, atol=2e-3)
+    # autograd: d/d(input) of conv_transpose2d(input, V) contracted with dpre = conv2d(dpre, V as [C1][Cout][3][3], s2 p1)
+    ref = F.conv2d(dpre.cpu().permute(0, 3, 1, 2).bfloat16().float(), V.bfloat16().float(), stride=2, padding=1) * 1.25
+    ref = ref.permute(0, 2, 3, 1).reshape(P, C1) * (gate.float().cpu() > 0)
+    np.testing.assert_allclose(out_b.float().cpu().numpy(), ref.numpy(), rtol=1e-2, atol=2e-3)
+    # without the column sums
+    out_c = torch.empty_like(out_a)
+    L.call("rbvae_deconv_last_dgrad_fused", 1, dpre, Wp, zero, col_b, gate, out_c, N, Cout, OH, OW, C1, C1, 1.25, None)
+    assert torch.equal(out_c.view(torch.int16), out_b.view(torch.int16))
