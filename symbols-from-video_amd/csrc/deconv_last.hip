@@ -19,11 +19,11 @@ typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
 
 struct DlFrameMap { int d1, d2; long s0, s1, s2; };
-__device__ __forceinline__ long dl_frame_off(const DlFrameMap& f, long n) {
-    if (f.d1 == 0) return n * f.s2;
-    const long a = n / f.d1, r = n - a * f.d1;
-    const long b = r / f.d2, c = r - b * f.d2;
-    return a * f.s0 + b * f.s1 + c * f.s2;
+__device__ __forceinline__ long dl_frame_off(const DlFrameMap& f, unsigned n) {
+    if (f.d1 == 0) return (long)n * f.s2;
+    const unsigned a = n / (unsigned)f.d1, r = n - a * (unsigned)f.d1;
+    const unsigned b = r / (unsigned)f.d2, c = r - b * (unsigned)f.d2;
+    return (long)a * f.s0 + (long)b * f.s1 + (long)c * f.s2;
 }
 
 struct DlArgs {
@@ -69,11 +69,28 @@ __global__ __launch_bounds__(256, (DL_SL == 1 ? 3 : 2)) void deconv_last_fused_k
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int OH = 2 * p.IH, OW = 2 * p.IW;
     const int tb_n = (p.IW + DL_TB - 1) / DL_TB, ta_n = (p.IH + DL_TA - 1) / DL_TA;
-    int blk = blockIdx.x;
-    const int tbi = blk % tb_n; blk /= tb_n;
-    const int tai = blk % ta_n;
-    const int n = blk / ta_n;
+    unsigned blk = blockIdx.x;
+    const int tbi = blk % (unsigned)tb_n; blk /= (unsigned)tb_n;
+    const int tai = blk % (unsigned)ta_n;
+    const int n = blk / (unsigned)ta_n;
     const int a0 = tai * DL_TA, b0 = tbi * DL_TB;
+
+    // the epilogue's operands that depend on nothing (targets, bias) are asked for first: their latency hides behind the
+    // staging and the MFMAs instead of sitting, one channel after the other, in front of the stores
+    constexpr int EPI = (2 * DL_TA * 2 * DL_TB) / 256;                // output pixels per thread
+    const int OHW = OH * OW;
+    float tg[EPI][4], bz[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) bz[c] = (p.bias && c < p.Cout) ? p.bias[c] : 0.f;
+#pragma unroll
+    for (int it = 0; it < EPI; ++it) {
+        const int q = tid + 256 * it;
+        const int oh = 2 * a0 + q / (2 * DL_TB), ow = 2 * b0 + q % (2 * DL_TB);
+        const bool ok = p.target && oh < OH && ow < OW;
+        const float* tp = p.target + (ok ? dl_frame_off(p.tfm, n) + (long)oh * OW + ow : 0);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) tg[it][c] = (ok && c < p.Cout) ? tp[(long)c * OHW] : 0.f;
+    }
 
     const int srow = lane >> 3, schunk = lane & 7;
     const int fi = lane & 15, fg = lane >> 4;
@@ -132,6 +149,14 @@ __global__ __launch_bounds__(256, (DL_SL == 1 ? 3 : 2)) void deconv_last_fused_k
             }
         }
     }
+    // the prefetched epilogue operands landed long ago; saying so here keeps the compiler from waiting for them (and with
+    // them for the x_recon stores) in the middle of the epilogue
+#pragma unroll
+    for (int it = 0; it < EPI; ++it)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) asm volatile("" : "+v"(tg[it][c]));
+#pragma unroll
+    for (int c = 0; c < 4; ++c) asm volatile("" : "+v"(bz[c]));
     // D[(tap,co) row 4g + r][pixel i]
 #pragma unroll
     for (int pi = 0; pi < 3; ++pi) {
@@ -153,13 +178,15 @@ __global__ __launch_bounds__(256, (DL_SL == 1 ? 3 : 2)) void deconv_last_fused_k
     const int Cout = p.Cout;
     const long plane = (long)OH * OW;
     float sse = 0.f, dsum[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int q = tid; q < 2 * DL_TA * 2 * DL_TB; q += 256) {
+#pragma unroll
+    for (int it = 0; it < EPI; ++it) {
+        const int q = tid + 256 * it;
         const int oy = q / (2 * DL_TB), ox = q - oy * (2 * DL_TB);
         const int oh = 2 * a0 + oy, ow = 2 * b0 + ox;
         if (oh >= OH || ow >= OW) continue;
         float v[4];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) v[c] = (p.bias && c < Cout) ? p.bias[c] : 0.f;
+        for (int c = 0; c < 4; ++c) v[c] = bz[c];
         for (int kh = (oh + 1) & 1; kh < 3; kh += 2) {
             const int a = (oh + 1 - kh) >> 1;
             if (a < 0 || a >= p.IH) continue;
@@ -173,20 +200,22 @@ __global__ __launch_bounds__(256, (DL_SL == 1 ? 3 : 2)) void deconv_last_fused_k
             }
         }
         const size_t xo = (size_t)n * Cout * plane + (size_t)oh * OW + ow;
-        const float* tp = p.target ? p.target + dl_frame_off(p.tfm, n) + (size_t)oh * OW + ow : nullptr;
-        float d4[4] = {0.f, 0.f, 0.f, 0.f};
+        float d4[4] = {0.f, 0.f, 0.f, 0.f}, sg[4];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            if (c >= Cout) break;
-            const float sg = sigmoidf_(v[c]);
-            p.xr[xo + (size_t)c * plane] = sg;
-            if (tp) {
-                const float d = sg - tp[(size_t)c * plane];
+        for (int c = 0; c < 4; ++c) sg[c] = sigmoidf_(v[c]);
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            if (c < Cout) p.xr[xo + (size_t)c * plane] = sg[c];
+        if (p.target) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                if (c >= Cout) break;
+                const float d = sg[c] - tg[it][c];
                 sse += d * d;
-                d4[c] = p.gscale * d * sg * (1.f - sg);
+                d4[c] = p.gscale * d * sg[c] * (1.f - sg[c]);
             }
         }
-        if (tp && p.dpre) {
+        if (p.target && p.dpre) {
             float* dp = p.dpre + ((size_t)(n * OH + oh) * OW + ow) * Cout;
             if (Cout == 4) *(float4*)dp = make_float4(d4[0], d4[1], d4[2], d4[3]);
             else
