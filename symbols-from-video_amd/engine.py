@@ -736,7 +736,7 @@ class Engine:
     # ---- backward --------------------------------------------------------------
     def backward(self, flat: torch.Tensor, gflat: torch.Tensor, sv: Saved, g_xr: Optional[torch.Tensor],
                  g_hs: Optional[torch.Tensor], g_z: Optional[torch.Tensor], g_e: Optional[torch.Tensor] = None,
-                 kl_weight: float = 0.0, kl_p: float = 0.5, g_hs_inplace: bool = False, side_first=None):
+                 kl_weight: float = 0.0, kl_p: float = 0.5, g_hs_inplace: bool = False, side_first=None, cut=None):
         """Writes every parameter gradient into gflat (same layout as flat).
         g_xr: [S,T,C,H,W] upstream gradient of x_recon (None: use the fused dpre3 of forward()).
         g_hs / g_z: [S,T,L] upstream gradients of h_seq / z_seq (None = 0).
@@ -744,7 +744,11 @@ class Engine:
         kl_weight: d(loss)/d(kl_mean) when the KL term was fused into forward().
         g_hs_inplace: the caller gives g_hs away (the binarise backward accumulates into it).
         side_first: optional callable issued on the side stream before anything else of this pass (the trainer's
-        loss bookkeeping: everything it reads exists once forward() is done)."""
+        loss bookkeeping: everything it reads exists once forward() is done).
+        cut: optional callable invoked once, on the main stream with every side stream joined, at the point where the
+        gradients of decoder_cnn.* and both LSTM stacks (the contiguous tail of gflat from
+        layout.offsets["decoder_cnn.fc.weight"]) are final and only the encoder CNN's remain to be computed: the
+        data-parallel trainer ends one graph and starts the next there and all-reduces that tail beside the rest."""
         self._join()                       # side-stream work of forward() (after_hs)
         book_with_decoder = (side_first is not None and self.book_with_dec and self._side_on(self.SIDE_DEC_WGRAD)
                              and not self._side_on(self.SIDE_BOOK))
@@ -832,10 +836,15 @@ class Engine:
         self._conv_idx(N, h1, w1, h2, w2)
         self._conv_idx(N, h2, w2, h3, w3)
         self._fork(0, self.SIDE_DEC_WGRAD)
+        # with a cut the reductions queued so far (decoder bias sums: their producers ran before the fork) go with the
+        # decoder's early reduction, so that every decoder gradient is final at the cut
+        fork_jobs = None
+        if cut is not None:
+            fork_jobs, self._jobs = self._jobs, JobList()
 
         def issue_decoder_side():
-            early = self._side_on(self.SIDE_DEC_WGRAD) and self._side_on(self.SIDE_DEC_REDUCE)
-            main_jobs, self._jobs = self._jobs, JobList()
+            early = (self._side_on(self.SIDE_DEC_WGRAD) and self._side_on(self.SIDE_DEC_REDUCE)) or cut is not None
+            main_jobs, self._jobs = self._jobs, (fork_jobs if cut is not None else JobList())
             with self._on_side(0, self.SIDE_DEC_WGRAD):
                 if book_with_decoder:
                     side_first()        # the loss bookkeeping rides the side stream's existing fork: no edge of its own
@@ -939,6 +948,15 @@ class Engine:
         da2 = tmp("da2", P2, c2)
         self._gemm(da3, self.W3d, da2, None, sv.a2, None, N, h3, w3, h3, w3, 1, h2, w2, 2, c3, c2, c3, c2, kk, "dgrad",
                    scale=gs, bias_grad=G(f"encoder_cnn.conv.{i1}.bias"), tag=(N, "da2"))
+        if cut is not None:
+            # here, not right behind the LSTM kernels: the decoder's weight gradients on the side stream take about as
+            # long as the main chain needs to get this far, so the join costs no idle time (at the LSTM kernels it cost
+            # 76 us per step, one-rank RCCL rehearsal)
+            if defer_side:
+                issue_decoder_side()
+                defer_side = False
+            self._join()
+            cut()
         # --- conv2
         self._wgrad(da2, sv.a1, self._conv_idx(N, h1, w1, h2, w2), P2, c2, c1, c2, c1, kk,
                     G(f"encoder_cnn.conv.{i1}.weight"), (c2, c1, kk), (kk * c1, 1, c1), tag=(N, "W2"))

@@ -55,10 +55,15 @@ class FusedTrainer:
         self.instrument = None       # optional callable(name, flops) -> context manager (bench roofline leg)
         import os
         self.one_graph = os.environ.get("RBVAE_ONE_GRAPH", "1") == "1"
+        # world > 1: the backward pass is cut where the decoder CNN's and the LSTM stacks' gradients are final (the
+        # contiguous tail of the flat buffer, 51 % of it at the headline config); that tail is all-reduced on the
+        # collective's own stream beside the encoder CNN's backward graph, the head after it.  RBVAE_DDP_OVERLAP=0:
+        # one all-reduce of the whole buffer between the backward graph and the Adam graph.
+        self.ddp_overlap = os.environ.get("RBVAE_DDP_OVERLAP", "1") == "1"
         self.fused_pair = os.environ.get("RBVAE_FUSED_PAIR", "1") == "1"
 
     # ---- the two halves of a step (plain launches; captured below) ------------------
-    def _fwd_bwd(self, x, U, tau, B, T):
+    def _fwd_bwd(self, x, U, tau, B, T, cut=None):
         eng, model = self.eng, self.model
         numel = x.numel()
         Ld = model.latent_dim
@@ -104,7 +109,7 @@ class FusedTrainer:
                    float(b2), self.hyper)
 
         eng.backward(model._flat, self.gflat, out["saved"], None, g_hs, None, kl_weight=self.beta_kl, kl_p=self.p,
-                     g_hs_inplace=True, side_first=bookkeeping)
+                     g_hs_inplace=True, side_first=bookkeeping, cut=cut)
 
     def _update(self):
         b1, b2 = self.betas
@@ -151,7 +156,15 @@ class FusedTrainer:
                 g = self._capture(st["x"], Uarg, float(temperature), B, T)
                 self._graphs[key] = g
             g[0].replay()
-            if g[1] is not None:
+            if len(g) == 3:
+                # tail (decoder CNN + LSTM gradients) on the collective's stream beside the encoder CNN's backward graph
+                tail, head = self._grad_buckets()
+                w = torch.distributed.all_reduce(tail, group=self.pg, async_op=True)
+                g[1].replay()
+                torch.distributed.all_reduce(head, group=self.pg)
+                w.wait()
+                g[2].replay()
+            elif g[1] is not None:
                 self._allreduce()
                 g[1].replay()
         self.steps += 1
@@ -173,6 +186,12 @@ class FusedTrainer:
         if self.world > 1:
             torch.distributed.all_reduce(self.gflat, group=self.pg)
 
+    def _grad_buckets(self):
+        """(tail, head) views of the flat gradient: tail = decoder_cnn.* and both LSTM stacks (final at the backward
+        pass's cut), head = encoder_cnn.* (final at its end)."""
+        o = self.eng.layout.offsets["decoder_cnn.fc.weight"]
+        return self.gflat[o:], self.gflat[:o]
+
     def _capture(self, x, U, tau, B, T):
         # two eager warm-up steps on a side stream (allocator + lazy kernel attributes), then capture.
         # The warm-ups are real optimiser steps; their effect on the counters is rolled back.
@@ -181,7 +200,7 @@ class FusedTrainer:
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
             for _ in range(2):
-                self._fwd_bwd(x, U, tau, B, T)
+                self._fwd_bwd(x, U, tau, B, T, cut=(lambda: None) if (self.world > 1 and self.ddp_overlap) else None)
                 self._update()
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
@@ -191,6 +210,31 @@ class FusedTrainer:
             with torch.cuda.graph(g1):
                 self._fwd_bwd(x, U, tau, B, T)
                 self._update()
+        elif self.world > 1 and self.ddp_overlap:
+            # three graphs: forward + backward up to the cut | the encoder CNN's backward | Adam
+            g2, g3 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+            cs = torch.cuda.Stream()
+            cs.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(cs):
+                g1.capture_begin()
+
+                def cut():
+                    g1.capture_end()
+                    g2.capture_begin(pool=g1.pool())
+
+                self._fwd_bwd(x, U, tau, B, T, cut=cut)
+                g2.capture_end()
+                g3.capture_begin(pool=g1.pool())
+                self._update()
+                g3.capture_end()
+            torch.cuda.current_stream().wait_stream(cs)
+            self.model._flat.copy_(flat0)
+            self.m.copy_(m0)
+            self.vv.copy_(v0)
+            self.step_dev.copy_(s0)
+            self.eng.pack(self.model._flat)
+            torch.cuda.synchronize()
+            return g1, g2, g3
         else:
             g2 = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g1):

@@ -1,0 +1,97 @@
+"""The data-parallel fused trainer on the GPU: two ranks share the one device over gloo (RCCL refuses duplicate
+devices; the collective calls, streams and graphs are the product path's).  The overlapped schedule (backward cut
+where the decoder / LSTM gradients are final, tail all-reduced beside the encoder CNN's backward graph) must give
+bit-identical parameters to the one-all-reduce schedule, and both must track a single process stepping on the
+global batch."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _run(rank, world, port, overlap, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK="0", RBVAE_DDP_OVERLAP=str(overlap))
+    from importlib import import_module
+    import sfv_amd as sfv
+    ddp = import_module("symbols-from-video_amd.ddp")
+    trainer_mod = import_module("symbols-from-video_amd.trainer")
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    if world > 1:
+        ddp.init_from_env("gloo")
+    torch.manual_seed(11)                                        # same initial weights on every rank
+    Ld = 32
+    model = sfv.Seq2SeqBinaryVAE(4, 4, Ld, Ld, variant="percep", input_hw=(16, 16), compute_dtype="bf16").to(dev).train()
+    g = torch.Generator().manual_seed(5)
+    Bg, T = 4, 4
+    items = [torch.rand(Bg, 2, T, 4, 16, 16, generator=g) for _ in range(3)]
+    Us = [torch.rand(2, Bg, T, Ld, generator=g) for _ in range(3)]
+    # dropout off (eval-mode masks are rank-local draws otherwise); host-supplied noise so that shards see the global draw
+    model.eval()
+    tr = trainer_mod.FusedTrainer(model, lr=1e-3, alpha=1.0, beta_kl=1.0, bernoulli_p=0.1, noise_ratio=0.1,
+                                  device_noise=False, use_graph=True,
+                                  process_group=torch.distributed.group.WORLD if world > 1 else None)
+    mine = ddp.shard_items(Bg, rank, world) if world > 1 else slice(0, Bg)
+    for it, U in zip(items, Us):
+        Ui = U[:, mine].reshape(2, -1, Ld).contiguous().to(dev)
+        tr.step(it[mine].contiguous().to(dev), 0.7, U=Ui)
+    torch.cuda.synchronize()
+    if rank == 0:
+        q.put((len(next(iter(tr._graphs.values()))), model._flat.detach().cpu().numpy().copy()))   # by value
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+def _launch(world, overlap):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_run, args=(r, world, port, overlap, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    import queue
+    import time
+    out, t0 = None, time.time()
+    while out is None:
+        try:
+            out = q.get(timeout=2)
+        except queue.Empty:
+            if any(p.exitcode not in (None, 0) for p in procs) or time.time() - t0 > 240:
+                for p in procs:
+                    if p.is_alive():
+                        p.terminate()
+                raise AssertionError("a rank died or timed out")
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    return out[0], torch.from_numpy(out[1])
+
+
+@pytest.mark.timeout(600)
+def test_ddp_overlap_matches_single_allreduce():
+    n_graphs_a, flat_a = _launch(2, 1)
+    n_graphs_b, flat_b = _launch(2, 0)
+    assert n_graphs_a == 3 and n_graphs_b == 2
+    assert torch.equal(flat_a, flat_b)
+    # sanity against one process on the global batch (per-rank losses are shard means, their average is the global mean);
+    # Adam turns bf16 accumulation-order noise on near-zero gradients into +-lr steps, hence the loose bound -- the
+    # reduction semantics themselves are pinned by tests/test_ddp_cpu.py
+    _, flat_1 = _launch(1, 0)
+    assert torch.isfinite(flat_a).all()
+    rel = float((flat_a - flat_1).norm() / flat_1.norm())
+    assert rel < 2e-2, rel

@@ -13,19 +13,26 @@ FusedTrainer = import_module("symbols-from-video_amd.trainer").FusedTrainer
 
 torch.cuda.set_device(0)
 dist.init_process_group("nccl", rank=0, world_size=1)
-torch.manual_seed(1)
-m = sfv.Seq2SeqBinaryVAE(4, 4, 32, 32, variant="percep", input_hw=(32, 32), compute_dtype="bf16").cuda().train()
-tr = FusedTrainer(m, alpha=1.0, beta_kl=1.0, bernoulli_p=0.1)
-tr.world = 2                       # take the two-graph path with the all_reduce between the replays
-tr.one_graph = False
 item = torch.randn(16, 2, 8, 4, 32, 32, device="cuda")
-for _ in range(5):
-    tr.step(item, 0.7)
-torch.cuda.synchronize()
-t0 = time.perf_counter()
-for _ in range(100):
-    tr.step(item, 0.7)
-torch.cuda.synchronize()
-dt = (time.perf_counter() - t0) / 100
-print(f"two graphs + RCCL all_reduce (1 rank): {dt * 1e3:.3f} ms/step, losses {[round(v, 4) for v in tr.losses.tolist()]}")
+flats = {}
+for overlap in (0, 1):
+    torch.manual_seed(1)
+    m = sfv.Seq2SeqBinaryVAE(4, 4, 32, 32, variant="percep", input_hw=(32, 32), compute_dtype="bf16").cuda().train()
+    tr = FusedTrainer(m, alpha=1.0, beta_kl=1.0, bernoulli_p=0.1)
+    tr.world = 2                       # take the multi-rank path (1/world in Adam: both runs alike)
+    tr.one_graph = False
+    tr.ddp_overlap = bool(overlap)     # 0: two graphs, one all_reduce; 1: three graphs, tail all_reduce beside the second
+    for _ in range(5):
+        tr.step(item, 0.7)
+    torch.cuda.synchronize()
+    flats[overlap] = m._flat.detach().clone()
+    t0 = time.perf_counter()
+    for _ in range(200):
+        tr.step(item, 0.7)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / 200
+    ng = len(next(iter(tr._graphs.values())))
+    print(f"{ng} graphs + RCCL all_reduce (1 rank), overlap={overlap}: {dt * 1e3:.3f} ms/step, "
+          f"losses {[round(v, 4) for v in tr.losses.tolist()]}", flush=True)
+print("parameters after 5 steps identical:", torch.equal(flats[0], flats[1]))
 dist.destroy_process_group()
