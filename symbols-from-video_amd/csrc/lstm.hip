@@ -398,30 +398,7 @@ __global__ __launch_bounds__(1024) void lstm_pair_fwd_k(const PairArgs p) {
     float* acts = stack ? p.acts_d : p.acts_e;
     float* cs = stack ? p.cs_d : p.cs_e;
     float* hb = hbuf + stack * (layers + 1) * T * L;     // this stack's slots
-    // ---- encoder input (plain or K-split slabs) and the noise term, staged by all threads
-    for (int i = threadIdx.x; i < T * L; i += blockDim.x) {
-        const long o = ((long)s * T) * L + i;
-        float v;
-        if (p.in_parts) {
-            v = p.in_parts[o];
-            for (int k = 1; k < p.nparts; ++k) v += p.in_parts[k * p.part_stride + o];
-            p.hs_e[o] = v;
-        } else {
-            v = p.hs_e[o];
-        }
-        hbuf[i] = v;
-        unsigned long long seed = p.seed;
-        if (p.seed_dev) seed += p.seed_dev[0] * 0x9E3779B97F4A7C15ull;
-        const float u = p.U ? p.U[o] : (float)(hash_u32(seed, (unsigned long long)o) >> 8) * (1.0f / 16777216.0f);
-        nbuf[i] = p.ratio * (logf(u + p.neps) - logf(1.0f - u + p.neps));
-    }
-    if (p.cast_out) {
-        const int pw = p.cast_ld - L;
-        for (int i = threadIdx.x; i < T * pw; i += blockDim.x) {
-            const long o = ((long)s * T + i / pw) * p.cast_ld + L + i % pw;
-            if (p.cast_bf16) ((bf16_t*)p.cast_out)[o] = 0; else ((float*)p.cast_out)[o] = 0.f;
-        }
-    }
+    // this thread's weight rows first: their loads are in flight while the input is staged
     const float* wblk = stack ? p.wblk_d : p.wblk_e;
     const float* wT = stack ? p.wT_d : p.wT_e;
     const float* wl = wblk + l * lstm_layer_floats(L);
@@ -439,6 +416,41 @@ __global__ __launch_bounds__(1024) void lstm_pair_fwd_k(const PairArgs p) {
             const float a = pi[kk], b = ph[kk];
             wih[k] = k < L ? a : 0.f;
             whh[k] = k < L ? b : 0.f;
+        }
+    }
+    // ---- encoder input (plain or K-split slabs) and the noise term, staged by all threads.  The slab loads of an
+    // element are issued together (summed in slab order all the same) and the step counter is read once: as a loop of
+    // dependent loads this prologue cost five memory round trips before the first time step.
+    for (int i = threadIdx.x; i < T * L; i += blockDim.x) {
+        const long o = ((long)s * T) * L + i;
+        // unconditional loads on always-valid addresses (absent operands alias the input element / a weight): nothing
+        // here branches, so all of them are in flight before the first is used
+        const bool parts = p.in_parts != nullptr;
+        const float* ip = parts ? p.in_parts + o : p.hs_e + o;
+        const long st = parts ? p.part_stride : 0;
+        const int np = parts ? p.nparts : 1;
+        const float a0 = ip[0];
+        const float a1 = ip[(np > 1 ? 1 : 0) * st];
+        const float a2 = ip[(np > 2 ? 2 : 0) * st];
+        const float a3 = ip[(np > 3 ? 3 : 0) * st];
+        const float uin = *(p.U ? p.U + o : ip);
+        const unsigned long long sdev = *(p.seed_dev ? p.seed_dev : (const unsigned long long*)p.wblk_e);
+        float v = a0;
+        v += np > 1 ? a1 : 0.f;
+        v += np > 2 ? a2 : 0.f;
+        v += np > 3 ? a3 : 0.f;
+        for (int k = 4; k < np; ++k) v += ip[k * st];
+        if (parts) p.hs_e[o] = v;
+        hbuf[i] = v;
+        const unsigned long long seed = p.seed + (p.seed_dev ? sdev * 0x9E3779B97F4A7C15ull : 0ull);
+        const float u = p.U ? uin : (float)(hash_u32(seed, (unsigned long long)o) >> 8) * (1.0f / 16777216.0f);
+        nbuf[i] = p.ratio * (logf(u + p.neps) - logf(1.0f - u + p.neps));
+    }
+    if (p.cast_out) {
+        const int pw = p.cast_ld - L;
+        for (int i = threadIdx.x; i < T * pw; i += blockDim.x) {
+            const long o = ((long)s * T + i / pw) * p.cast_ld + L + i % pw;
+            if (p.cast_bf16) ((bf16_t*)p.cast_out)[o] = 0; else ((float*)p.cast_out)[o] = 0.f;
         }
     }
     float c = 0.f;
@@ -538,46 +550,62 @@ __global__ __launch_bounds__(1024) void lstm_bwd_wave_k(const float* __restrict_
     const bool row = j < 4 * L;
     const int kcol = j % L, prt = j / L;
     {
-        // Stage g_top, the saved gates and cell states of this sequence: gtop | sacts | scs are consecutive in LDS,
-        // so one flat index covers all three.  Every load of a batch is issued before the first LDS store (a plain
-        // "dst[i] = src[i]" loop per tensor waited for each load in turn: 13 memory round trips in this prologue).
+        // Stage g_top, the saved gates and cell states of this sequence: gtop | sacts | scs are consecutive in LDS, so
+        // one flat index covers all three.  Every load is issued before the first value is used or stored: the saved
+        // tensors by unconditional loads on clamped indices (a branch per element made the compiler wait for each load
+        // in turn -- 12 memory round trips in front of the first time step), then the operands of g_top (plain, K-split
+        // slabs, or the fused binarise backward), then the arithmetic, then the LDS stores.
         constexpr int U = 12;
         const int n0 = T * L, na = T * 4 * L, n1 = n0 + layers * na, ntot = n1 + layers * n0;
-        for (int base = threadIdx.x; base < ntot; base += U * blockDim.x) {
-            float v[U];
+        const int nth = blockDim.x;
+        float v[U];
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
-                int i = base + u * blockDim.x;
-                i = i < ntot ? i : ntot - 1;
-                const float* src;
-                if (i < n0 && bb.on) {
-                    const long e = ((long)s * T) * L + i;
-                    float g = bb.gz[e];
-                    if (bb.klw != 0.f) g += bb.klw * kl_elem_grad(bb.z[e], bb.lp, bb.l1p, bb.keps, bb.clamp);
-                    const float yv = bb.y[e];
-                    float gt = g * yv * (1.0f - yv) / bb.tau;
-                    if (bb.g_hs) gt = bb.g_hs[e] + gt;
-                    v[u] = gt;
-                    continue;
+        for (int u = 0; u < U; ++u) {
+            int i = n0 + (int)threadIdx.x + u * nth;
+            i = i < ntot ? i : ntot - 1;
+            const bool in_acts = i < n1;
+            const int rel = in_acts ? i - n0 : i - n1;
+            const int per = in_acts ? na : n0;
+            const int ll = rel / per, r = rel - ll * per;
+            const float* src = (in_acts ? acts : cs) + (((long)ll * S + s) * T) * (in_acts ? 4 * L : L) + r;
+            v[u] = *src;
+        }
+        // g_top: one element per thread and round (T * L <= the block size in every shipped configuration)
+        for (int i0 = 0; i0 < n0; i0 += nth) {
+            const int i = i0 + (int)threadIdx.x;
+            const long e = ((long)s * T) * L + (i < n0 ? i : n0 - 1);
+            float gt;
+            if (bb.on) {
+                const float g = bb.gz[e], zv = bb.z[e], yv = bb.y[e];
+                const float hsv = bb.g_hs ? bb.g_hs[e] : 0.f;
+                float gg = g;
+                if (bb.klw != 0.f) gg += bb.klw * kl_elem_grad(zv, bb.lp, bb.l1p, bb.keps, bb.clamp);
+                gt = hsv + gg * yv * (1.0f - yv) / bb.tau;
+            } else {
+                // plain, or K-split slabs (rbvae_skinny_linear_parts) summed in slab order, four loads in flight
+                const float* gp = g_top + e;
+                gt = gp[0];
+                int q = 1;
+                for (; q + 3 <= nparts; q += 3) {
+                    const float a = gp[q * part_stride], b = gp[(q + 1) * part_stride], c = gp[(q + 2) * part_stride];
+                    gt = ((gt + a) + b) + c;
                 }
-                if (i < n0 && nparts > 1) {
-                    // g_top as K-split slabs (rbvae_skinny_linear_parts): summed in slab order
-                    const float* gp = g_top + ((long)s * T) * L + i;
-                    float a = gp[0];
-                    for (int q = 1; q < nparts; ++q) a += gp[q * part_stride];
-                    v[u] = a;
-                    continue;
-                }
-                if (i < n0) src = g_top + ((long)s * T) * L + i;
-                else if (i < n1) { const int ll = (i - n0) / na, r = (i - n0) - ll * na; src = acts + (((long)ll * S + s) * T) * 4 * L + r; }
-                else { const int ll = (i - n1) / n0, r = (i - n1) - ll * n0; src = cs + (((long)ll * S + s) * T) * L + r; }
-                v[u] = *src;
+                for (; q < nparts; ++q) gt += gp[q * part_stride];
             }
+            if (i < n0) sm[i] = gt;
+        }
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int i = base + u * blockDim.x;
-                if (i < ntot) sm[i] = v[u];
-            }
+        for (int u = 0; u < U; ++u) {
+            const int i = n0 + (int)threadIdx.x + u * nth;
+            if (i < ntot) sm[i] = v[u];
+        }
+        // (more than U rounds of the saved tensors: long sequences)
+        for (int base = n0 + (int)threadIdx.x + U * nth; base < ntot; base += nth) {
+            const bool in_acts = base < n1;
+            const int rel = in_acts ? base - n0 : base - n1;
+            const int per = in_acts ? na : n0;
+            const int ll = rel / per, r = rel - ll * per;
+            sm[base] = ((in_acts ? acts : cs) + (((long)ll * S + s) * T) * (in_acts ? 4 * L : L))[r];
         }
     }
     if (cast_out) {
