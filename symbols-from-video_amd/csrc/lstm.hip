@@ -810,14 +810,26 @@ __global__ __launch_bounds__(256) void lstm_wgrad_mfma_k(const float* __restrict
     constexpr int UB = 16;
     for (int r0 = rbeg; r0 < rend; r0 += 4 * UB) {
         float a[UB], b[UB];
+        // All 2 * UB loads are issued before the first value is looked at (the two asm statements below take the raw
+        // values of eight steps each): left to itself the compiler keeps every pair of loads next to the select that
+        // consumes it and waits there -- 16 dependent memory round trips per wave, which WAS this kernel's run time.
 #pragma unroll
         for (int u = 0; u < UB; ++u) {
-            const int r = r0 + 4 * u + g;
-            const int rc = min(r, R - 1);
-            const float av = gp[(long)rc * 4 * L], bv = xp[(long)rc * L];
-            const bool rv = r < rend;
-            a[u] = (rv && jv) ? av : 0.f;
-            b[u] = rv ? (kcol < L ? bv : (kcol == L ? 1.f : 0.f)) : 0.f;
+            const int rc = min(r0 + 4 * u + g, R - 1);
+            a[u] = gp[(long)rc * 4 * L];
+            b[u] = xp[(long)rc * L];
+        }
+        static_assert(UB == 16, "operand lists below");
+        asm volatile("" : "+v"(a[0]), "+v"(b[0]), "+v"(a[1]), "+v"(b[1]), "+v"(a[2]), "+v"(b[2]), "+v"(a[3]), "+v"(b[3]),
+                          "+v"(a[4]), "+v"(b[4]), "+v"(a[5]), "+v"(b[5]), "+v"(a[6]), "+v"(b[6]), "+v"(a[7]), "+v"(b[7]),
+                          "+v"(a[8]), "+v"(b[8]), "+v"(a[9]), "+v"(b[9]), "+v"(a[10]), "+v"(b[10]), "+v"(a[11]), "+v"(b[11]),
+                          "+v"(a[12]), "+v"(b[12]), "+v"(a[13]), "+v"(b[13]), "+v"(a[14]), "+v"(b[14]));
+        asm volatile("" : "+v"(a[15]), "+v"(b[15]));
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+            const bool rv = r0 + 4 * u + g < rend;
+            a[u] = (rv && jv) ? a[u] : 0.f;
+            b[u] = rv ? (kcol < L ? b[u] : (kcol == L ? 1.f : 0.f)) : 0.f;
         }
 #pragma unroll
         for (int u = 0; u < UB; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u], b[u], acc, 0, 0, 0);
