@@ -73,6 +73,7 @@ __global__ __launch_bounds__(256) void gn_partial_k(const T* __restrict__ x, int
     constexpr int V = GnVec<T>::V;
     __shared__ float chs[256 * V];            // [row lanes][C] per-channel sums (row lanes * C == 256 * V)
     __shared__ float gm[64];
+    __shared__ float chc[256 * V];            // [C] per-channel totals (C <= 256 * V)
     const int tpr = C / V, rl_n = 256 / tpr;  // threads per row, row lanes
     const int rl = threadIdx.x / tpr, cv = threadIdx.x - rl * tpr;
     const int rb = rl_n * GN_PASSES;
@@ -94,10 +95,17 @@ __global__ __launch_bounds__(256) void gn_partial_k(const T* __restrict__ x, int
 #pragma unroll
         for (int k = 0; k < V; ++k) chs[rl * C + cv * V + k] = cs[k];
         __syncthreads();
+        // per-channel totals over the row lanes by C threads, then the group's cg channels: rl_n + cg dependent LDS
+        // reads instead of rl_n * cg by the first `groups` threads alone
+        for (int c = threadIdx.x; c < C; c += 256) {
+            float a = 0.f;
+            for (int q = 0; q < rl_n; ++q) a += chs[q * C + c];
+            chc[c] = a;
+        }
+        __syncthreads();
         float t = 0.f;
         if ((int)threadIdx.x < groups) {
-            for (int q = 0; q < rl_n; ++q)
-                for (int c = 0; c < cg; ++c) t += chs[q * C + threadIdx.x * cg + c];
+            for (int c = 0; c < cg; ++c) t += chc[threadIdx.x * cg + c];
         }
         __syncthreads();
         return t;
@@ -178,12 +186,36 @@ __global__ __launch_bounds__(256) void gn_apply_vec_k(const T* __restrict__ x, T
             ga[0] = g0.x; ga[1] = g0.y; ga[2] = g0.z; ga[3] = g0.w;
             be[0] = b0.x; be[1] = b0.y; be[2] = b0.z; be[3] = b0.w;
         }
+        if ((cg & 3) == 0) {
+            // a run of 4 channels (c0 is a multiple of V) lies in one group: V/4 statistics loads instead of 2 V, one
+            // fma per element; bf16 storage takes the swish through the hardware exp2 / rcp (error far below its
+            // rounding): with a division and two statistics loads per element this pass was ALU / latency bound
+            float mu[V / 4], rs[V / 4];
 #pragma unroll
-        for (int k = 0; k < V; ++k) {
-            const int sg = n * groups + (c0 + k) / cg;
-            float v = (Elem<T>::load(e + k) - mean[sg]) * rstd[sg] * ga[k] + be[k];
-            if (swish) v = v * sigmoidf_(v);
-            Elem<T>::store(e + k, v);
+            for (int h = 0; h < V / 4; ++h) {
+                const int sg = n * groups + (c0 + 4 * h) / cg;
+                mu[h] = mean[sg]; rs[h] = rstd[sg];
+            }
+#pragma unroll
+            for (int k = 0; k < V; ++k) {
+                const float sc = rs[k >> 2] * ga[k];
+                float v = fmaf(Elem<T>::load(e + k), sc, be[k] - mu[k >> 2] * sc);
+                if (swish) {
+                    if constexpr (sizeof(T) == 2)
+                        v = v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504f * v));
+                    else
+                        v = v * sigmoidf_(v);
+                }
+                Elem<T>::store(e + k, v);
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < V; ++k) {
+                const int sg = n * groups + (c0 + k) / cg;
+                float v = (Elem<T>::load(e + k) - mean[sg]) * rstd[sg] * ga[k] + be[k];
+                if (swish) v = v * sigmoidf_(v);
+                Elem<T>::store(e + k, v);
+            }
         }
         *(uint4*)(y + (size_t)r * ldy + c0) = raw;
     }
