@@ -202,7 +202,8 @@ __global__ __launch_bounds__(256, (DL_SL == 1 ? 3 : 2)) void deconv_last_fused_k
         const size_t xo = (size_t)n * Cout * plane + (size_t)oh * OW + ow;
         float d4[4] = {0.f, 0.f, 0.f, 0.f}, sg[4];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) sg[c] = sigmoidf_(v[c]);
+        for (int c = 0; c < 4; ++c)     // hardware exp2 / rcp (about 1 ulp each; this kernel is the bf16-storage path)
+            sg[c] = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * v[c]));
 #pragma unroll
         for (int c = 0; c < 4; ++c)
             if (c < Cout) p.xr[xo + (size_t)c * plane] = sg[c];
