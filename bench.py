@@ -3,36 +3,64 @@
 forward + backward + losses + Adam) on synthetic LDM-latent frames.
 
   python bench.py --gpus N --steps K --warmup W
-  (N > 1: launched by torch.distributed.run, one rank per GPU, RCCL all-reduce of the flat gradients)
 
-Workload (BASELINE.json configs[1]): percep_RBVAE, item [16,2,8,4,32,32] ~ N(0,1)
+N > 1 works both ways: launched by torch.distributed.run (RANK / WORLD_SIZE in the environment), or typed as is --
+then this process spawns N fresh rank processes BEFORE anything touches the GPU, waits for them and relays rank 0's
+JSON line.  One rank per GPU, RCCL all-reduce of the flat gradients (RBVAE_DIST_BACKEND=gloo rehearses the N > 1
+path with several ranks sharing one GPU).
+
+Workload (BASELINE.json configs[1]): percep_RBVAE, items [16,2,8,4,32,32] ~ N(0,1)
 (256 frames per step per GPU = the latents of 256x256 frames), latent 32, 4-layer LSTMs, bf16
 storage / f32 accumulation, tau 0.7, noise ratio 0.1, p 0.1, alpha = beta = 1, dropout on.
+A step includes the gather of its batch from the HBM-resident latent table (the reference's DataLoader + .to(device)).
 Prints ONE JSON line on rank 0.
 """
 import argparse
 import contextlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import torch
-
 B_ITEMS, T_STATES, C_IN, HW, LATENT = 16, 8, 4, (32, 32), 32
 TAU, NOISE_R, BERN_P, ALPHA, BETA = 0.7, 0.1, 0.1, 1.0, 1.0
-MFMA_BF16_PEAK_TFLOPS = 2500.0     # MI355X_MICROARCH.md: dense bf16 MFMA peak
-# HBM bytes per launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this same command (separate
-# passes, FETCH doubled per the guide's gfx950 correction); filled in from profiles/ by tools/pmc_traffic.py
-PMC_TRAFFIC = {}
-try:
-    with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as _f:
-        PMC_TRAFFIC = json.load(_f)
-except (OSError, ValueError):
-    pass
+FRAMES_PER_STATE = 512                # synthetic latent table: 8 states x 512 frames (4 096 frames, 64 MB f32)
+MFMA_BF16_PEAK_TFLOPS = 2500.0        # MI355X_MICROARCH.md: dense bf16 MFMA peak
+# SURVEY.md 8d, cfg 2: 596.3 MFLOP and 1.805 MB (bf16 layer-boundary bytes) per frame
+#   HBM roof  = 8.0 TB/s / 1.805 MB  = 4.43 M frames/s;  MFMA roof = 2.5 PFLOP/s / 596.3 MFLOP = 4.19 M frames/s
+ROOF_HBM_FPS, ROOF_MFMA_FPS = 8.0e12 / 1.805e6, 2.5e15 / 596.3e6
+ROOF_F32 = (8.0e12 / 3.611e6, 157.3e12 / 596.3e6)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def self_launch(n, argv):
+    """`python bench.py --gpus N` typed as is: N rank processes, started before this one has made any GPU call
+    (it never makes one), environment as torch.distributed.run would set it.  Returns the exit code."""
+    port = _free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out, _ = procs[0].communicate()
+    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out.decode())
+    sys.stdout.flush()
+    return next((c for c in codes if c), 0)
 
 
 class KernelTimer:
@@ -44,6 +72,7 @@ class KernelTimer:
 
     @contextlib.contextmanager
     def __call__(self, flops):
+        import torch
         st = torch.cuda.current_stream()
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record(st)
@@ -53,21 +82,28 @@ class KernelTimer:
         self.flops += flops
 
     def result(self):
+        import torch
         torch.cuda.synchronize()
         ms = sum(a.elapsed_time(b) for a, b in self.pairs)
         return ms, len(self.pairs), self.flops
 
 
-def roofline_leg(trainer, item, steps, tname):
-    """Re-run `steps` steps eagerly on ONE stream (RBVAE_OVERLAP off for this leg, so an event pair brackets exactly
-    one kernel) with HIP events around every launch of the two matrix-core kernel families, keyed by the template
-    instance the library's dispatch picks.  Returns {instance: (ms, launches, algorithmic flops)}.
+def roofline_leg(trainer, steps, tname, overlap):
+    """Re-run `steps` steps eagerly with HIP events around every launch of the two matrix-core kernel families, each
+    pair recorded on the stream its kernel is launched on, keyed by the template instance the library's dispatch picks.
+
+    overlap=True: the SAME multi-stream schedule as the captured graph (side streams on), so a kernel is timed beside
+    whatever the graph runs beside it -- this is what `roofline.frac` is computed from.  overlap=False: everything on
+    one stream (the kernel alone on the chip) -- reported as `isolated`.  Either way the streams are held behind a
+    ~20 ms device-side sleep while the host enqueues the whole step, so an event pair brackets the kernel and not the
+    host's launch latency, and the cost of an empty event pair is measured the same way and subtracted.
 
       gather_gemm_k<T,4,8,3>  128x128 row-gather GEMM, deep K, 129..256 workgroups: conv2 forward, first deconv
                               forward (4 parity classes) and their two input-gradient twins
       wgrad_gemm_k<T,2,3>     128x128 weight-gradient GEMM with K split over workgroups: the five 256-channel ones
     Algorithmic FLOPs: 2 * output rows * Nout * Kc * taps for the gather GEMM (the 4 parity classes of a
     transposed convolution share its k*k taps: taps/4 per output pixel), 2 * P * Co * Ci * taps for wgrad."""
+    import torch
     eng = trainer.eng
     timers = {}
     orig_gemm, orig_wgrad = eng._gemm, eng._wgrad
@@ -102,23 +138,20 @@ def roofline_leg(trainer, item, steps, tname):
     calib = KernelTimer()                  # event pairs around nothing: the event records' own cost
 
     eng._gemm, eng._wgrad = timed_gemm, timed_wgrad
-    overlap = eng.overlap
-    eng.overlap = False
+    was_overlap = eng.overlap
+    eng.overlap = overlap
     trainer.instrument = True
     try:
-        for _ in range(2):                   # the eager one-stream path's own first-use work (job tables, buffers)
-            trainer.step(item, TAU)
+        for _ in range(2):                   # the eager path's own first-use work (job tables, buffers)
+            trainer.step(None, TAU)
         torch.cuda.synchronize()
         timers.clear()
         for _ in range(steps):
-            # Hold the stream behind a ~20 ms device-side sleep while the host enqueues the whole step: the GPU then
-            # runs the launches and event records back to back, so an event pair brackets the kernel and not the
-            # host's launch latency (eager launches are host bound: ~10 us of idle queue per launch otherwise).
             torch.cuda._sleep(40_000_000)
             for _ in range(4):
                 with calib(0.0):
                     pass
-            trainer.step(item, TAU)
+            trainer.step(None, TAU)
             torch.cuda.synchronize()
         cms, cn, _ = calib.result()
         per_pair = cms / max(cn, 1)
@@ -129,13 +162,14 @@ def roofline_leg(trainer, item, steps, tname):
         res["_event_pair_overhead_us"] = per_pair * 1e3
     finally:
         eng._gemm, eng._wgrad = orig_gemm, orig_wgrad
-        eng.overlap = overlap
+        eng.overlap = was_overlap
         trainer.instrument = None
     return res
 
 
 def cpu_baseline(seconds_budget=15.0):
     """The oracle (plain-torch restatement pinned to the reference by tests/golden) on this host's cores."""
+    import torch
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import rbvae_oracle as O
     try:
@@ -165,14 +199,27 @@ def cpu_baseline(seconds_budget=15.0):
         with torch.no_grad():
             O.adam_step({k: v for k, v in p.items()}, {k: v.grad for k, v in p.items()}, state, 1e-3, step)
         times.append(time.perf_counter() - t0)
-        print(f"[cpu_baseline] step {len(times)}: {times[-1]:.2f} s", file=sys.stderr, flush=True)
         if (len(times) >= 2 and time.perf_counter() - t_start > seconds_budget) or len(times) >= 400:
             break
     times = times[1:] if len(times) > 1 else times   # first step warms the allocator / oneDNN primitives
     frames = Bc * 2 * T_STATES
+    cpu_model = ""
+    try:
+        with open("/proc/cpuinfo") as f:
+            cpu_model = next((l.split(":", 1)[1].strip() for l in f if l.startswith("model name")), "")
+    except OSError:
+        pass
     return {"value": round(frames / (sum(times) / len(times)), 2), "unit": "frames/s", "cores": cores, "kind": "port",
             "sample": f"{len(times)} steps of {frames} frames (item [{Bc},2,{T_STATES},{C_IN},{HW[0]},{HW[1]}]), "
-                      f"fwd+bwd+Adam, torch {torch.__version__} CPU, {cores} threads"}
+                      f"fwd+bwd+Adam, torch {torch.__version__} CPU, {cores} threads, {cpu_model}"}
+
+
+def load_profile_json(name):
+    try:
+        with open(os.path.join(ROOT, "profiles", name)) as f:
+            return json.load(f)
+    except (OSError, ValueError):
+        return {}
 
 
 def main():
@@ -182,13 +229,20 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--no-roofline", action="store_true", help="skip the per-kernel event legs")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args.gpus, sys.argv[1:]))          # no GPU call has happened in this process
+
+    import random
+    import torch
     import sfv_amd as sfv
     from importlib import import_module
     ddp = import_module("symbols-from-video_amd.ddp")
     trainer_mod = import_module("symbols-from-video_amd.trainer")
+    data_mod = import_module("symbols-from-video_amd.data")
     # RCCL ("nccl") is the backend of record; RBVAE_DIST_BACKEND=gloo lets the N > 1 code path be rehearsed
     # with several ranks sharing one GPU (RCCL refuses duplicate devices)
     backend = os.environ.get("RBVAE_DIST_BACKEND", "nccl")
@@ -197,7 +251,7 @@ def main():
         torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")) % ndev)
     rank, world, local = ddp.init_from_env(backend)
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     local = local % ndev
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
@@ -206,24 +260,26 @@ def main():
     model = sfv.Seq2SeqBinaryVAE(C_IN, C_IN, LATENT, LATENT, variant="percep", input_hw=HW,
                                  compute_dtype=args.dtype).to(dev).train()
     ddp.broadcast_(model._flat)
-    g = torch.Generator(device="cpu").manual_seed(1234 + rank)          # per-rank shard of the global batch
-    item = torch.randn(B_ITEMS, 2, T_STATES, C_IN, *HW, generator=g).to(dev)
+    # per-rank shard of the data: its own synthetic latent table, pairs and shuffle (seed + rank)
+    g = torch.Generator(device="cpu").manual_seed(1234 + rank)
+    table = torch.randn(T_STATES * FRAMES_PER_STATE, C_IN, *HW, generator=g)
+    random.seed(1234 + rank)
+    segs = [(s * FRAMES_PER_STATE, (s + 1) * FRAMES_PER_STATE) for s in range(T_STATES)]
+    ds = data_mod.DeviceStatePairDataset(table, segs, mode="train", device=dev)
+    plan = ds.plan(torch.randperm(len(ds), generator=g), B_ITEMS)
     tr = trainer_mod.FusedTrainer(model, lr=1e-3, alpha=ALPHA, beta_kl=BETA, bernoulli_p=BERN_P, noise_ratio=NOISE_R,
-                                  device_noise=True, use_graph=not args.no_graph)
+                                  device_noise=True, use_graph=not args.no_graph, seed=1234)
+    tr.set_data(ds.table, plan)
     frames_per_step = B_ITEMS * 2 * T_STATES
-    # the batch lives in the trainer's static input buffer (a device-resident data loader gathers into it in place)
-    buf = tr.input_buffer(B_ITEMS, T_STATES, C_IN, *HW)
-    buf.copy_(item)
-    item = buf
 
     for _ in range(args.warmup):
-        tr.step(item, TAU)
+        tr.step(None, TAU)
     if world > 1:
         torch.distributed.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        tr.step(item, TAU)
+        tr.step(None, TAU)
     torch.cuda.synchronize()
     if world > 1:
         torch.distributed.barrier()
@@ -237,38 +293,65 @@ def main():
     roof = None
     roof_all = None
     cpu = None
-    # every rank runs the instrumented leg (its steps contain the gradient all-reduce: a collective)
     tname = "unsigned short" if args.dtype == "bf16" else "float"
-    legs = roofline_leg(tr, item, min(args.steps, 20), tname)
-    if rank == 0:
+    nleg = min(args.steps, 20)
+    if not args.no_roofline:
+        # every rank runs the instrumented legs (their steps contain the gradient all-reduce: a collective)
+        legs = roofline_leg(tr, nleg, tname, overlap=True)
+        legs_iso = roofline_leg(tr, nleg, tname, overlap=False)
+    if rank == 0 and not args.no_roofline:
         peak = MFMA_BF16_PEAK_TFLOPS if args.dtype == "bf16" else 157.3
+        traffic = load_profile_json("pmc_traffic.json")
+        mfma_busy = load_profile_json("pmc_mfma_busy.json")
         roof_all = {}
         ev_us = legs.pop("_event_pair_overhead_us", 0.0)
+        legs_iso.pop("_event_pair_overhead_us", None)
         for name, (ms, launches, flops) in sorted(legs.items(), key=lambda kv: -kv[1][0]):
             ach = flops / (ms * 1e-3) / 1e12
-            roof_all[name] = {"achieved": round(ach, 2), "frac": round(ach / peak, 4), "launches": launches,
-                              "avg_us": round(ms * 1e3 / max(launches, 1), 2),
-                              "us_per_step": round(ms * 1e3 / min(args.steps, 20), 1)}
+            e = {"achieved": round(ach, 2), "frac": round(ach / peak, 4), "launches": launches,
+                 "avg_us": round(ms * 1e3 / max(launches, 1), 2), "us_per_step": round(ms * 1e3 / nleg, 1)}
+            if name in legs_iso:
+                ims, il, ifl = legs_iso[name]
+                e["isolated"] = {"avg_us": round(ims * 1e3 / max(il, 1), 2),
+                                 "frac": round(ifl / (ims * 1e-3) / 1e12 / peak, 4)}
+            if name in mfma_busy:
+                e["pmc"] = mfma_busy[name]
+            roof_all[name] = e
         dom = next(iter(roof_all))                       # the instance with the largest total time
         d = roof_all[dom]
         roof = {"bound": "mfma", "kernel": dom, "achieved": d["achieved"], "peak": peak, "unit": "TFLOP/s",
-                "frac": d["frac"], "traffic": PMC_TRAFFIC.get(dom), "launches": d["launches"], "avg_us": d["avg_us"],
-                "us_per_step": d["us_per_step"], "event_pair_overhead_us_subtracted": round(ev_us, 2)}
-        if world == 1 and not args.no_cpu:
-            cpu = cpu_baseline()
+                "frac": d["frac"], "traffic": traffic.get(dom), "launches": d["launches"], "avg_us": d["avg_us"],
+                "us_per_step": d["us_per_step"], "isolated": d.get("isolated"), "pmc": d.get("pmc"),
+                "timing": "HIP events on the launching stream, same multi-stream schedule as the captured graph "
+                          "(side streams on); `isolated` = the kernel alone on one stream",
+                "event_pair_overhead_us_subtracted": round(ev_us, 2)}
+    if rank == 0 and world == 1 and not args.no_cpu:
+        cpu = cpu_baseline()
     if world > 1:
         torch.distributed.barrier()
     if rank == 0:
         value = frames_per_step * world * args.steps / dt
+        hbm_roof, mfma_roof = (ROOF_HBM_FPS, ROOF_MFMA_FPS) if args.dtype == "bf16" else ROOF_F32
+        per_gpu = value / world
+        e2e = {"frames_per_s_per_gpu": round(per_gpu, 1), "hbm_roof_frames_per_s": round(hbm_roof, 0),
+               "frac_hbm": round(per_gpu / hbm_roof, 4), "mfma_roof_frames_per_s": round(mfma_roof, 0),
+               "frac_mfma": round(per_gpu / mfma_roof, 4),
+               "basis": "SURVEY.md 8d: 596.3 MFLOP and 1.805 MB (bf16; 3.611 MB f32) per frame fwd+bwd; 8.0 TB/s, "
+                        "2.5 PFLOP/s bf16 (157.3 TFLOP/s f32)"}
+        if roof is not None:
+            roof["e2e"] = e2e
+        else:
+            roof = {"e2e": e2e}
         line = {"metric": "frames/sec (enc+binarise+dec fwd+bwd), batch 256x256, 1/2/4/8 MI355X",
                 "value": round(value, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
                 "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True,
                 "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-                "config": {"workload": "percep_RBVAE fused train step (fwd+bwd+losses+Adam), item [16,2,8,4,32,32] "
-                                       "per GPU = 256 frames/step/GPU (latents of 256x256 frames), latent 32, "
-                                       "4-layer LSTMs, dropout on",
+                "config": {"workload": "percep_RBVAE fused train step (batch gather from the HBM-resident latent table "
+                                       "+ fwd+bwd+losses+Adam), item [16,2,8,4,32,32] per GPU = 256 frames/step/GPU "
+                                       "(latents of 256x256 frames), latent 32, 4-layer LSTMs, dropout on",
                            "frames_per_step_per_gpu": frames_per_step, "global_frames_per_step": frames_per_step * world,
                            "parallelism": f"dp{world}", "graph": not args.no_graph,
+                           "graphs_captured": len(tr._graphs), "launcher": "torch.distributed.run or self-spawned ranks",
                            "last_losses": {"total": losses[0], "recon": losses[1], "kl": losses[2], "pair": losses[3]}},
                 "roofline": roof, "roofline_all_mfma_kernels": roof_all, "cpu_baseline": cpu}
         print(json.dumps(line))

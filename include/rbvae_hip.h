@@ -18,7 +18,10 @@
  *    (bf16 storage, f32 accumulation, bf16 MFMA).  LSTM, binarise and the loss
  *    reductions are always f32;
  *  - activations are NHWC ("pixel rows of C channels"), weights are the packed
- *    layouts produced by rbvae_pack_conv_weight / rbvae_pack_linear_weight.
+ *    layouts written by the rbvae_run_jobs pack jobs (kinds 0 and 3, see that entry
+ *    point) from the reference-layout f32 parameters.
+ * The hardware-map probes and phase-stamp hooks of debug builds are NOT part of this
+ * ABI: include/rbvae_dbg.h, librbvae_dbg.so.
  */
 #ifndef RBVAE_HIP_H
 #define RBVAE_HIP_H
@@ -64,13 +67,16 @@ int rbvae_binarize_kl_fwd(const float* h, const float* U, float* y_soft, float* 
  * one-workgroup form above is ALU-latency bound at the trainer's 256 x 32 logits; this one is not. */
 int rbvae_binarize_kl_nparts(int rows, int L);
 int rbvae_binarize_kl_fwd_parts(const float* h, const float* U, float* y_soft, float* z, float* kl_parts,
-                                int rows, int L, float tau, float noise_ratio, float noise_eps, int hard,
+                                int rows, int L, float tau, const float* tau_dev, float noise_ratio, float noise_eps, int hard,
                                 float kl_p, float kl_eps, int kl_clamp, unsigned long long seed,
                                 const unsigned long long* seed_dev, void* stream);
 /* dh (+)= (g_z + kl_weight * gscale * dKL/dz) * y_soft*(1-y_soft)/tau (straight-through when hard).
- * g_z may be NULL; gscale_dev (device scalar, may be NULL = 1) multiplies kl_weight. */
+ * g_z may be NULL; gscale_dev (device scalar, may be NULL = 1) multiplies kl_weight.
+ * tau_dev (here and in every entry point that has it): when not NULL the kernel reads the temperature from that
+ * device float instead of `tau`, so a captured HIP graph follows the reference's annealing schedule
+ * (percep_RBVAE_train.py:424-437) without being re-captured. */
 int rbvae_binarize_kl_bwd(const float* g_z, const float* y_soft, const float* z, float* dh, int accumulate,
-                          int rows, int L, float tau, float kl_weight, const float* gscale_dev,
+                          int rows, int L, float tau, const float* tau_dev, float kl_weight, const float* gscale_dev,
                           float kl_p, float kl_eps, int kl_clamp, void* stream);
 
 /* kl_binary_concrete as a free function (percep_RBVAE_train.py:52-76; simple
@@ -155,12 +161,13 @@ int rbvae_stream_gemm(const void* A, const void* W, void* Out, const float* bias
 /* ---- weight-gradient GEMM ---------------------------------------------------------
  * dW[ks][co][t][ci] = sum over K-slice ks of Dy[p][co] * In[idx[t][p]][ci]  (f32 slabs, one per
  * K-slice; sum them with rbvae_permute_reduce).  idx = rbvae_conv_gather_index table or NULL
- * (identity, 1 tap: Linear).  Autograd of the Conv2d/ConvTranspose2d/Linear weights
+ * (identity, 1 tap: Linear).  in_rows = rows of In: an index outside [0, in_rows) reads the zero row, so a
+ * wrong table can give wrong sums but never an out-of-bounds access.  Autograd of the Conv2d/ConvTranspose2d/Linear weights
  * (percep_RBVAE_model.py:51-61,74-82). */
 int rbvae_conv_gather_index(int* idx, int Nimg, int IH, int IW, int OH, int OW, int KH, int KW, int stride,
                             int pad, void* stream);
 int rbvae_wgrad_gemm(int dtype, const void* Dy, const void* In, float* dW_slabs, const int* idx,
-                     const void* zero_page, int P, int Co, int Ci, int ldy, int ldi, int taps, int ksplit,
+                     const void* zero_page, int P, int in_rows, int Co, int Ci, int ldy, int ldi, int taps, int ksplit,
                      void* stream);
 
 /* ---- layout helpers --------------------------------------------------------------
@@ -297,15 +304,15 @@ int rbvae_lstm_pair_fwd_ok(int T, int L, int layers);
 int rbvae_lstm_pair_fwd(const float* wblk_enc, const float* wT_enc, const float* wblk_dec, const float* wT_dec,
                         float* hs_enc, float* hprev_enc, float* acts_enc, float* cs_enc, float* hs_dec,
                         float* hprev_dec, float* acts_dec, float* cs_dec, const float* in_parts, int nparts,
-                        long part_stride, const float* U, float* y_soft, float* kl_parts, float tau, float noise_ratio,
-                        float noise_eps, int hard, float kl_p, float kl_eps, int kl_clamp, unsigned long long seed,
+                        long part_stride, const float* U, float* y_soft, float* kl_parts, float tau, const float* tau_dev,
+                        float noise_ratio, float noise_eps, int hard, float kl_p, float kl_eps, int kl_clamp, unsigned long long seed,
                         const unsigned long long* seed_dev, void* cast_out, int cast_dtype, int cast_ld, int S, int T,
                         int L, int layers, void* stream);
 /* The encoder stack's BPTT with rbvae_binarize_kl_bwd fused into its prologue (wavefront kernel only):
  *   g_top = g_hs + (g_z + kl_weight/(S*T) * dKL/dz(z)) * y_soft*(1-y_soft)/tau,   g_hs may be NULL;
  * cast_out / dx_colsum as in rbvae_lstm_bwd_ex. */
 int rbvae_lstm_bwd_bin(const float* wblk, const float* acts, const float* cs, const float* g_z, const float* y_soft,
-                       const float* z, const float* g_hs, float tau, float kl_weight, float kl_p, float kl_eps,
+                       const float* z, const float* g_hs, float tau, const float* tau_dev, float kl_weight, float kl_p, float kl_eps,
                        int kl_clamp, float* dG, float* dx, void* cast_out, int cast_dtype, int cast_ld, float* dx_colsum,
                        int S, int T, int L, int layers, void* stream);
 int rbvae_lstm_wgrad(const float* dG, const float* hs_all, const float* hprev, float* gblk, int S, int T, int L,
@@ -314,6 +321,13 @@ int rbvae_lstm_wgrad(const float* dG, const float* hs_all, const float* hprev, f
 int rbvae_lstm_wgrad_pair(const float* dG_a, const float* hs_a, const float* hprev_a, float* gblk_a, const float* dG_b,
                           const float* hs_b, const float* hprev_b, float* gblk_b, int S, int T, int L, int layers,
                           int accumulate, void* stream);
+
+/* The trainer's DataLoader + item.to(device) (percep_RBVAE_train.py:509-518, ShuffledStatePairDataset.__getitem__
+ * :312-360) for a latent table resident in HBM: out[r] = table[plan[batch][r]] for r < rows, frames of frame_elems
+ * floats; plan is [n_batches][rows] table rows (int64, the epoch's shuffled batches laid out in advance) and
+ * batch = *counter_dev % n_batches (the device step counter: the gather can sit inside the captured step graph) or 0. */
+int rbvae_gather_frames(const float* table, long table_rows, const long* plan, int rows, int n_batches,
+                        const unsigned long long* counter_dev, long frame_elems, float* out, void* stream);
 
 /* torch.optim.Adam defaults (percep_RBVAE_train.py:753,553) on a flat f32 buffer; g is scaled by gscale
  * first.  The step number comes from `step` or, when step_dev != NULL, from a device counter that the call
@@ -328,11 +342,12 @@ int rbvae_adam_step(float* w, const float* g, float* m, float* v, long n, double
  * kl_parts > 0, kl_scale * sum(kl[0..kl_parts)) (rbvae_binarize_kl_fwd_parts' per-block sums); pair = pair[0]
  * or, when pair_parts > 0, w_sim * sum(pair[2i]) + w_dis * sum(pair[2i+1]) (rbvae_contrast_term_fused).
  * step_dev != NULL: also advances the device step counter and leaves Adam's bias-correction terms for that step
- * in hyper_ws (2 floats); rbvae_adam_step(step_dev = NULL, hyper_ws) then uses them without a launch of its own. */
+ * in hyper_ws (2 floats); rbvae_adam_step(step_dev = NULL, hyper_ws) then uses them without a launch of its own.
+ * lr_dev != NULL: the learning rate is read from that device double (a captured graph follows an lr schedule). */
 int rbvae_combine_losses(const float* sse_ws, int nparts, float inv_n, const float* recon, const float* kl,
                          int kl_parts, float kl_scale, const float* pair, int pair_parts, float w_sim, float w_dis,
-                         float beta, float alpha, float* out4, unsigned long long* step_dev, double lr, double beta1,
-                         double beta2, float* hyper_ws, void* stream);
+                         float beta, float alpha, float* out4, unsigned long long* step_dev, double lr,
+                         const double* lr_dev, double beta1, double beta2, float* hyper_ws, void* stream);
 
 /* ---- frozen LDM / Stable-Diffusion VAE encoder (cfg 5: on-the-fly latents) ------------------------
  * The convolutions, 1x1 projections and both attention products run on rbvae_gather_gemm (stride-1 and
@@ -354,16 +369,6 @@ int rbvae_softmax_rows(int dtype, const void* x, void* y, long rows, int n, int 
 int rbvae_transpose2d(int dtype, const void* in, void* out, int R, int C, int ldi, int ldo, void* stream);
 int rbvae_posterior_sample(int dtype, const void* moments, int ld, const float* eps, float* latent, int N, int Z,
                            int HW, float scale, void* stream);
-
-/* ---- hardware-map probes (diagnostics; tests/test_hw_maps.py) ------------------
- * One-wave kernels that pin the gfx950 lane maps the GEMM kernels assume. */
-int rbvae_dbg_mfma_bf16(const void* A, const void* B, float* D, void* stream);   /* [16x32]x[32x16] bf16 */
-int rbvae_dbg_mfma_f32(const float* A, const float* B, float* D, void* stream);  /* [16x4]x[4x16] f32 */
-int rbvae_dbg_glds(const void* src, const int* lane_src_chunk, void* out, void* stream);
-/* every later rbvae_gather_gemm launch writes 8 phase time stamps (100 MHz) per workgroup into buf (NULL = off) */
-int rbvae_dbg_gg_stamps(unsigned long long* buf, void* stream);
-int rbvae_dbg_wg_stamps(unsigned long long* buf, void* stream);   /* same for rbvae_wgrad_gemm (-DWG_STAMPS=1 builds) */
-int rbvae_dbg_tr16(const void* img, const int* rowsel, const int* colsel, void* out, void* stream);
 
 #ifdef __cplusplus
 }

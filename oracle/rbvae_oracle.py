@@ -309,9 +309,11 @@ def step_losses(variant: str, p: Dict[str, Tensor], item: Tensor, U: Sequence[Te
                 alpha: float = 0.1, beta: float = 0.1, margin: float = 1.0,
                 hard: bool = False, train: bool = False,
                 masks: Optional[Sequence[Sequence[Tensor]]] = None,
-                validation_norm: bool = False) -> Dict[str, Tensor]:
+                validation_norm: bool = False, pair_loss: Optional[str] = None) -> Dict[str, Tensor]:
     """One trainer step's loss for item [B,2,T,C,H,W] (percep_RBVAE_train.py:517-549;
-    validation weighting :590-635 when validation_norm)."""
+    validation weighting :590-635 when validation_norm).
+    pair_loss: "contrast" | "triplet" overrides the variant's own pairwise term (BASELINE configs[4]: the
+    percep-shaped network trained with the triplet term of triplet_RBVAE_train.py:461-468)."""
     recons, kls, hs = [], [], []
     for vw in range(2):
         xr, h, z = forward(variant, p, item[:, vw], U[vw], temperature, hard, noise_ratio,
@@ -321,7 +323,7 @@ def step_losses(variant: str, p: Dict[str, Tensor], item: Tensor, U: Sequence[Te
         hs.append(h)
     recon = (recons[0] + recons[1]) / 2
     kl = (kls[0] + kls[1]) / 2
-    if variant == "triplet":
+    if (pair_loss or ("triplet" if variant == "triplet" else "contrast")) == "triplet":
         pair = triplet_term(hs[0], hs[1], margin)
     else:
         pair = contrast_term(hs[0], hs[1])

@@ -89,3 +89,26 @@ def call(name, *args):
 
 def query(name, *args):
     return getattr(lib(), name)(*args)
+
+
+# ---- diagnostic probes (include/rbvae_dbg.h, librbvae_dbg.so): not part of the product ABI ----------------
+DBG_HEADER = os.path.join(os.path.dirname(HERE), "include", "rbvae_dbg.h")
+DBG_LIB_PATH = os.path.join(HERE, "librbvae_dbg.so")
+_dbg = None
+
+
+def dbg_call(name, *args):
+    """Call a hardware-map probe of librbvae_dbg.so on torch's current stream."""
+    global _dbg
+    if _dbg is None:
+        lib()                                   # the probes resolve rbvae::fail from the main library
+        l = ctypes.CDLL(DBG_LIB_PATH)
+        for n, (restype, a) in parse_header(DBG_HEADER).items():
+            fn = getattr(l, n, None)            # the stamp hooks exist in stamped builds of the main library only
+            if fn is not None:
+                fn.restype = restype
+                fn.argtypes = [t for t, _ in a]
+        _dbg = l
+    rc = getattr(_dbg, name)(*[_ptr(a) for a in args], stream_ptr())
+    if rc != 0:
+        raise RuntimeError(f"{name} failed ({rc}): {lib().rbvae_last_error().decode()}")

@@ -1,4 +1,7 @@
-"""Build librbvae_hip.so for gfx950 with hipcc (in-tree, next to this file)."""
+"""Build librbvae_hip.so (the product C-ABI, include/rbvae_hip.h) and librbvae_dbg.so (hardware-map probes,
+include/rbvae_dbg.h) for gfx950 with hipcc, in-tree, next to this file.
+RBVAE_DEBUG=1: also build librbvae_hip_debug.so with the GEMM kernels' phase stamps compiled in (-DGG_STAMPS=1
+-DWG_STAMPS=1; select it with RBVAE_LIB=...)."""
 import concurrent.futures
 import os
 import subprocess
@@ -8,6 +11,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "build")
 LIB = os.path.join(HERE, "librbvae_hip.so")
+DBG_LIB = os.path.join(HERE, "librbvae_dbg.so")
+DEBUG_LIB = os.path.join(HERE, "librbvae_hip_debug.so")
+DBG_SOURCES = ("dbg.hip",)
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]
 
@@ -23,16 +29,16 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def _compile(src):
-    obj = os.path.join(OBJ, src[:-4] + ".o")
+def _compile(src, extra=(), suffix=""):
+    obj = os.path.join(OBJ, src[:-4] + suffix + ".o")
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
     headers.append(os.path.join(os.path.dirname(HERE), "include", "rbvae_hip.h"))
     if _stale(obj, [os.path.join(CSRC, src)] + headers):
-        cmd = [HIPCC] + FLAGS + ["-c", os.path.join(CSRC, src), "-o", obj]
+        cmd = [HIPCC] + FLAGS + list(extra) + ["-c", os.path.join(CSRC, src), "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed on {src}:\n{r.stdout}\n{r.stderr}")
-        if src in ISA_CHECKED:
+        if src in ISA_CHECKED and not extra:
             try:
                 _check_asm_reads(src)
             except Exception:
@@ -71,14 +77,26 @@ def build(verbose=False):
     os.makedirs(OBJ, exist_ok=True)
     with concurrent.futures.ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 2)) as ex:
         res = list(ex.map(_compile, sources()))
-    objs = [o for o, _ in res]
-    if any(c for _, c in res) or _stale(LIB, objs):
-        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
-        r = subprocess.run(cmd, capture_output=True, text=True)
-        if r.returncode != 0:
-            raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
-        if verbose:
-            print("built", LIB)
+    objs = [o for (o, _), src in zip(res, sources()) if src not in DBG_SOURCES]
+    dbg_objs = [o for (o, _), src in zip(res, sources()) if src in DBG_SOURCES]
+
+    def link(target, objects, extra=()):
+        if _stale(target, objects) or any(c for _, c in res):
+            cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", target] + objects + list(extra)
+            r = subprocess.run(cmd, capture_output=True, text=True)
+            if r.returncode != 0:
+                raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
+            if verbose:
+                print("built", target)
+
+    link(LIB, objs)
+    # the probes report errors through the main library's rbvae::fail
+    link(DBG_LIB, dbg_objs, ["-L" + HERE, "-lrbvae_hip", "-Wl,-rpath,$ORIGIN"])
+    if os.environ.get("RBVAE_DEBUG") == "1":
+        stamped = ["-DGG_STAMPS=1", "-DWG_STAMPS=1"]
+        with concurrent.futures.ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 2)) as ex:
+            dres = list(ex.map(lambda s_: _compile(s_, stamped, ".dbg"), [s_ for s_ in sources() if s_ not in DBG_SOURCES]))
+        link(DEBUG_LIB, [o for o, _ in dres])
     return LIB
 
 

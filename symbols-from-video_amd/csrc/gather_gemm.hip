@@ -609,12 +609,15 @@ static int dispatch_gg(const GgArgs& a, hipStream_t st, int max_steps) {
 using namespace rbvae;
 
 static unsigned long long* g_gg_stamps = nullptr;
-/* debug: every later rbvae_gather_gemm launch writes 8 phase stamps per workgroup into buf (null = off) */
+#if GG_STAMPS
+/* stamped builds only (include/rbvae_dbg.h): every later rbvae_gather_gemm launch writes 8 phase stamps per
+ * workgroup into buf (null = off) */
 extern "C" int rbvae_dbg_gg_stamps(unsigned long long* buf, void* stream) {
     (void)stream;
     g_gg_stamps = buf;
     return RBVAE_OK;
 }
+#endif
 
 extern "C" int rbvae_gather_gemm(int dtype, const void* A, const void* W, void* Out, const float* bias,
                                  const void* gate, const void* mask, const void* addend, const void* zero_page, int Nimg, int IH,

@@ -732,9 +732,11 @@ __global__ __launch_bounds__(1024) void combine_losses_k(const float* __restrict
                                                          float w_sim, float w_dis,
                                                          float beta, float alpha, float* __restrict__ out4,
                                                          unsigned long long* __restrict__ step_dev, double lr,
+                                                         const double* __restrict__ lr_dev,
                                                          double b1, double b2, float* __restrict__ hyper) {
     __shared__ float red[16];
     if (step_dev && threadIdx.x == 64) {
+        if (lr_dev) lr = lr_dev[0];
         // the optimiser's bias corrections for the step that follows (what adam_hyper_k does as its own launch)
         const unsigned long long s1 = step_dev[0] + 1;
         step_dev[0] = s1;
@@ -779,13 +781,13 @@ __global__ __launch_bounds__(1024) void combine_losses_k(const float* __restrict
 
 int rbvae_combine_losses(const float* sse_ws, int nparts, float inv_n, const float* recon, const float* kl,
                          int kl_parts, float kl_scale, const float* pair, int pair_parts, float w_sim, float w_dis,
-                         float beta, float alpha, float* out4, unsigned long long* step_dev, double lr, double beta1,
-                         double beta2, float* hyper_ws, void* stream) {
+                         float beta, float alpha, float* out4, unsigned long long* step_dev, double lr,
+                         const double* lr_dev, double beta1, double beta2, float* hyper_ws, void* stream) {
     RBVAE_CHECK_ARG(kl && pair && out4 && (sse_ws || recon) && kl_parts >= 0 && pair_parts >= 0, "combine_losses: bad arguments");
     RBVAE_CHECK_ARG(!step_dev || hyper_ws, "combine_losses: step_dev needs hyper_ws");
     hipLaunchKernelGGL(combine_losses_k, dim3(1), dim3(1024), 0, (hipStream_t)stream, sse_ws, nparts, inv_n, recon, kl,
-                       kl_parts, kl_scale, pair, pair_parts, w_sim, w_dis, beta, alpha, out4, step_dev, lr, beta1, beta2,
-                       hyper_ws);
+                       kl_parts, kl_scale, pair, pair_parts, w_sim, w_dis, beta, alpha, out4, step_dev, lr, lr_dev, beta1,
+                       beta2, hyper_ws);
     RBVAE_CHECK_LAUNCH("combine_losses");
     return RBVAE_OK;
 }
@@ -842,6 +844,34 @@ __global__ void adam_hyper_k(unsigned long long* __restrict__ step_dev, double l
     const double st = (double)s1;
     hyper[0] = (float)(lr / (1.0 - pow(b1, st)));
     hyper[1] = (float)sqrt(1.0 - pow(b2, st));
+}
+
+// Batch gather of the device-resident latent table: out[r] = table[plan[batch][r]], 16 bytes per lane.
+__global__ __launch_bounds__(256) void gather_frames_k(const float4* __restrict__ table, const long* __restrict__ plan,
+                                                       int rows, int n_batches,
+                                                       const unsigned long long* __restrict__ counter, long table_rows,
+                                                       int vec_per_row, float4* __restrict__ out) {
+    const int r = blockIdx.y;
+    const long b = counter ? (long)(counter[0] % (unsigned long long)n_batches) : 0;
+    long src = plan[b * rows + r];
+    if (src < 0 || src >= table_rows) src = 0;       // set_data() validated the plan; never read outside the table
+    const float4* s = table + src * vec_per_row;
+    float4* d = out + (long)r * vec_per_row;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < vec_per_row; i += gridDim.x * 256) d[i] = s[i];
+}
+
+int rbvae_gather_frames(const float* table, long table_rows, const long* plan, int rows, int n_batches,
+                        const unsigned long long* counter_dev, long frame_elems, float* out, void* stream) {
+    RBVAE_CHECK_ARG(table && plan && out && rows > 0 && n_batches > 0 && table_rows > 0, "gather_frames: bad arguments");
+    RBVAE_CHECK_ARG(frame_elems > 0 && frame_elems % 4 == 0 && frame_elems / 4 < (1l << 31),
+                    "gather_frames: frame of %ld floats (must be a multiple of 4)", frame_elems);
+    RBVAE_CHECK_ARG(((uintptr_t)table | (uintptr_t)out) % 16 == 0, "gather_frames: pointers must be 16-byte aligned");
+    const int vec = (int)(frame_elems / 4);
+    const int gx = vec >= 4096 ? 8 : (vec >= 1024 ? 4 : 1);
+    hipLaunchKernelGGL(gather_frames_k, dim3(gx, rows), dim3(256), 0, (hipStream_t)stream, (const float4*)table, plan,
+                       rows, n_batches, counter_dev, table_rows, vec, (float4*)out);
+    RBVAE_CHECK_LAUNCH("gather_frames");
+    return RBVAE_OK;
 }
 
 int rbvae_adam_step(float* w, const float* g, float* m, float* v, long n, double lr, double beta1, double beta2,

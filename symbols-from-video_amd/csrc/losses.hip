@@ -62,10 +62,11 @@ __global__ __launch_bounds__(RED_THREADS) void binarize_kl_fwd_k(
 // many-workgroup form: one element per thread, per-block partial KL sums (fixed order inside the block)
 __global__ __launch_bounds__(256) void binarize_kl_fwd_parts_k(
     const float* __restrict__ h, const float* __restrict__ U, float* __restrict__ y_soft,
-    float* __restrict__ z, float* __restrict__ kl_parts, int n, float tau, float ratio,
-    float neps, int hard, float lp, float l1p, float keps, int clamp, unsigned long long seed,
+    float* __restrict__ z, float* __restrict__ kl_parts, int n, float tau, const float* __restrict__ tau_dev,
+    float ratio, float neps, int hard, float lp, float l1p, float keps, int clamp, unsigned long long seed,
     const unsigned long long* __restrict__ seed_dev) {
     __shared__ float red[4];
+    if (tau_dev) tau = tau_dev[0];
     const int i = blockIdx.x * 256 + threadIdx.x;
     float acc = 0.f;
     if (i < n) {
@@ -86,9 +87,10 @@ __global__ __launch_bounds__(256) void binarize_kl_fwd_parts_k(
 
 __global__ void binarize_kl_bwd_k(const float* __restrict__ g_z, const float* __restrict__ y_soft,
                                   const float* __restrict__ z, float* __restrict__ dh, int accumulate,
-                                  int n, int rows, float tau, float klw, const float* __restrict__ gs,
-                                  float lp, float l1p, float keps, int clamp) {
+                                  int n, int rows, float tau, const float* __restrict__ tau_dev, float klw,
+                                  const float* __restrict__ gs, float lp, float l1p, float keps, int clamp) {
     __builtin_amdgcn_s_setprio(3);               // sits between the two LSTM backward launches of the chain
+    if (tau_dev) tau = tau_dev[0];
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     float w = klw / (float)rows;
@@ -454,28 +456,28 @@ int rbvae_binarize_kl_fwd(const float* h, const float* U, float* y_soft, float* 
 int rbvae_binarize_kl_nparts(int rows, int L) { return cdiv((long)rows * L, 256); }
 
 int rbvae_binarize_kl_fwd_parts(const float* h, const float* U, float* y_soft, float* z, float* kl_parts, int rows,
-                                int L, float tau, float noise_ratio, float noise_eps, int hard, float kl_p,
-                                float kl_eps, int kl_clamp, unsigned long long seed,
+                                int L, float tau, const float* tau_dev, float noise_ratio, float noise_eps, int hard,
+                                float kl_p, float kl_eps, int kl_clamp, unsigned long long seed,
                                 const unsigned long long* seed_dev, void* stream) {
     RBVAE_CHECK_ARG(h && y_soft && z, "binarize_kl_fwd_parts: null pointer");
-    RBVAE_CHECK_ARG(rows > 0 && L > 0 && tau > 0.f, "binarize_kl_fwd_parts: rows=%d L=%d tau=%g", rows, L, tau);
+    RBVAE_CHECK_ARG(rows > 0 && L > 0 && (tau_dev || tau > 0.f), "binarize_kl_fwd_parts: rows=%d L=%d tau=%g", rows, L, tau);
     RBVAE_CHECK_ARG(!kl_parts || (kl_p > 0.f && kl_p < 1.f), "binarize_kl_fwd_parts: kl_p=%g outside (0,1)", kl_p);
     const int n = rows * L;
     hipLaunchKernelGGL(binarize_kl_fwd_parts_k, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, h, U, y_soft, z,
-                       kl_parts, n, tau, noise_ratio, noise_eps, hard, logf(kl_p), logf(1.0f - kl_p), kl_eps,
+                       kl_parts, n, tau, tau_dev, noise_ratio, noise_eps, hard, logf(kl_p), logf(1.0f - kl_p), kl_eps,
                        kl_clamp, seed, seed_dev);
     RBVAE_CHECK_LAUNCH("binarize_kl_fwd_parts");
     return RBVAE_OK;
 }
 
 int rbvae_binarize_kl_bwd(const float* g_z, const float* y_soft, const float* z, float* dh, int accumulate,
-                          int rows, int L, float tau, float kl_weight, const float* gscale_dev, float kl_p,
-                          float kl_eps, int kl_clamp, void* stream) {
+                          int rows, int L, float tau, const float* tau_dev, float kl_weight, const float* gscale_dev,
+                          float kl_p, float kl_eps, int kl_clamp, void* stream) {
     RBVAE_CHECK_ARG(y_soft && z && dh, "binarize_kl_bwd: null pointer");
-    RBVAE_CHECK_ARG(rows > 0 && L > 0 && tau > 0.f, "binarize_kl_bwd: rows=%d L=%d tau=%g", rows, L, tau);
+    RBVAE_CHECK_ARG(rows > 0 && L > 0 && (tau_dev || tau > 0.f), "binarize_kl_bwd: rows=%d L=%d tau=%g", rows, L, tau);
     const int n = rows * L;
     hipLaunchKernelGGL(binarize_kl_bwd_k, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, g_z, y_soft, z,
-                       dh, accumulate, n, rows, tau, kl_weight, gscale_dev, logf(kl_p), logf(1.0f - kl_p),
+                       dh, accumulate, n, rows, tau, tau_dev, kl_weight, gscale_dev, logf(kl_p), logf(1.0f - kl_p),
                        kl_eps, kl_clamp);
     RBVAE_CHECK_LAUNCH("binarize_kl_bwd");
     return RBVAE_OK;

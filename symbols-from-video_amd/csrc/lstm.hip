@@ -372,7 +372,8 @@ struct PairArgs {
     float *hs_d, *hp_d, *acts_d, *cs_d;          // decoder stack: slot 0 receives z
     const float* in_parts; int nparts; long part_stride;     // encoder input as K-split slabs (or null)
     const float* U; float* y_soft; float* kl_parts;          // uniform noise (null: counter hash), y, per-sequence KL sums
-    float tau, ratio, neps, lp, l1p, keps; int hard, clamp;
+    float tau; const float* tau_dev;                         // temperature by value, or (when set) from a device float
+    float ratio, neps, lp, l1p, keps; int hard, clamp;
     unsigned long long seed; const unsigned long long* seed_dev;
     void* cast_out; int cast_bf16, cast_ld;                   // decoder top layer once more, cast / padded
     int S, T, L, layers, G;
@@ -383,6 +384,7 @@ __global__ __launch_bounds__(1024) void lstm_pair_fwd_k(const PairArgs p) {
     RBVAE_RAISE_PRIO();
     const int L = EXACT ? LMAX : p.L;
     const int T = p.T, S = p.S, layers = p.layers, G = p.G;
+    const float inv_tau_src = p.tau_dev ? p.tau_dev[0] : p.tau;   // uniform: one scalar load at the top of the kernel
     extern __shared__ __attribute__((aligned(16))) float sm[];
     float* hbuf = sm;                                    // [2][layers+1][T][L]: stack, slot, time
     float* gates = hbuf + 2 * (layers + 1) * T * L;      // [2*layers][4L] activated gates
@@ -499,7 +501,7 @@ __global__ __launch_bounds__(1024) void lstm_pair_fwd_k(const PairArgs p) {
             if (q == layers - 1) {
                 // binary_concrete_logits on the encoder's output (percep_RBVAE_model.py:17-44): z feeds the decoder stack
                 const long e = ((long)s * T + t) * L + j;
-                const float y = sigmoidf_((h + nbuf[t * L + j]) / p.tau);
+                const float y = sigmoidf_((h + nbuf[t * L + j]) / inv_tau_src);
                 const float zz = p.hard ? (y > 0.5f ? 1.0f : 0.0f) : y;
                 p.y_soft[e] = y;
                 p.hs_d[e] = zz;
@@ -526,7 +528,8 @@ __global__ __launch_bounds__(1024) void lstm_pair_fwd_k(const PairArgs p) {
 //   g_top = g_hs + (gz + klw * dKL/dz(z)) * y (1 - y) / tau      (straight-through: the same with hard codes)
 struct BinBwd {
     const float *gz, *y, *z, *g_hs;      // gz: gradient of the codes (decoder stack's input gradient); g_hs may be null
-    float tau, klw, lp, l1p, keps;
+    float tau; const float* tau_dev;     // temperature by value, or (when set) from a device float
+    float klw, lp, l1p, keps;
     int clamp, on;
 };
 
@@ -539,6 +542,7 @@ __global__ __launch_bounds__(1024) void lstm_bwd_wave_k(const float* __restrict_
                                                         float* __restrict__ dx_colsum, const BinBwd bb) {
     RBVAE_RAISE_PRIO();
     const int L = EXACT ? LMAX : L_;
+    const float bin_tau = (bb.on && bb.tau_dev) ? bb.tau_dev[0] : bb.tau;     // uniform scalar load, hoisted out of the staging loop
     extern __shared__ float sm[];
     float* gtop = sm;                              // [T][L]
     float* sacts = gtop + T * L;                   // [layers][T][4L]
@@ -580,7 +584,7 @@ __global__ __launch_bounds__(1024) void lstm_bwd_wave_k(const float* __restrict_
                 const float hsv = bb.g_hs ? bb.g_hs[e] : 0.f;
                 float gg = g;
                 if (bb.klw != 0.f) gg += bb.klw * kl_elem_grad(zv, bb.lp, bb.l1p, bb.keps, bb.clamp);
-                gt = hsv + gg * yv * (1.0f - yv) / bb.tau;
+                gt = hsv + gg * yv * (1.0f - yv) / bin_tau;
             } else {
                 // plain, or K-split slabs (rbvae_skinny_linear_parts) summed in slab order, four loads in flight
                 const float* gp = g_top + e;
@@ -919,8 +923,8 @@ int rbvae_lstm_pair_fwd_ok(int T, int L, int layers) {
 int rbvae_lstm_pair_fwd(const float* wblk_enc, const float* wT_enc, const float* wblk_dec, const float* wT_dec,
                         float* hs_enc, float* hprev_enc, float* acts_enc, float* cs_enc, float* hs_dec,
                         float* hprev_dec, float* acts_dec, float* cs_dec, const float* in_parts, int nparts,
-                        long part_stride, const float* U, float* y_soft, float* kl_parts, float tau, float noise_ratio,
-                        float noise_eps, int hard, float kl_p, float kl_eps, int kl_clamp, unsigned long long seed,
+                        long part_stride, const float* U, float* y_soft, float* kl_parts, float tau, const float* tau_dev,
+                        float noise_ratio, float noise_eps, int hard, float kl_p, float kl_eps, int kl_clamp, unsigned long long seed,
                         const unsigned long long* seed_dev, void* cast_out, int cast_dtype, int cast_ld, int S, int T,
                         int L, int layers, void* stream) {
     RBVAE_CHECK_ARG(wblk_enc && wblk_dec && hs_enc && hs_dec && y_soft && S > 0 && T > 0 && L > 0 && layers > 0,
@@ -930,7 +934,7 @@ int rbvae_lstm_pair_fwd(const float* wblk_enc, const float* wT_enc, const float*
     RBVAE_CHECK_ARG((acts_enc == nullptr) == (cs_enc == nullptr) && (acts_enc == nullptr) == (hprev_enc == nullptr) &&
                     (acts_dec == nullptr) == (acts_enc == nullptr) && (cs_dec == nullptr) == (acts_enc == nullptr) &&
                     (hprev_dec == nullptr) == (acts_enc == nullptr), "lstm_pair_fwd: saved-state buffers must be given together");
-    RBVAE_CHECK_ARG(tau > 0.f && (!kl_parts || (kl_p > 0.f && kl_p < 1.f)), "lstm_pair_fwd: tau=%g kl_p=%g", tau, kl_p);
+    RBVAE_CHECK_ARG((tau_dev || tau > 0.f) && (!kl_parts || (kl_p > 0.f && kl_p < 1.f)), "lstm_pair_fwd: tau=%g kl_p=%g", tau, kl_p);
     RBVAE_CHECK_ARG(!in_parts || (nparts >= 1 && part_stride >= (long)S * T * L), "lstm_pair_fwd: bad slabs");
     RBVAE_CHECK_ARG(!cast_out || ((cast_dtype == RBVAE_F32 || cast_dtype == RBVAE_BF16) && cast_ld >= L),
                     "lstm_pair_fwd: cast output dtype %d ld %d", cast_dtype, cast_ld);
@@ -940,7 +944,7 @@ int rbvae_lstm_pair_fwd(const float* wblk_enc, const float* wT_enc, const float*
     a.hs_d = hs_dec; a.hp_d = hprev_dec; a.acts_d = acts_dec; a.cs_d = cs_dec;
     a.in_parts = in_parts; a.nparts = nparts; a.part_stride = part_stride;
     a.U = U; a.y_soft = y_soft; a.kl_parts = kl_parts;
-    a.tau = tau; a.ratio = noise_ratio; a.neps = noise_eps; a.lp = kl_parts ? logf(kl_p) : 0.f;
+    a.tau = tau; a.tau_dev = tau_dev; a.ratio = noise_ratio; a.neps = noise_eps; a.lp = kl_parts ? logf(kl_p) : 0.f;
     a.l1p = kl_parts ? logf(1.0f - kl_p) : 0.f; a.keps = kl_eps; a.hard = hard; a.clamp = kl_clamp;
     a.seed = seed; a.seed_dev = seed_dev;
     a.cast_out = cast_out; a.cast_bf16 = cast_dtype == RBVAE_BF16; a.cast_ld = cast_ld;
@@ -1006,13 +1010,13 @@ int rbvae_lstm_bwd_ex(const float* wblk, const float* acts, const float* cs, con
 }
 
 int rbvae_lstm_bwd_bin(const float* wblk, const float* acts, const float* cs, const float* g_z, const float* y_soft,
-                       const float* z, const float* g_hs, float tau, float kl_weight, float kl_p, float kl_eps,
-                       int kl_clamp, float* dG, float* dx, void* cast_out, int cast_dtype, int cast_ld, float* dx_colsum,
+                       const float* z, const float* g_hs, float tau, const float* tau_dev, float kl_weight, float kl_p,
+                       float kl_eps, int kl_clamp, float* dG, float* dx, void* cast_out, int cast_dtype, int cast_ld, float* dx_colsum,
                        int S, int T, int L, int layers, void* stream) {
-    RBVAE_CHECK_ARG(g_z && y_soft && z && tau > 0.f, "lstm_bwd_bin: bad arguments");
+    RBVAE_CHECK_ARG(g_z && y_soft && z && (tau_dev || tau > 0.f), "lstm_bwd_bin: bad arguments");
     RBVAE_CHECK_ARG(kl_weight == 0.f || (kl_p > 0.f && kl_p < 1.f), "lstm_bwd_bin: kl_p=%g outside (0,1)", kl_p);
     BinBwd bb;
-    bb.gz = g_z; bb.y = y_soft; bb.z = z; bb.g_hs = g_hs; bb.tau = tau;
+    bb.gz = g_z; bb.y = y_soft; bb.z = z; bb.g_hs = g_hs; bb.tau = tau; bb.tau_dev = tau_dev;
     bb.klw = kl_weight / (float)((long)S * T);
     bb.lp = kl_weight != 0.f ? logf(kl_p) : 0.f; bb.l1p = kl_weight != 0.f ? logf(1.0f - kl_p) : 0.f;
     bb.keps = kl_eps; bb.clamp = kl_clamp; bb.on = 1;

@@ -28,6 +28,7 @@ struct WgArgs {
     const unsigned char* In;   // [*][ldi] T
     float* dW;                 // [ksplit][Co][taps][Ci] f32
     const int* idx;            // [taps][P] row of In per (tap, pixel), -1 = zero row; null = identity
+    int in_rows;               // rows of In: indices outside [0, in_rows) read the zero row
     const unsigned char* zero; // >= 16 zero bytes
     int P, Co, Ci, ldy, ldi, taps, ksplit, Pper;
     int xcd_order;             // 1: workgroup id -> (K-slice, tile) so that one XCD's workgroups cover <= 2 K-slices
@@ -138,7 +139,13 @@ __global__ __launch_bounds__(512, WG_NS == 2 ? 2 : 1) void wgrad_gemm_k(const Wg
     {
         const int* idx = p.idx ? p.idx + (size_t)tap * p.P + pbeg : nullptr;
         const int padded = nsteps * WG_BK;
-        for (int i = tid; i < padded; i += 512) s_idx[i] = i < npix ? (idx ? idx[i] : pbeg + i) : -1;
+        // an index outside [0, in_rows) reads the zero row: a table that is stale, half-built or built for another shape
+        // gives wrong sums (the parity tests see those), never an out-of-bounds access
+        for (int i = tid; i < padded; i += 512) {
+            int r = i < npix ? (idx ? idx[i] : pbeg + i) : -1;
+            if ((unsigned)r >= (unsigned)p.in_rows) r = -1;
+            s_idx[i] = r;
+        }
     }
     __syncthreads();
     WG_STAMP(1);
@@ -461,12 +468,14 @@ static unsigned long long* g_wg_stamps = nullptr;
 
 extern "C" {
 
-/* debug (stamped builds only: -DWG_STAMPS=1): later rbvae_wgrad_gemm launches write phase stamps into buf */
+#if WG_STAMPS
+/* stamped builds only (include/rbvae_dbg.h): later rbvae_wgrad_gemm launches write phase stamps into buf */
 int rbvae_dbg_wg_stamps(unsigned long long* buf, void* stream) {
     (void)stream;
     g_wg_stamps = buf;
     return RBVAE_OK;
 }
+#endif
 
 int rbvae_conv_gather_index(int* idx, int Nimg, int IH, int IW, int OH, int OW, int KH, int KW, int stride,
                             int pad, void* stream) {
@@ -481,9 +490,10 @@ int rbvae_conv_gather_index(int* idx, int Nimg, int IH, int IW, int OH, int OW, 
 }
 
 int rbvae_wgrad_gemm(int dtype, const void* Dy, const void* In, float* dW_slabs, const int* idx,
-                     const void* zero_page, int P, int Co, int Ci, int ldy, int ldi, int taps, int ksplit,
+                     const void* zero_page, int P, int in_rows, int Co, int Ci, int ldy, int ldi, int taps, int ksplit,
                      void* stream) {
     RBVAE_CHECK_ARG(Dy && In && dW_slabs && zero_page, "wgrad_gemm: null pointer");
+    RBVAE_CHECK_ARG(in_rows > 0 && (idx || in_rows >= P), "wgrad_gemm: in_rows=%d (P=%d)", in_rows, P);
     RBVAE_CHECK_ARG(dtype == RBVAE_F32 || dtype == RBVAE_BF16, "wgrad_gemm: dtype %d", dtype);
     const int ES = dtype == RBVAE_F32 ? 4 : 2;
     RBVAE_CHECK_ARG(P > 0 && Co > 0 && Ci > 0 && taps > 0 && ksplit > 0, "wgrad_gemm: bad sizes");
@@ -493,7 +503,7 @@ int rbvae_wgrad_gemm(int dtype, const void* Dy, const void* In, float* dW_slabs,
     RBVAE_CHECK_ARG(((uintptr_t)Dy | (uintptr_t)In | (uintptr_t)dW_slabs | (uintptr_t)zero_page) % 16 == 0,
                     "wgrad_gemm: pointers must be 16-byte aligned");
     WgArgs a;
-    a.Dy = (const unsigned char*)Dy; a.In = (const unsigned char*)In; a.dW = dW_slabs; a.idx = idx;
+    a.Dy = (const unsigned char*)Dy; a.In = (const unsigned char*)In; a.dW = dW_slabs; a.idx = idx; a.in_rows = in_rows;
     a.zero = (const unsigned char*)zero_page;
     a.P = P; a.Co = Co; a.Ci = Ci; a.ldy = ldy; a.ldi = ldi; a.taps = taps; a.ksplit = ksplit;
     a.Pper = ((cdiv(P, ksplit) + 63) / 64) * 64;

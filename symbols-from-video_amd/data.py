@@ -147,6 +147,17 @@ class DeviceStatePairDataset:
         torch.index_select(self.table, 0, rows.reshape(-1), out=out.view(-1, *self.table.shape[1:]))
         return out
 
+    def plan(self, order, batch_size: int) -> torch.Tensor:
+        """An epoch's full batches laid out in advance: [n_batches, B, 2, T] table rows (int64, on the device) for the
+        item order `order` (e.g. a torch.randperm of len(self), the DataLoader's shuffle).  The ragged last batch of
+        len(order) % batch_size items is not in the plan (fetch it with batch()).  FusedTrainer.set_data(table, plan)
+        trains from it without any host work per step."""
+        ii = torch.as_tensor(order, dtype=torch.long, device=self.device)
+        nb = ii.numel() // batch_size
+        if nb == 0:
+            raise ValueError(f"{ii.numel()} items do not fill one batch of {batch_size}")
+        return self.index[ii[:nb * batch_size]].reshape(nb, batch_size, 2, self.num_states)
+
     def __getitem__(self, idx) -> torch.Tensor:
         return self.batch([idx])[0]
 

@@ -182,7 +182,7 @@ class JobList:
 
 class Saved:
     """Activations one forward call keeps for its backward."""
-    __slots__ = ("N", "S", "T", "hw", "train", "tau", "hard", "col1", "a1", "a2", "a3", "e", "hs_enc", "hp_enc",
+    __slots__ = ("N", "S", "T", "hw", "train", "tau", "tau_dev", "hard", "col1", "a1", "a2", "a3", "e", "hs_enc", "hp_enc",
                  "acts_enc", "cs_enc", "y", "z", "hs_dec", "hp_dec", "acts_dec", "cs_dec", "ds_pad", "f", "d1", "d2",
                  "xr", "gate_scale", "dpre3", "b3_parts")
 
@@ -424,13 +424,29 @@ class Engine:
                float(scale), int(seed), seed_dev, ws)
 
     def _conv_idx(self, nimg, ih, iw, oh, ow):
+        """Gather-index table of a stride-2 convolution (cached per shape, read by weight-gradient GEMMs on ANY
+        stream).  A table is complete in device memory before it enters the cache: its kernel is followed by a
+        host-side stream synchronisation (first use of a shape only), so no consumer on another stream can ever
+        read a table whose kernel it has not waited for.  During graph capture nothing may be built: the trainer's
+        eager warm-up steps (or prepare()) have filled the cache by then."""
         key = (nimg, ih, iw, oh, ow)
         t = self._idx_cache.get(key)
         if t is None:
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("gather-index table missing during graph capture: run Engine.prepare(N) or one "
+                                   "eager step of this shape first")
             t = torch.empty(self.k * self.k * nimg * oh * ow, dtype=torch.int32, device=self.device)
             L.call("rbvae_conv_gather_index", t, nimg, ih, iw, oh, ow, self.k, self.k, 2, 1)
+            torch.cuda.current_stream().synchronize()
             self._idx_cache[key] = t
         return t
+
+    def prepare(self, N: int):
+        """Build every device table a pass over N frames reads from more than one stream (the gather-index tables
+        of the weight-gradient GEMMs), on the current stream, before any side stream is forked."""
+        (h1, w1), (h2, w2), (h3, w3) = self.g1, self.g2, self.g3
+        self._conv_idx(N, h1, w1, h2, w2)
+        self._conv_idx(N, h2, w2, h3, w3)
 
     def _wgrad(self, Dy, In, idx, P, Co, Ci, ldy, ldi, taps, out, dims, strides, tag=None):
         """wgrad GEMM into K-slice slabs; their fixed-order reduction into the torch layout is a job."""
@@ -443,7 +459,7 @@ class Engine:
             ks = self._ks_force                 # RBVAE_WG_KS: experiment switch (K-slices of the multi-tile weight gradients)
         ks = max(ks, -(-P // 4096))            # the kernel keeps a K-slice's gather indices in LDS (<= 4096)
         slabs = self._buf(("slabs", tag), ks * Co * taps * Ci)
-        L.call("rbvae_wgrad_gemm", self.dt, Dy, In, slabs, idx, self.zero, P, Co, Ci, ldy, ldi, taps, ks)
+        L.call("rbvae_wgrad_gemm", self.dt, Dy, In, slabs, idx, self.zero, P, In.numel() // ldi, Co, Ci, ldy, ldi, taps, ks)
         self._jobs.add(JOB_PERMUTE, slabs, out, dims, strides, nslab=ks, slab=Co * taps * Ci)
 
     def _colsum(self, dt, X, P, C, ld, out, tag=None):
@@ -505,8 +521,10 @@ class Engine:
                 seed: int = 0, need_grad: bool = True, encode_only: bool = False,
                 target: Optional[torch.Tensor] = None, recon_gscale: float = 0.0, kl_p: Optional[float] = None,
                 after_hs=None, defer_losses: bool = False, repack: bool = False,
-                frame_map: Optional[Tuple[int, int, int, int, int]] = None):
+                frame_map: Optional[Tuple[int, int, int, int, int]] = None, tau_dev: Optional[torch.Tensor] = None):
         """x: [S,T,C,H,W] f32 NCHW frames; U: [S*T, L] uniform noise.
+        tau_dev: optional device float the kernels read the temperature from instead of `tau` (graph-replayed
+        steps under an annealing schedule; backward() reads the same tensor).
         masks: explicit dropout keep-masks (u8, NHWC rows) for the 4 dropout sites, else a counter hash.
         target/recon_gscale: fuse recon_loss and its gradient into the last kernel (trainer path).
         defer_losses: leave recon_loss and the KL mean as per-block partial sums ("sse": (ws, nparts, 1/n),
@@ -540,6 +558,7 @@ class Engine:
 
         sv = Saved()
         sv.N, sv.S, sv.T, sv.hw, sv.train, sv.tau, sv.hard = N, S, T, (H, W), train, tau, hard
+        sv.tau_dev = tau_dev
         sv.gate_scale = dscale
         # encoder CNN
         if repack:
@@ -609,7 +628,7 @@ class Engine:
             sv.ds_pad = self._E(N, self.Lp)
             L.call("rbvae_lstm_pair_fwd", wenc, self.wT_enc, wdec, self.wT_dec, sv.hs_enc, sv.hp_enc, sv.acts_enc,
                    sv.cs_enc, sv.hs_dec, sv.hp_dec, sv.acts_dec, sv.cs_dec, e_parts, self.fc_split, N * Ld, U, sv.y,
-                   parts, float(tau), float(r), v.eps, int(hard), float(kl_p if kl_p is not None else 0.5), 1e-8, 1,
+                   parts, float(tau), tau_dev, float(r), v.eps, int(hard), float(kl_p if kl_p is not None else 0.5), 1e-8, 1,
                    int(seed) * 8 + 5, self.seed_dev, sv.ds_pad, self.dt, self.Lp, S, T, Ld, nl)
             if kl_p is not None and not defer_losses:
                 kl = (parts.sum() * (1.0 / N)).reshape(1)
@@ -638,7 +657,7 @@ class Engine:
             if defer_losses and kl_p is not None:
                 nkl = L.query("rbvae_binarize_kl_nparts", N, Ld)
                 parts = self._E(nkl, dtype=torch.float32)
-                L.call("rbvae_binarize_kl_fwd_parts", hs, U, sv.y, sv.z, parts, N, Ld, float(tau), float(r), v.eps,
+                L.call("rbvae_binarize_kl_fwd_parts", hs, U, sv.y, sv.z, parts, N, Ld, float(tau), tau_dev, float(r), v.eps,
                        int(hard), float(kl_p), 1e-8, 1, int(seed) * 8 + 5, self.seed_dev)
                 kl = (parts, nkl, 1.0 / N)
             else:
@@ -830,11 +849,9 @@ class Engine:
             self._wgrad(df, sv.ds_pad, None, N, self.F3, self.Lp, self.F3, self.Lp, 1, G("decoder_cnn.fc.weight"),
                         (c3, g3, Ld), (self.Lp, c3 * self.Lp, 1), tag=(N, "Wdfc"))
 
-        # The gather-index tables both streams' weight-gradient GEMMs read are built here, on the main stream before
-        # the fork (they are cached: built by whichever stream asked first, the other stream could otherwise read
-        # a table whose kernel it never waited for)
-        self._conv_idx(N, h1, w1, h2, w2)
-        self._conv_idx(N, h2, w2, h3, w3)
+        # The gather-index tables both streams' weight-gradient GEMMs read: complete before they enter the cache
+        # (_conv_idx), built here on the main stream before the fork
+        self.prepare(N)
         self._fork(0, self.SIDE_DEC_WGRAD)
         # with a cut the reductions queued so far (decoder bias sums: their producers ran before the fork) go with the
         # decoder's early reduction, so that every decoder gradient is final at the cut
@@ -890,16 +907,16 @@ class Engine:
                 de_pad = tmp("de_pad", N, self.Lp)
                 de_sums = self._buf((N, "de_sums"), S * Ld)
                 L.call("rbvae_lstm_bwd_bin", wenc, sv.acts_enc, sv.cs_enc, gz, sv.y, sv.z,
-                       None if g_hs is None else g_hs.reshape(N, Ld).contiguous(), float(sv.tau), float(kl_weight),
+                       None if g_hs is None else g_hs.reshape(N, Ld).contiguous(), float(sv.tau), sv.tau_dev, float(kl_weight),
                        float(kl_p), 1e-8, 1, dGe, de, de_pad, self.dt, self.Lp, de_sums, S, T, Ld, nl)
             else:
                 if g_hs is not None and g_hs_inplace and g_hs.is_contiguous():
                     dh = g_hs.view(N, Ld)
-                    L.call("rbvae_binarize_kl_bwd", gz, sv.y, sv.z, dh, 1, N, Ld, float(sv.tau), float(kl_weight), None,
+                    L.call("rbvae_binarize_kl_bwd", gz, sv.y, sv.z, dh, 1, N, Ld, float(sv.tau), sv.tau_dev, float(kl_weight), None,
                            float(kl_p), 1e-8, 1)
                 else:
                     dh = tmp("dh", N, Ld, dtype=f32)
-                    L.call("rbvae_binarize_kl_bwd", gz, sv.y, sv.z, dh, 0, N, Ld, float(sv.tau), float(kl_weight), None,
+                    L.call("rbvae_binarize_kl_bwd", gz, sv.y, sv.z, dh, 0, N, Ld, float(sv.tau), sv.tau_dev, float(kl_weight), None,
                            float(kl_p), 1e-8, 1)
                     if g_hs is not None:
                         dh = dh + g_hs.reshape(N, Ld)
@@ -916,7 +933,7 @@ class Engine:
             # decoder stack input = encoder stack output
             dz = tmp("dz", N, Ld, dtype=f32)
             L.call("rbvae_lstm_bwd", wenc, sv.acts_enc, sv.cs_enc, d_in_dec, dGe, dz, S, T, Ld, nl)
-            L.call("rbvae_binarize_kl_bwd", dz, sv.y, sv.z, de, 0, N, Ld, float(sv.tau), 0.0, None, 0.5, 1e-10, 0)
+            L.call("rbvae_binarize_kl_bwd", dz, sv.y, sv.z, de, 0, N, Ld, float(sv.tau), None, 0.0, None, 0.5, 1e-10, 0)
             if g_e is not None:
                 de = de + g_e.reshape(N, Ld)
         # LSTM weight gradients (few workgroups, latency bound) ride the side stream beside the encoder CNN backward

@@ -58,7 +58,7 @@ class _BinarizeFn(torch.autograd.Function):
         y, z = ctx.saved_tensors
         gz = g.reshape(y.shape).float().contiguous()
         dh = torch.empty_like(y)
-        L.call("rbvae_binarize_kl_bwd", gz, y, z, dh, 0, y.shape[0], y.shape[1], ctx.tau, 0.0, None, 0.5, 1e-8, 1)
+        L.call("rbvae_binarize_kl_bwd", gz, y, z, dh, 0, y.shape[0], y.shape[1], ctx.tau, None, 0.0, None, 0.5, 1e-8, 1)
         return dh.reshape(g.shape), None, None, None, None, None
 
 
@@ -250,14 +250,20 @@ class Seq2SeqBinaryVAE(nn.Module):
         return _ForwardFn.apply(self, x.float(), self._noise(x, u), float(temperature), bool(hard),
                                 float(noise_ratio), masks, need, *params)
 
-    def encode(self, x, temperature=0.5, hard=False, noise_ratio=0.1, u=None):
-        """percep_RBVAE_model.py:172-191 -> z_seq [B,T,L] (no gradient: the callers are eval loops)."""
+    def encode(self, x, temperature=0.5, hard=False, noise_ratio=0.1, u=None, dropout_masks=None):
+        """percep_RBVAE_model.py:172-191 -> z_seq [B,T,L] (no gradient: the callers are eval loops).
+        Like the reference, the encoder CNN runs in the module's current mode: after .train() its two Dropout
+        layers are live (dropout_masks: optional explicit keep-masks for those two sites)."""
         self._check(x)
         if VARIANTS[self.variant].simple_order:
             raise AttributeError("the simple variant has no encode() (simple_RBVAE_model.py)")
         eng = self._engine_for(x)
         self._pack()
+        masks = None
+        if dropout_masks is not None and self.training:
+            masks = [_mask_to_rows(m.to(x.device)) for m in dropout_masks]
         with torch.no_grad():
             out = eng.forward(self._flat, x.float(), self._noise(x, u), float(temperature), bool(hard),
-                              float(noise_ratio), False, None, need_grad=False, encode_only=True)
+                              float(noise_ratio), bool(self.training), masks, seed=self._next_seed(),
+                              need_grad=False, encode_only=True)
         return out["z"].clone()

@@ -8,34 +8,66 @@ models/triplet_RBVAE/triplet_RBVAE_train.py:443-478) as one hand-scheduled pass.
   binarise kernel, the pairwise term in one launch, hand-scheduled backward,
   gradient all-reduce (RCCL) when world_size > 1, fused Adam on the flat buffer.
 
-The step is captured into HIP graphs (forward+backward; Adam+repack) so a step costs
-two graph launches and, across ranks, one all-reduce between them.
+The step is captured into HIP graphs (one graph on a single GPU; across ranks the graphs are cut where a
+gradient bucket is final and the all-reduces run between / beside them).  Temperature and learning rate are
+read by the kernels from device scalars, so ONE graph per batch shape serves the whole annealing schedule
+(percep_RBVAE_train.py:424-437).
 """
 from __future__ import annotations
 
 from typing import Dict, Optional
 
 import torch
+import torch.distributed as dist
 
 from . import _lib as L
 from .engine import VARIANTS
 
 
+def noise_key(seed: int, rank: int) -> int:
+    """Key of a rank's dropout / Binary-Concrete noise streams: splitmix64 of (seed, rank), 58 bits (the engine
+    appends 3 bits of site index).  Different ranks and different seeds draw unrelated streams; the device step
+    counter is mixed in by the kernels, so a resumed run continues the stream of its seed."""
+    m = (1 << 64) - 1
+    x = (int(seed) * 0x9E3779B97F4A7C15 + (int(rank) + 1) * 0xD1B54A32D192ED03) & m
+    x ^= x >> 30
+    x = (x * 0xBF58476D1CE4E5B9) & m
+    x ^= x >> 27
+    x = (x * 0x94D049BB133111EB) & m
+    x ^= x >> 31
+    return x >> 6
+
+
 class FusedTrainer:
     def __init__(self, model, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, alpha=0.1, beta_kl=0.1, bernoulli_p=0.5,
-                 noise_ratio=0.1, margin=1.0, device_noise=True, use_graph=True, process_group=None):
+                 noise_ratio=0.1, margin=1.0, device_noise=True, use_graph=True, process_group=None, seed=None,
+                 pair_loss=None):
+        """seed: key of the device-side noise (dropout masks, Binary-Concrete uniforms); default torch.initial_seed(),
+        so torch.manual_seed() before constructing the trainer makes a run reproducible.  The rank is mixed in:
+        every data-parallel rank draws its own streams.
+        pair_loss: "contrast" (percep_RBVAE_train.py:534-543) or "triplet" (triplet_RBVAE_train.py:461-468);
+        default: the model variant's own trainer.  Independent of the conv widths (BASELINE configs[4]: the
+        percep-shaped network on LDM latents with the triplet term)."""
         self.model = model
         self.v = VARIANTS[model.variant]
         if self.v.simple_order:
             raise ValueError("FusedTrainer covers the percep / contrastive / triplet trainers")
+        if pair_loss is None:
+            pair_loss = "triplet" if model.variant == "triplet" else "contrast"
+        if pair_loss not in ("contrast", "triplet"):
+            raise ValueError("pair_loss must be 'contrast' or 'triplet'")
+        self.pair_loss = pair_loss
         self.lr, self.betas, self.eps = lr, betas, eps
         self.alpha, self.beta_kl, self.p, self.r, self.margin = alpha, beta_kl, bernoulli_p, noise_ratio, margin
         self.device_noise = device_noise
         self.use_graph = use_graph
         self.pg = process_group
-        self.world = 1
-        if process_group is not None or (torch.distributed.is_available() and torch.distributed.is_initialized()):
-            self.world = torch.distributed.get_world_size(process_group)
+        self.world, self.rank = 1, 0
+        if process_group is not None or (dist.is_available() and dist.is_initialized()):
+            self.world = dist.get_world_size(process_group)
+            self.rank = dist.get_rank(process_group)
+        self.seed = int(torch.initial_seed() if seed is None else seed)
+        self._noise_key = noise_key(self.seed, self.rank)
         dev = model._flat.device
         if dev.type != "cuda":
             raise RuntimeError("FusedTrainer: move the model to the GPU first (there is no CPU fallback)")
@@ -46,11 +78,17 @@ class FusedTrainer:
         self.vv = torch.zeros(n, device=dev)
         self.step_dev = torch.zeros(1, dtype=torch.int64, device=dev)       # device step counter
         self.hyper = torch.zeros(2, device=dev)
+        # schedule scalars the captured kernels read: temperature (f32) and learning rate (f64)
+        self.tau_dev = torch.ones(1, device=dev)
+        self.lr_dev = torch.full((1,), float(lr), dtype=torch.float64, device=dev)
+        self._tau_host, self._lr_host = 1.0, float(lr)
         self.losses = torch.zeros(4, device=dev)                               # total, recon, kl, pair
         self._pair = torch.zeros(1, device=dev)
         self.steps = 0
         self._graphs: Dict = {}
+        self._pool = None             # one memory pool shared by every captured graph of this trainer
         self._static: Dict = {}
+        self._data = None             # (table, plan_dev [n_batches, B*2*T], B, T): device-resident loader, see set_data()
         self.eng = None
         self.instrument = None       # optional callable(name, flops) -> context manager (bench roofline leg)
         import os
@@ -63,19 +101,19 @@ class FusedTrainer:
         self.fused_pair = os.environ.get("RBVAE_FUSED_PAIR", "1") == "1"
 
     # ---- the two halves of a step (plain launches; captured below) ------------------
-    def _fwd_bwd(self, x, U, tau, B, T, cut=None):
+    def _fwd_bwd(self, x, U, tau, B, T, cut=None, masks=None):
         eng, model = self.eng, self.model
         numel = x.numel()
         Ld = model.latent_dim
         g_hs = torch.empty(2 * B, T, Ld, device=self.dev)
         pair = self._pair
 
-        fused_pair = self.fused_pair and self.model.variant != "triplet"
+        fused_pair = self.fused_pair and self.pair_loss != "triplet"
         pair_parts = torch.empty(2 * L.query("rbvae_contrast_term_nparts", B, T), device=self.dev) if fused_pair else None
 
         def pair_term(hs):                   # [2B, T, L]
             h0, h1 = hs[:B], hs[B:]
-            if self.model.variant == "triplet":
+            if self.pair_loss == "triplet":
                 L.call("rbvae_triplet_term_fwd", h0, h1, B, T, Ld, float(self.margin), pair)
                 L.call("rbvae_triplet_term_bwd", h0, h1, B, T, Ld, float(self.margin), float(self.alpha), None,
                        g_hs[:B], g_hs[B:])
@@ -87,12 +125,18 @@ class FusedTrainer:
                 L.call("rbvae_contrast_term_fwd", h0, h1, B, T, Ld, pair)
                 L.call("rbvae_contrast_term_bwd", h0, h1, B, T, Ld, float(self.alpha), None, g_hs[:B], g_hs[B:])
 
+        if self._data is not None and self._data_active:
+            # the batch of this step: gathered from the HBM-resident table by the device step counter (inside the graph)
+            table, plan, _, _ = self._data
+            L.call("rbvae_gather_frames", table, table.shape[0], plan, plan.shape[1], plan.shape[0], self.step_dev,
+                   table[0].numel(), x)
         # dropout follows the module's mode like the reference (model.train() in train_one_epoch, :501)
         # x is the item batch [B, 2, T, C, H, W] as it is; frame (v, b, t) = sequence v*B + b, state t
         chw = numel // (2 * B * T)
-        out = eng.forward(model._flat, x.view(2 * B, T, *x.shape[3:]), U, tau, False, self.r, bool(model.training), None,
-                          seed=0, need_grad=True, target=x, recon_gscale=2.0 / numel, kl_p=self.p, after_hs=pair_term,
-                          defer_losses=True, repack=True, frame_map=(B * T, T, T * chw, 2 * T * chw, chw))
+        out = eng.forward(model._flat, x.view(2 * B, T, *x.shape[3:]), U, tau, False, self.r, bool(model.training), masks,
+                          seed=self._noise_key, need_grad=True, target=x, recon_gscale=2.0 / numel, kl_p=self.p,
+                          after_hs=pair_term, defer_losses=True, repack=True,
+                          frame_map=(B * T, T, T * chw, 2 * T * chw, chw), tau_dev=self.tau_dev)
         sse_ws, nparts, inv_n = out["sse"]
         kl_parts, nkl, kl_scale = out["kl"]
         b1, b2 = self.betas
@@ -105,8 +149,8 @@ class FusedTrainer:
             else:
                 pargs = (self._pair, 0, 0.0, 0.0)
             L.call("rbvae_combine_losses", sse_ws, nparts, inv_n, None, kl_parts, nkl, kl_scale, *pargs,
-                   float(self.beta_kl), float(self.alpha), self.losses, self.step_dev, float(self.lr), float(b1),
-                   float(b2), self.hyper)
+                   float(self.beta_kl), float(self.alpha), self.losses, self.step_dev, float(self.lr), self.lr_dev,
+                   float(b1), float(b2), self.hyper)
 
         eng.backward(model._flat, self.gflat, out["saved"], None, g_hs, None, kl_weight=self.beta_kl, kl_p=self.p,
                      g_hs_inplace=True, side_first=bookkeeping, cut=cut)
@@ -118,11 +162,22 @@ class FusedTrainer:
         # the packed bf16 copies are refreshed at the start of the next step (beside its first kernels)
 
     # ---- public --------------------------------------------------------------------
-    def step(self, item: torch.Tensor, temperature: float, U: Optional[torch.Tensor] = None):
-        """One optimiser step on item [B,2,T,C,H,W] (device tensor).  U: optional [2, B*T, L] uniform
+    def step(self, item: Optional[torch.Tensor], temperature: float, U: Optional[torch.Tensor] = None,
+             dropout_masks=None):
+        """One optimiser step on item [B,2,T,C,H,W] (device tensor), or on the next batch of set_data()'s plan when
+        item is None.  U: optional [2, B*T, L] uniform
         noise (view 0, view 1) -- default: device-side counter-hash noise (device_noise=True) or a host
-        torch.rand draw like the reference (device_noise=False).  Returns the device tensor
-        [total, recon, kl, pair] of this step (no host sync)."""
+        torch.rand draw like the reference (device_noise=False).
+        dropout_masks: optional explicit keep-masks [view][site] of shape [B*T, C, H, W] (torch layout) for the four
+        Dropout sites (reproducible parity runs; such a step runs eagerly, not from the captured graph).
+        Returns the device tensor [total, recon, kl, pair] of this step (no host sync)."""
+        from_data = item is None
+        if from_data:
+            if self._data is None:
+                raise ValueError("step(None, ...) needs set_data() first")
+            table, _, B, T = self._data
+            C, H, W = table.shape[1:]
+            item = self.input_buffer(B, T, C, H, W)
         if item.dim() != 6 or item.shape[1] != 2:
             raise ValueError(f"expected item of shape [B, 2, T, C, H, W], got {tuple(item.shape)}")
         B, _, T, C, H, W = item.shape
@@ -133,9 +188,12 @@ class FusedTrainer:
             self.eng = model._engine_for(item)
             self.eng.seed_dev = self.step_dev
         Ld = model.latent_dim
+        self._data_active = from_data
         if U is None and not self.device_noise:
             U = torch.rand((2, B * T, Ld)).to(item.device)
-        key = (B, T, float(temperature), U is not None)
+        # temperature / lr travel through device scalars: they are NOT part of the graph key
+        key = (B, T, U is not None, bool(model.training), from_data)
+        self._set_schedule(float(temperature))
         st = self._static.get(key[:2])
         if st is None:
             st = {"x": torch.empty(B, 2, T, C, H, W, device=self.dev),
@@ -146,8 +204,13 @@ class FusedTrainer:
         if U is not None:
             st["U"].copy_(U.reshape(2 * B * T, Ld))
         Uarg = st["U"] if U is not None else None
-        if not self.use_graph or self.instrument is not None:
-            self._fwd_bwd(st["x"], Uarg, float(temperature), B, T)
+        masks = None
+        if dropout_masks is not None and model.training:
+            from .model import _mask_to_rows
+            masks = [torch.cat([_mask_to_rows(dropout_masks[0][j].to(self.dev)),
+                                _mask_to_rows(dropout_masks[1][j].to(self.dev))]) for j in range(4)]
+        if not self.use_graph or self.instrument is not None or masks is not None:
+            self._fwd_bwd(st["x"], Uarg, float(temperature), B, T, masks=masks)
             self._allreduce()
             self._update()
         else:
@@ -159,9 +222,9 @@ class FusedTrainer:
             if len(g) == 3:
                 # tail (decoder CNN + LSTM gradients) on the collective's stream beside the encoder CNN's backward graph
                 tail, head = self._grad_buckets()
-                w = torch.distributed.all_reduce(tail, group=self.pg, async_op=True)
+                w = dist.all_reduce(tail, group=self.pg, async_op=True)
                 g[1].replay()
-                torch.distributed.all_reduce(head, group=self.pg)
+                dist.all_reduce(head, group=self.pg)
                 w.wait()
                 g[2].replay()
             elif g[1] is not None:
@@ -170,6 +233,117 @@ class FusedTrainer:
         self.steps += 1
         self.model._packed_version = None     # anything else that runs the model before the next step repacks first
         return self.losses
+
+    def validate(self, item: torch.Tensor, temperature: float, U: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """The reference's validation step on one batch (percep_RBVAE_train.py:590-635): dropout off, hard codes at the
+        given (final) temperature, total = (recon + beta*kl + alpha*pair) / (1 + alpha + beta).  No gradients, no
+        optimiser state touched.  item [B,2,T,C,H,W]; U optional [2, B*T, L] (default: a host torch.rand draw like
+        the reference's forward).  Returns a new device tensor [total, recon, kl, pair]."""
+        if item.dim() != 6 or item.shape[1] != 2:
+            raise ValueError(f"expected item of shape [B, 2, T, C, H, W], got {tuple(item.shape)}")
+        B, _, T, C, H, W = item.shape
+        if T < 2:
+            raise ZeroDivisionError("float division by zero")
+        model = self.model
+        if self.eng is None:
+            self.eng = model._engine_for(item)
+            self.eng.seed_dev = self.step_dev
+        eng, Ld = self.eng, model.latent_dim
+        if U is None:
+            U = torch.rand((2, B * T, Ld)).to(item.device)
+        U = U.reshape(2 * B * T, Ld).float().contiguous()
+        x = item.float().contiguous()
+        chw = C * H * W
+        model._pack()
+        with torch.no_grad():
+            out = eng.forward(model._flat, x.view(2 * B, T, C, H, W), U, float(temperature), True, self.r, False, None,
+                              seed=self._noise_key, need_grad=False, target=x, recon_gscale=0.0, kl_p=self.p,
+                              defer_losses=True, frame_map=(B * T, T, T * chw, 2 * T * chw, chw))
+            hs = out["hs"]
+            h0, h1 = hs[:B], hs[B:]
+            pair = torch.empty(1, device=self.dev)
+            if self.pair_loss == "triplet":
+                L.call("rbvae_triplet_term_fwd", h0, h1, B, T, Ld, float(self.margin), pair)
+            else:
+                L.call("rbvae_contrast_term_fwd", h0, h1, B, T, Ld, pair)
+            sse_ws, nparts, inv_n = out["sse"]
+            kl_parts, nkl, kl_scale = out["kl"]
+            res = torch.empty(4, device=self.dev)
+            L.call("rbvae_combine_losses", sse_ws, nparts, inv_n, None, kl_parts, nkl, kl_scale, pair, 0, 0.0, 0.0,
+                   float(self.beta_kl), float(self.alpha), res, None, 0.0, None, 0.0, 0.0, None)
+            res[0] /= 1.0 + float(self.alpha) + float(self.beta_kl)
+        return res
+
+    # ---- checkpoint state (percep_RBVAE_train.py:691-702 stores optimizer.state_dict()) -----------------
+    def state_dict(self) -> Dict:
+        """{"optimizer_state_dict": torch.optim.Adam-format state over the model's parameters in registration
+        order (loadable by a real torch.optim.Adam(model.parameters())), "seed", "steps"}."""
+        lay = self.model._layout
+        step = int(self.step_dev.item())
+        state = {}
+        if step > 0:
+            for i, n in enumerate(lay.names):
+                state[i] = {"step": torch.tensor(float(step)), "exp_avg": lay.view(self.m, n).clone(),
+                            "exp_avg_sq": lay.view(self.vv, n).clone()}
+        group = {"lr": float(self.lr), "betas": tuple(self.betas), "eps": float(self.eps), "weight_decay": 0,
+                 "amsgrad": False, "maximize": False, "foreach": None, "capturable": False, "differentiable": False,
+                 "fused": None, "decoupled_weight_decay": False, "params": list(range(len(lay.names)))}
+        return {"optimizer_state_dict": {"state": state, "param_groups": [group]}, "seed": self.seed,
+                "steps": self.steps}
+
+    def load_state_dict(self, sd: Dict):
+        """Accepts state_dict()'s output or a bare torch.optim.Adam state_dict (the reference's checkpoint entry)."""
+        opt = sd.get("optimizer_state_dict", sd)
+        lay = self.model._layout
+        groups = opt["param_groups"]
+        if len(groups) != 1 or len(groups[0]["params"]) != len(lay.names):
+            raise ValueError("optimizer state does not match this model's parameter list")
+        g = groups[0]
+        if g.get("weight_decay", 0) or g.get("amsgrad", False) or g.get("maximize", False):
+            raise ValueError("FusedTrainer implements plain Adam (no weight decay / amsgrad / maximize)")
+        self.lr, self.betas, self.eps = float(g["lr"]), tuple(g["betas"]), float(g["eps"])
+        state = opt["state"]
+        steps = {int(float(st["step"])) for st in state.values()}
+        if len(steps) > 1:
+            raise ValueError("per-parameter step counts differ; the fused optimiser keeps one")
+        self.m.zero_()
+        self.vv.zero_()
+        for i, n in enumerate(lay.names):
+            st = state.get(g["params"][i])
+            if st is not None:
+                lay.view(self.m, n).copy_(st["exp_avg"])
+                lay.view(self.vv, n).copy_(st["exp_avg_sq"])
+        self.step_dev.fill_(steps.pop() if steps else 0)
+        if "seed" in sd:
+            self.seed = int(sd["seed"])
+            self._noise_key = noise_key(self.seed, self.rank)
+            self._graphs.clear()          # the noise key is a by-value kernel argument of the captured launches
+        self.steps = int(sd.get("steps", int(self.step_dev.item())))
+
+    def set_data(self, table: torch.Tensor, plan: torch.Tensor):
+        """Device-resident data loading: `table` [F,C,H,W] f32 latents in HBM
+        (DeviceStatePairDataset.table), `plan` [n_batches, B, 2, T] int64 table rows -- an epoch's batches laid out in
+        advance (DeviceStatePairDataset.plan()).  step(None, tau) then trains on batch (steps so far) % n_batches,
+        gathered by a kernel inside the captured step: no host work and no separate copy of the batch per step.
+        A new plan of the same shape (next epoch's shuffle) is copied into the same device buffer: the graph stays."""
+        if table.dim() != 4 or plan.dim() != 4 or plan.shape[2] != 2:
+            raise ValueError("table must be [F,C,H,W], plan [n_batches,B,2,T]")
+        if table.dtype != torch.float32 or table.device != self.dev or not table.is_contiguous():
+            raise ValueError("table must be a contiguous f32 tensor on the trainer's device")
+        if table[0].numel() % 4:
+            raise ValueError("frame size must be a multiple of 4 floats")
+        plan = plan.to(torch.int64)
+        if plan.numel() == 0 or int(plan.min()) < 0 or int(plan.max()) >= table.shape[0]:
+            raise ValueError("plan is empty or holds rows outside the table")
+        nb, B, _, T = plan.shape
+        flat = plan.reshape(nb, B * 2 * T).to(self.dev).contiguous()
+        old = self._data
+        if old is not None and old[0].data_ptr() == table.data_ptr() and old[1].shape == flat.shape:
+            old[1].copy_(flat)
+        else:
+            self._data = (table, flat, B, T)
+            self._graphs = {k: g for k, g in self._graphs.items() if not k[4]}
+    _data_active = False
 
     def input_buffer(self, B: int, T: int, C: int, H: int, W: int) -> torch.Tensor:
         """The step's static input [B, 2, T, C, H, W] (the address the captured graphs read).  A data loader that
@@ -182,9 +356,21 @@ class FusedTrainer:
             self._static[(B, T)] = st
         return st["x"]
 
+    def _set_schedule(self, tau: float):
+        """Write the step's temperature / learning rate into the device scalars (stream-ordered fills, only when
+        the value changed: the reference updates tau every num_steps_to_update steps)."""
+        if tau <= 0.0:
+            raise ValueError(f"temperature must be positive, got {tau}")
+        if tau != self._tau_host:
+            self.tau_dev.fill_(tau)
+            self._tau_host = tau
+        if float(self.lr) != self._lr_host:
+            self.lr_dev.fill_(float(self.lr))
+            self._lr_host = float(self.lr)
+
     def _allreduce(self):
         if self.world > 1:
-            torch.distributed.all_reduce(self.gflat, group=self.pg)
+            dist.all_reduce(self.gflat, group=self.pg)
 
     def _grad_buckets(self):
         """(tail, head) views of the flat gradient: tail = decoder_cnn.* and both LSTM stacks (final at the backward
@@ -205,9 +391,12 @@ class FusedTrainer:
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
         g1, g2 = torch.cuda.CUDAGraph(), None
+        if self._pool is None:
+            self._pool = torch.cuda.graph_pool_handle()
+        pool = self._pool
         if self.world == 1 and self.one_graph:
             # no collective between backward and Adam: the whole step is one graph launch
-            with torch.cuda.graph(g1):
+            with torch.cuda.graph(g1, pool=pool):
                 self._fwd_bwd(x, U, tau, B, T)
                 self._update()
         elif self.world > 1 and self.ddp_overlap:
@@ -216,15 +405,15 @@ class FusedTrainer:
             cs = torch.cuda.Stream()
             cs.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(cs):
-                g1.capture_begin()
+                g1.capture_begin(pool=pool)
 
                 def cut():
                     g1.capture_end()
-                    g2.capture_begin(pool=g1.pool())
+                    g2.capture_begin(pool=pool)
 
                 self._fwd_bwd(x, U, tau, B, T, cut=cut)
                 g2.capture_end()
-                g3.capture_begin(pool=g1.pool())
+                g3.capture_begin(pool=pool)
                 self._update()
                 g3.capture_end()
             torch.cuda.current_stream().wait_stream(cs)
@@ -237,9 +426,9 @@ class FusedTrainer:
             return g1, g2, g3
         else:
             g2 = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g1):
+            with torch.cuda.graph(g1, pool=pool):
                 self._fwd_bwd(x, U, tau, B, T)
-            with torch.cuda.graph(g2, pool=g1.pool()):
+            with torch.cuda.graph(g2, pool=pool):
                 self._update()
         self.model._flat.copy_(flat0)
         self.m.copy_(m0)

@@ -95,3 +95,23 @@ def test_ddp_overlap_matches_single_allreduce():
     assert torch.isfinite(flat_a).all()
     rel = float((flat_a - flat_1).norm() / flat_1.norm())
     assert rel < 2e-2, rel
+
+
+@pytest.mark.timeout(600)
+def test_bench_gpus2_self_launches():
+    """`python bench.py --gpus 2` typed as is (no torch.distributed.run): the parent spawns the two ranks before making
+    any GPU call, the ranks run the data-parallel step (gloo here: two ranks share the one GPU), rank 0's JSON line
+    comes back through the parent."""
+    import json
+    import subprocess
+    env = dict(os.environ, RBVAE_DIST_BACKEND="gloo")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                        "--no-cpu", "--no-roofline"], env=env, capture_output=True, text=True, timeout=540)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["config"]["global_frames_per_step"] == 512 and line["value"] > 0
+    assert line["config"]["graphs_captured"] == 1
+    assert 0 < line["roofline"]["e2e"]["frac_hbm"] < 1
+    assert all(abs(v) < 1e4 for v in line["config"]["last_losses"].values())

@@ -17,7 +17,7 @@ def test_mfma_bf16_map(L):
     A = torch.randint(-4, 5, (16, 32), generator=g).float()
     B = torch.randint(-4, 5, (32, 16), generator=g).float()     # asymmetric
     D = torch.empty(16, 16, device="cuda")
-    L.call("rbvae_dbg_mfma_bf16", A.bfloat16().cuda(), B.bfloat16().cuda(), D)
+    L.dbg_call("rbvae_dbg_mfma_bf16", A.bfloat16().cuda(), B.bfloat16().cuda(), D)
     assert torch.equal(D.cpu(), A @ B)
 
 
@@ -26,7 +26,7 @@ def test_mfma_f32_map(L):
     A = torch.randn(16, 4, generator=g)
     B = torch.randn(4, 16, generator=g)
     D = torch.empty(16, 16, device="cuda")
-    L.call("rbvae_dbg_mfma_f32", A.cuda(), B.cuda(), D)
+    L.dbg_call("rbvae_dbg_mfma_f32", A.cuda(), B.cuda(), D)
     ref = torch.zeros(16, 16)
     for k in range(4):                      # k-ordered fma chain
         ref = torch.addcmul(ref, A[:, k:k + 1].expand(16, 16), B[k:k + 1, :].expand(16, 16))
@@ -37,7 +37,7 @@ def test_glds_lane_linear_destination(L):
     src = torch.arange(64 * 4 * 2, dtype=torch.int32)           # 128 chunks of 16 B
     perm = torch.randperm(128, generator=torch.Generator().manual_seed(2))[:64].to(torch.int32)
     out = torch.empty(256, dtype=torch.int32, device="cuda")
-    L.call("rbvae_dbg_glds", src.cuda(), perm.cuda(), out)
+    L.dbg_call("rbvae_dbg_glds", src.cuda(), perm.cuda(), out)
     want = src.view(128, 4)[perm.long()].reshape(-1)            # lane i lands at LDS byte 16*i
     assert torch.equal(out.cpu(), want)
 
@@ -54,7 +54,7 @@ def test_tr16_block_transpose(L):
     rowsel = (row0 + q).to(torch.int32)
     colsel = (col0 + 4 * p).to(torch.int32)
     out = torch.empty(64 * 4, dtype=torch.int16, device="cuda")
-    L.call("rbvae_dbg_tr16", img.cuda(), rowsel.cuda(), colsel.cuda(), out)
+    L.dbg_call("rbvae_dbg_tr16", img.cuda(), rowsel.cuda(), colsel.cuda(), out)
     im = img.view(32, 64)
     want = torch.stack([im[row0 + j, col0 + i] for j in range(4)], dim=1).reshape(-1)
     assert torch.equal(out.cpu(), want)

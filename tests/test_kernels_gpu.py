@@ -147,10 +147,40 @@ def test_conv_wgrad(sfv, dtype, k, C, Co, N, H, W, ks):
     sfv._lib.call("rbvae_conv_gather_index", idx, N, H, W, Ho, Wo, k, k, 2, 1)
     slabs = torch.full((ks, Co, k * k, C), 9.0, device="cuda")
     zero = torch.zeros(256, dtype=torch.uint8, device="cuda")
-    sfv._lib.call("rbvae_wgrad_gemm", dt, nhwc(dy, tdt), nhwc(x, tdt), slabs, idx, zero, P, Co, C, Co, C, k * k, ks)
+    sfv._lib.call("rbvae_wgrad_gemm", dt, nhwc(dy, tdt), nhwc(x, tdt), slabs, idx, zero, P, N * H * W, Co, C, Co, C, k * k, ks)
     out = torch.empty(Co, C, k * k, device="cuda")
     sfv._lib.call("rbvae_permute_reduce", slabs, ks, Co * k * k * C, out, Co, C, k * k, k * k * C, 1, C, 1.0, 0)
     assert rel(out.cpu().reshape(Co, C, k, k), w.grad) < tol
+
+
+def test_conv_wgrad_bad_indices_read_the_zero_row(sfv):
+    """A gather table holding out-of-range rows (stale, half-built, built for another shape) must not fault: such
+    entries read the zero row, exactly like the table's own -1 padding entries."""
+    from importlib import import_module
+    E = import_module("symbols-from-video_amd.engine")
+    k, C, Co, N, H, W, ks = 3, 64, 64, 2, 8, 8, 2
+    g = torch.Generator().manual_seed(33)
+    Ho, Wo = E.conv_out(H, k), E.conv_out(W, k)
+    P = N * Ho * Wo
+    x = torch.randn(N * H * W, C, generator=g).cuda()
+    dy = torch.randn(P, Co, generator=g).cuda()
+    idx = torch.empty(k * k * P, dtype=torch.int32, device="cuda")
+    sfv._lib.call("rbvae_conv_gather_index", idx, N, H, W, Ho, Wo, k, k, 2, 1)
+    bad = idx.clone()
+    sel = torch.randperm(bad.numel(), generator=g)[:40].cuda()
+    bad[sel[:20]] = 2_000_000_000
+    bad[sel[20:30]] = N * H * W            # first row past the end
+    bad[sel[30:]] = -12345
+    good = idx.clone()
+    good[sel] = -1
+    zero = torch.zeros(256, dtype=torch.uint8, device="cuda")
+    outs = []
+    for table in (bad, good):
+        slabs = torch.empty(ks, Co, k * k, C, device="cuda")
+        sfv._lib.call("rbvae_wgrad_gemm", 0, dy, x, slabs, table, zero, P, N * H * W, Co, C, Co, C, k * k, ks)
+        outs.append(slabs)
+    torch.cuda.synchronize()
+    assert torch.equal(outs[0], outs[1])
 
 
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
@@ -306,15 +336,20 @@ def test_binarize_parts_and_combine(sfv):
     nparts = sfv._lib.query("rbvae_binarize_kl_nparts", rows, L)
     assert nparts == -(-rows * L // 256)
     parts = torch.empty(nparts, device="cuda")
-    sfv._lib.call("rbvae_binarize_kl_fwd_parts", h, U, y1, z1, parts, rows, L, 0.7, 0.1, 1e-8, 0, 0.1, 1e-8, 1, 0, None)
+    sfv._lib.call("rbvae_binarize_kl_fwd_parts", h, U, y1, z1, parts, rows, L, 0.7, None, 0.1, 1e-8, 0, 0.1, 1e-8, 1, 0, None)
     assert torch.equal(y0, y1) and torch.equal(z0, z1)
+    # temperature from a device float (by-value argument ignored): same bits
+    y2, z2, parts2 = torch.empty_like(y1), torch.empty_like(z1), torch.empty_like(parts)
+    tau_dev = torch.tensor([0.7], device="cuda")
+    sfv._lib.call("rbvae_binarize_kl_fwd_parts", h, U, y2, z2, parts2, rows, L, 123.0, tau_dev, 0.1, 1e-8, 0, 0.1, 1e-8, 1, 0, None)
+    assert torch.equal(y1, y2) and torch.equal(z1, z2) and torch.equal(parts, parts2)
     sse = torch.rand(37, generator=g).cuda()
     pair = torch.tensor([0.375], device="cuda")
     out4 = torch.empty(4, device="cuda")
     step = torch.tensor([4], dtype=torch.int64, device="cuda")
     hyper = torch.zeros(2, device="cuda")
     sfv._lib.call("rbvae_combine_losses", sse, 37, 1.0 / 1000, None, parts, nparts, 1.0 / rows, pair, 0, 0.0, 0.0, 0.5, 2.0,
-                  out4, step, 1e-3, 0.9, 0.999, hyper)
+                  out4, step, 1e-3, None, 0.9, 0.999, hyper)
     recon, kl = float(sse.sum()) / 1000, kl0.item()
     got = out4.cpu().tolist()
     assert abs(got[1] - recon) < 1e-6 and abs(got[2] - kl) < 1e-5 * max(1.0, abs(kl)) and got[3] == 0.375
@@ -438,7 +473,7 @@ def test_lstm_pair_forward_equals_three_launches(sfv, L, layers, S, T, hard):
     nkl = sfv._lib.query("rbvae_binarize_kl_nparts", N, L)
     parts0 = torch.empty(nkl, device="cuda")
     sfv._lib.call("rbvae_lstm_fwd", we, None, he, pe, ae, ce, S, T, L, layers)
-    sfv._lib.call("rbvae_binarize_kl_fwd_parts", he[layers].contiguous(), U, y0, hd[0], parts0, N, L, tau, r, 1e-8, hard, p,
+    sfv._lib.call("rbvae_binarize_kl_fwd_parts", he[layers].contiguous(), U, y0, hd[0], parts0, N, L, tau, None, r, 1e-8, hard, p,
                   1e-8, 1, 0, None)
     pad0 = torch.zeros(N, 64, dtype=torch.bfloat16, device="cuda")
     sfv._lib.call("rbvae_lstm_fwd_ex", wd, None, hd, pd, ad, cd, S, T, L, layers, None, 1, 0, pad0, 1, 64)
@@ -449,7 +484,7 @@ def test_lstm_pair_forward_equals_three_launches(sfv, L, layers, S, T, hard):
     parts1 = torch.empty(S, device="cuda")
     pad1 = torch.full((N, 64), 3.0, dtype=torch.bfloat16, device="cuda")
     sfv._lib.call("rbvae_lstm_pair_fwd", we, None, wd, None, he1, pe1, ae1, ce1, hd1, pd1, ad1, cd1, None, 1, 0, U, y1, parts1,
-                  tau, r, 1e-8, hard, p, 1e-8, 1, 0, None, pad1, 1, 64, S, T, L, layers)
+                  123.0, torch.tensor([tau], device="cuda"), r, 1e-8, hard, p, 1e-8, 1, 0, None, pad1, 1, 64, S, T, L, layers)
     names = "hs_enc hprev_enc acts_enc cs_enc hs_dec hprev_dec acts_dec cs_dec y_soft cast".split()
     pairs = ((he, he1), (pe, pe1), (ae, ae1), (ce, ce1), (hd, hd1), (pd, pd1), (ad, ad1), (cd, cd1), (y0, y1), (pad0, pad1))
     for nm, (a, b) in zip(names, pairs):

@@ -75,8 +75,12 @@ def test_binarize_kl_fused_bwd(L):
         L.call("rbvae_binarize_kl_fwd", h.detach().cuda(), U.cuda(), y, zd, kl, rows, Ld, tau, r, 1e-8, hard, 0.1, 1e-8, 1, 0, None)
         assert abs(kl.item() - O.kl_binary_concrete(z.detach(), 0.1).item()) < 1e-5
         dh = torch.full((rows, Ld), 7.0, device="cuda")
-        L.call("rbvae_binarize_kl_bwd", gz.cuda(), y, zd, dh, 0, rows, Ld, tau, 0.3, None, 0.1, 1e-8, 1)
+        L.call("rbvae_binarize_kl_bwd", gz.cuda(), y, zd, dh, 0, rows, Ld, tau, None, 0.3, None, 0.1, 1e-8, 1)
         np.testing.assert_allclose(dh.cpu().numpy(), gh.numpy(), atol=2e-6, rtol=1e-5)
+        dh2 = torch.empty_like(dh)       # temperature read from a device float: same bits
+        L.call("rbvae_binarize_kl_bwd", gz.cuda(), y, zd, dh2, 0, rows, Ld, 55.0, torch.tensor([tau], device="cuda"), 0.3,
+               None, 0.1, 1e-8, 1)
+        assert torch.equal(dh, dh2)
 
 
 def test_pairdist_and_contrast_term(L):
@@ -172,5 +176,5 @@ def test_contrast_term_fused_matches_two_launch_form(L):
         out4 = torch.empty(4, device="cuda")
         one = torch.tensor([0.25], device="cuda")
         L.call("rbvae_combine_losses", None, 0, 0.0, one, one, 0, 0.0, parts, n, 1.0 / (B * T), 1.0 / (B * (T - 1)), 1.0, 1.0,
-               out4, None, 0.0, 0.0, 0.0, None)
+               out4, None, 0.0, None, 0.0, 0.0, None)
         assert abs(out4[3].item() - ref.item()) < 1e-5 * max(1.0, abs(ref.item()))

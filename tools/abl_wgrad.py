@@ -14,7 +14,7 @@ def run(N, H, ks, iters=30):
     idx = torch.empty(9 * P, dtype=torch.int32, device="cuda")
     L.call("rbvae_conv_gather_index", idx, N, H, H, Ho, Ho, 3, 3, 2, 1)
     slabs = torch.empty(ks * C * 9 * C, dtype=torch.float32, device="cuda")
-    args = (1, Dy, In, slabs, idx, zero, P, C, C, C, C, 9, ks)
+    args = (1, Dy, In, slabs, idx, zero, P, In.numel() // C, C, C, C, C, 9, ks)
     for _ in range(3):
         L.call("rbvae_wgrad_gemm", *args)
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

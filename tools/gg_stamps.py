@@ -35,10 +35,10 @@ def launch(kind, N=256, C=256, gate=False, bias=True, drop=1):
         L.call("rbvae_gather_gemm", *args)
     nwg = 8192
     st = torch.zeros(nwg * 8, dtype=torch.int64, device="cuda")
-    L.call("rbvae_dbg_gg_stamps", st)
+    L.dbg_call("rbvae_dbg_gg_stamps", st)
     L.call("rbvae_gather_gemm", *args)
     torch.cuda.synchronize()
-    L.call("rbvae_dbg_gg_stamps", None)
+    L.dbg_call("rbvae_dbg_gg_stamps", None)
     s = st.cpu().numpy().reshape(nwg, 8)
     s = s[s[:, 0] > 0]
     t0 = s[:, 0].min()

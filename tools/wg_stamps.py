@@ -17,7 +17,7 @@ def run(N, ih, oh, C=256, ks=7):
     idx = torch.empty(9 * P, dtype=torch.int32, device="cuda")
     L.call("rbvae_conv_gather_index", idx, N, ih, ih, oh, oh, 3, 3, 2, 1)
     slabs = torch.empty(ks * C * 9 * C, device="cuda")
-    args = (1, Dy, In, slabs, idx, zero, P, C, C, C, C, 9, ks)
+    args = (1, Dy, In, slabs, idx, zero, P, In.numel() // C, C, C, C, C, 9, ks)
     for _ in range(3):
         L.call("rbvae_wgrad_gemm", *args)
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -27,10 +27,10 @@ def run(N, ih, oh, C=256, ks=7):
     b.record(); torch.cuda.synchronize()
     us = a.elapsed_time(b) / 20 * 1e3
     st = torch.zeros(4096 * 8, dtype=torch.int64, device="cuda")
-    L.call("rbvae_dbg_wg_stamps", st)
+    L.dbg_call("rbvae_dbg_wg_stamps", st)
     L.call("rbvae_wgrad_gemm", *args)
     torch.cuda.synchronize()
-    L.call("rbvae_dbg_wg_stamps", None)
+    L.dbg_call("rbvae_dbg_wg_stamps", None)
     s = st.cpu().numpy().reshape(-1, 8)
     s = s[s[:, 0] > 0]
     if len(s) == 0:
