@@ -165,8 +165,20 @@ def _drop(a: Tensor, rate: float, train: bool, mask: Optional[Tensor]) -> Tensor
     return a * mask / (1.0 - rate)
 
 
+def _relu(a: Tensor, gates, j: int, pre: Optional[list]) -> Tensor:
+    """ReLU, or -- parity diagnostics -- multiplication by a given 0/1 gate (the device's own ReLU decisions), so that
+    a pre-activation within rounding of zero cannot make two correct implementations disagree by a whole element's
+    gradient.  `pre` collects the pre-activations so a test can check that given gates differ from sign(x) only
+    where |x| is within rounding of zero."""
+    if pre is not None:
+        pre.append(a.detach())
+    if gates is None:
+        return torch.relu(a)
+    return a * gates[j].to(a.dtype)
+
+
 def encoder_cnn(v: Variant, p: Dict[str, Tensor], X: Tensor, train: bool,
-                masks: Optional[Sequence[Tensor]]) -> Tensor:
+                masks: Optional[Sequence[Tensor]], gates=None, pre: Optional[list] = None) -> Tensor:
     k = v.kernel
     idx = (0, 2, 4) if v.name == "simple" else (0, 3, 6)
     a = X
@@ -175,7 +187,7 @@ def encoder_cnn(v: Variant, p: Dict[str, Tensor], X: Tensor, train: bool,
                      stride=2, padding=1)
         last = j == 2
         if not last or v.name == "simple":
-            a = torch.relu(a)
+            a = _relu(a, gates if not last else None, j, pre if not last else None)
         if not last and v.dropout > 0:
             a = _drop(a, v.dropout, train, None if masks is None else masks[j])
     flat = a.flatten(1)                       # NCHW flatten order
@@ -183,7 +195,7 @@ def encoder_cnn(v: Variant, p: Dict[str, Tensor], X: Tensor, train: bool,
 
 
 def decoder_cnn(v: Variant, p: Dict[str, Tensor], d: Tensor, hw_b: Tuple[int, int],
-                train: bool, masks: Optional[Sequence[Tensor]]) -> Tensor:
+                train: bool, masks: Optional[Sequence[Tensor]], gates=None, pre: Optional[list] = None) -> Tensor:
     k = v.kernel
     idx = (0, 2, 4) if v.name == "simple" else (0, 3, 6)
     op = 1 if k == 3 else 0
@@ -194,7 +206,7 @@ def decoder_cnn(v: Variant, p: Dict[str, Tensor], d: Tensor, hw_b: Tuple[int, in
                                p[f"decoder_cnn.deconv.{i}.bias"],
                                stride=2, padding=1, output_padding=op)
         if j < 2:
-            a = torch.relu(a)
+            a = _relu(a, gates, 2 + j, pre)
             if v.dropout > 0:
                 a = _drop(a, v.dropout, train, None if masks is None else masks[2 + j])
         else:
@@ -204,8 +216,10 @@ def decoder_cnn(v: Variant, p: Dict[str, Tensor], d: Tensor, hw_b: Tuple[int, in
 
 def forward(variant: str, p: Dict[str, Tensor], x: Tensor, U: Tensor,
             temperature: float = 1.0, hard: bool = False, noise_ratio: float = 0.1,
-            train: bool = False, masks: Optional[Sequence[Tensor]] = None):
+            train: bool = False, masks: Optional[Sequence[Tensor]] = None, gates=None,
+            pre: Optional[list] = None):
     """Seq2SeqBinaryVAE.forward.  x: [B,T,C,H,W]; U: [B*T, L] uniform noise.
+    gates / pre: parity diagnostics, see _relu (4 gate tensors: conv1, conv2, deconv0, deconv1 outputs, NCHW).
 
     Returns (x_recon, h_seq, z_seq) for percep/contrastive/triplet and
     (x_recon, logits) for simple, exactly like the reference modules."""
@@ -215,12 +229,12 @@ def forward(variant: str, p: Dict[str, Tensor], x: Tensor, U: Tensor,
     hw_b = bottleneck_hw(v, (H, W))
     r = noise_ratio if v.noise_ratio_arg else 1.0
     X = x.reshape(B * T, C, H, W)
-    e = encoder_cnn(v, p, X, train, masks)                      # [B*T, L]
+    e = encoder_cnn(v, p, X, train, masks, gates, pre)          # [B*T, L]
     if v.order == "cnn-rnn-bin-rnn-cnn":
         hs = lstm_stack(e.reshape(B, T, L), p, "encoder_rnn", v.lstm_layers)
         z = binarize(hs.reshape(B * T, L), U, temperature, hard, r, v.eps)
         ds = lstm_stack(z.reshape(B, T, L), p, "decoder_rnn", v.lstm_layers)
-        xr = decoder_cnn(v, p, ds.reshape(B * T, L), hw_b, train, masks)
+        xr = decoder_cnn(v, p, ds.reshape(B * T, L), hw_b, train, masks, gates, pre)
         return xr.reshape(B, T, -1, H, W), hs, z.reshape(B, T, L)
     z = binarize(e, U, temperature, hard, r, v.eps)
     hs = lstm_stack(z.reshape(B, T, L), p, "encoder_rnn", v.lstm_layers)
@@ -309,15 +323,19 @@ def step_losses(variant: str, p: Dict[str, Tensor], item: Tensor, U: Sequence[Te
                 alpha: float = 0.1, beta: float = 0.1, margin: float = 1.0,
                 hard: bool = False, train: bool = False,
                 masks: Optional[Sequence[Sequence[Tensor]]] = None,
-                validation_norm: bool = False, pair_loss: Optional[str] = None) -> Dict[str, Tensor]:
+                validation_norm: bool = False, pair_loss: Optional[str] = None, gates=None,
+                pre: Optional[list] = None) -> Dict[str, Tensor]:
     """One trainer step's loss for item [B,2,T,C,H,W] (percep_RBVAE_train.py:517-549;
     validation weighting :590-635 when validation_norm).
     pair_loss: "contrast" | "triplet" overrides the variant's own pairwise term (BASELINE configs[4]: the
     percep-shaped network trained with the triplet term of triplet_RBVAE_train.py:461-468)."""
     recons, kls, hs = [], [], []
     for vw in range(2):
+        pv = [] if pre is not None else None
         xr, h, z = forward(variant, p, item[:, vw], U[vw], temperature, hard, noise_ratio,
-                           train, None if masks is None else masks[vw])
+                           train, None if masks is None else masks[vw], None if gates is None else gates[vw], pv)
+        if pre is not None:
+            pre.append(pv)
         recons.append(recon_loss(xr, item[:, vw]))
         kls.append(kl_binary_concrete(z, bernoulli_p))
         hs.append(h)

@@ -139,6 +139,7 @@ class FusedTrainer:
                           frame_map=(B * T, T, T * chw, 2 * T * chw, chw), tau_dev=self.tau_dev)
         sse_ws, nparts, inv_n = out["sse"]
         kl_parts, nkl, kl_scale = out["kl"]
+        self.last_saved = out["saved"]          # diagnostics (tests read the device's ReLU decisions from it)
         b1, b2 = self.betas
 
         def bookkeeping():
