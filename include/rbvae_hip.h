@@ -366,6 +366,14 @@ int rbvae_groupnorm_swish_ws(int dtype, const void* x, void* y, const float* gam
                              size_t ws_floats, int N, int HW, int C, int ldx, int ldy, int groups, float eps, int swish,
                              void* stream);
 int rbvae_softmax_rows(int dtype, const void* x, void* y, long rows, int n, int ld, void* stream);
+/* AttnBlock.forward's q k^T * C^-0.5 -> softmax -> . v (ldm/modules/diffusionmodules/model.py:186-198) for N images
+ * of hw tokens x C channels as ONE batched, tiled, online-softmax kernel: the hw x hw scores are never materialised.
+ * Q, K, V, O: NHWC rows [N*hw][ld*] (may be column blocks of one fused q|k|v projection).  rbvae_attention_ok tells
+ * whether the shape is covered (bf16, hw % 32 == 0, C in {64,128,256,512}); otherwise use the three-launch form
+ * (rbvae_gather_gemm + rbvae_softmax_rows + rbvae_transpose2d). */
+int rbvae_attention_ok(int dtype, int hw, int C);
+int rbvae_attention(int dtype, const void* Q, const void* K, const void* V, void* O, int N, int hw, int C, int ldq,
+                    int ldk, int ldv, int ldo, float scale, void* stream);
 int rbvae_transpose2d(int dtype, const void* in, void* out, int R, int C, int ldi, int ldo, void* stream);
 int rbvae_posterior_sample(int dtype, const void* moments, int ld, const float* eps, float* latent, int N, int Z,
                            int HW, float scale, void* stream);

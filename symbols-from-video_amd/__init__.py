@@ -14,3 +14,5 @@ from .data import (DeviceStatePairDataset, assign_label, build_pairs, consistenc
                    split_indices, state_consistency)
 from .ldm import LDMEncoder  # noqa: F401
 from .model import Seq2SeqBinaryVAE, binary_concrete_logits  # noqa: F401
+from .trainer import FusedTrainer, noise_key  # noqa: F401
+from .compose import OnTheFlyLatentTrainer  # noqa: F401

@@ -157,6 +157,10 @@ class LDMEncoder(nn.Module):
                 pk[name] = pack3(w, (co, K), (co, ci, 1), (K, 1, 0))
             else:
                 pk[name] = pack3(w, (co, kk, ci), (co, ci, kk), (kk * ci, 1, ci))   # [co][t][ci]
+        for prefix, kind, cin, _ in self.plan:
+            if kind == "attn":        # q | k | v as one projection [3C][C] for the fused attention path
+                pk[f"{prefix}.qkv.weight"] = torch.cat([pk[f"{prefix}.{n}.weight"] for n in ("q", "k", "v")]).contiguous()
+                pk[f"{prefix}.qkv.bias"] = torch.cat([self._p(f"{prefix}.{n}.bias").float() for n in ("q", "k", "v")]).contiguous()
         self._packed = (dev, dt, tdt, ke, pk)
         self._zero = torch.zeros(256, dtype=torch.uint8, device=dev)
         self._d_conv = _conv_desc(3, -1)          # stride 1, pad 1
@@ -207,6 +211,17 @@ class LDMEncoder(nn.Module):
             raise ValueError(f"mid-block attention: {hw} tokens must be a multiple of {ke} "
                              f"(frame sides divisible by {8 * int(math.isqrt(ke))})")
         h = self._gn(f"{prefix}.norm", x, N, hw, C, swish=False)
+        if L.query("rbvae_attention_ok", dt, hw, C):
+            # one fused q|k|v projection, then the batched online-softmax kernel (csrc/attn.hip): no hw x hw scores,
+            # no per-image loop, no transposed copy of V
+            pk = self._packed[4]
+            qkv = torch.empty(N * hw, 3 * C, dtype=tdt, device=x.device)
+            self._gemm(h, pk[f"{prefix}.qkv.weight"], qkv, pk[f"{prefix}.qkv.bias"], None, N * hw, 1, 1, 1, 1, 1, 1, 1, C,
+                       3 * C, h.shape[1], 3 * C, 1, self._d_one)
+            o = torch.empty(N * hw, C, dtype=tdt, device=x.device)
+            L.call("rbvae_attention", dt, qkv, qkv[:, C:], qkv[:, 2 * C:], o, N, hw, C, 3 * C, 3 * C, 3 * C, C,
+                   float(int(C) ** (-0.5)))
+            return self._conv1(f"{prefix}.proj_out", o, N * hw, C, C, addend=x)
         q = self._conv1(f"{prefix}.q", h, N * hw, C, C)
         k = self._conv1(f"{prefix}.k", h, N * hw, C, C)
         v = self._conv1(f"{prefix}.v", h, N * hw, C, C)
@@ -271,15 +286,23 @@ class LDMEncoder(nn.Module):
         return h
 
     @torch.no_grad()
-    def encode(self, x: torch.Tensor, eps: Optional[torch.Tensor] = None, sample: bool = True) -> torch.Tensor:
+    def encode(self, x: torch.Tensor, eps: Optional[torch.Tensor] = None, sample: bool = True,
+               out: Optional[torch.Tensor] = None) -> torch.Tensor:
         """frame batch -> latent [N, 4, H/8, W/8] f32 = 0.18215 * posterior sample (get_percep_embeddings.py:101-103).
-        eps: the N(0,1) draw (default: torch.randn on the host like distributions.py:36); sample=False = mode."""
+        eps: the N(0,1) draw (default: torch.randn on the host like distributions.py:36); sample=False = mode.
+        out: write the latents into this contiguous f32 tensor of N*4*(H/8)*(W/8) elements (e.g. a slice of
+        FusedTrainer.input_buffer(): the on-the-fly pipeline of BASELINE configs[4] never copies a latent)."""
         m = self.moments(x)
         N, _, H, W = x.shape
         Z, hw = self.cfg["embed_dim"], (H // 8) * (W // 8)
         if sample and eps is None:
             eps = torch.randn((N, Z, H // 8, W // 8)).to(x.device)
-        lat = torch.empty(N, Z, H // 8, W // 8, dtype=torch.float32, device=x.device)
+        if out is not None:
+            if out.dtype != torch.float32 or not out.is_contiguous() or out.numel() != N * Z * hw or out.device != x.device:
+                raise ValueError(f"out must be a contiguous f32 tensor of {N * Z * hw} elements on {x.device}")
+            lat = out.view(N, Z, H // 8, W // 8)
+        else:
+            lat = torch.empty(N, Z, H // 8, W // 8, dtype=torch.float32, device=x.device)
         L.call("rbvae_posterior_sample", self._packed[1], m, m.shape[1], eps.float().contiguous() if sample else None,
                lat, N, Z, hw, SCALE_FACTOR)
         return lat

@@ -1,0 +1,81 @@
+"""BASELINE configs[4] / SURVEY.md 8f row 4: frames -> frozen LDM VAE encode on the fly -> percep-shaped RBVAE trained
+with the triplet term, against ldm_oracle.encode + rbvae_oracle.step_losses(pair_loss="triplet")."""
+import pytest
+import torch
+
+import ldm_oracle as LO
+import rbvae_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(dtype, seed=70):
+    import sfv_amd as sfv
+    torch.manual_seed(seed)
+    enc = sfv.LDMEncoder(compute_dtype=dtype)
+    enc_params = {k: v.clone() for k, v in enc.state_dict().items()}
+    torch.manual_seed(seed + 1)
+    Ld, lat_hw = 32, (8, 8)
+    m = sfv.Seq2SeqBinaryVAE(4, 4, Ld, Ld, variant="percep", input_hw=lat_hw, compute_dtype=dtype)
+    params = {k: v.clone().requires_grad_() for k, v in m.state_dict().items()}
+    m = m.cuda().eval()
+    return sfv, enc.cuda(), enc_params, m, params, Ld, lat_hw
+
+
+def test_on_the_fly_triplet_step_matches_oracles_f32():
+    sfv, enc, enc_params, m, params, Ld, lat_hw = _setup("f32")
+    B, T, H, W = 2, 3, 64, 64
+    g = torch.Generator().manual_seed(72)
+    frames = torch.rand(B, 2, T, 3, H, W, generator=g) * 2 - 1
+    eps = torch.randn(B, 2, T, 4, *lat_hw, generator=g)
+    U = torch.rand(2, B * T, Ld, generator=g)
+    alpha, beta, p, r, margin, tau = 0.8, 0.5, 0.1, 0.1, 0.2, 0.7
+    # oracle: the reference encoder's arithmetic, then the RBVAE step on its latents
+    with torch.no_grad():
+        lat = LO.encode(enc_params, frames.reshape(-1, 3, H, W), eps.reshape(-1, 4, *lat_hw)).reshape(B, 2, T, 4, *lat_hw)
+    ref = O.step_losses("percep", params, lat, [U[0], U[1]], tau, r, p, alpha, beta, margin, pair_loss="triplet")
+    ref["total"].backward()
+    tr = sfv.FusedTrainer(m, lr=1e-3, alpha=alpha, beta_kl=beta, bernoulli_p=p, noise_ratio=r, margin=margin,
+                          device_noise=False, use_graph=False, pair_loss="triplet")
+    pipe = sfv.OnTheFlyLatentTrainer(enc, tr, frames_per_chunk=5)          # ragged chunks: 5 + 5 + 2 frames
+    got = pipe.step(frames.cuda(), tau, eps=eps.cuda(), U=U.cuda()).cpu().tolist()
+    buf = tr.input_buffer(B, T, 4, *lat_hw)
+    assert float((buf.cpu() - lat).abs().max()) < 2e-4                      # the latents landed in the step's buffer
+    for x, k in zip(got, ("total", "recon", "kl", "pair")):
+        assert abs(x - float(ref[k])) < 2e-4 * max(1.0, abs(float(ref[k]))), (k, x, float(ref[k]))
+    lay = tr.eng.layout
+    for k in lay.names:
+        gr = lay.view(tr.gflat, k).cpu().double().reshape(-1)
+        rf = params[k].grad.double().reshape(-1)
+        assert float((gr - rf).norm()) <= 2e-3 * max(float(rf.norm()), 1e-7), k
+    # validation on the same pipeline: hard codes, normalised weights (percep_RBVAE_train.py:590-635)
+    with torch.no_grad():
+        w = {k: v.detach() for k, v in m.state_dict().items()}
+        w = {k: v.cpu() for k, v in w.items()}
+        vref = O.step_losses("percep", w, lat, [U[0], U[1]], 0.3, r, p, alpha, beta, margin, hard=True,
+                             validation_norm=True, pair_loss="triplet")
+    vgot = pipe.validate(frames.cuda(), 0.3, eps=eps.cuda(), U=U.cuda()).cpu().tolist()
+    for x, k in zip(vgot, ("total", "recon", "kl", "pair")):
+        assert abs(x - float(vref[k])) < 2e-4 * max(1.0, abs(float(vref[k]))), (k, x, float(vref[k]))
+
+
+def test_on_the_fly_bf16_graph_runs_and_tracks():
+    """The configuration as it would run: bf16 storage, device noise, graph replay, dropout on; the loss must stay
+    finite, fall, and sit near the f32 oracle's first-step value."""
+    sfv, enc, enc_params, m, params, Ld, lat_hw = _setup("bf16", seed=74)
+    m.train()
+    B, T, H, W = 2, 3, 64, 64
+    g = torch.Generator().manual_seed(75)
+    frames = torch.rand(B, 2, T, 3, H, W, generator=g) * 2 - 1
+    eps = torch.randn(B, 2, T, 4, *lat_hw, generator=g)
+    tr = sfv.FusedTrainer(m, lr=1e-3, alpha=1.0, beta_kl=1.0, bernoulli_p=0.1, margin=0.2, device_noise=True,
+                          use_graph=True, pair_loss="triplet", seed=1)
+    pipe = sfv.OnTheFlyLatentTrainer(enc, tr)
+    hist = [pipe.step(frames.cuda(), 0.7, eps=eps.cuda())[0].item() for _ in range(12)]
+    assert all(abs(h) < 1e4 for h in hist) and hist[-1] < hist[0]
+    assert len(tr._graphs) == 1
+    with torch.no_grad():
+        lat = LO.encode(enc_params, frames.reshape(-1, 3, H, W), eps.reshape(-1, 4, *lat_hw)).reshape(B, 2, T, 4, *lat_hw)
+    assert float((tr.input_buffer(B, T, 4, *lat_hw).cpu() - lat).norm() / lat.norm()) < 5e-2
+    with pytest.raises(ValueError):
+        pipe.step(torch.zeros(1, 2, 3, 3, 128, 128, device="cuda"), 0.7)

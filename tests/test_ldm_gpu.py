@@ -80,3 +80,27 @@ def test_groupnorm_tiled_matches_torch(dtype, C, N, HW):
     if dtype == "f32":
         mean = ws[:N * groups].cpu().reshape(N, groups)
         np.testing.assert_allclose(mean.numpy(), xq.reshape(N, groups, -1).mean(-1).numpy(), rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize("N,hw,C", [(2, 96, 512), (1, 4096, 512), (3, 64, 64), (2, 160, 256), (1, 32, 128)])
+def test_attention_online_softmax_matches_torch(N, hw, C):
+    """rbvae_attention (batched, tiled, online softmax; csrc/attn.hip) against AttnBlock's arithmetic
+    (model.py:186-198: bmm, * C^-0.5, softmax, bmm) on bf16-rounded operands, including a 4096-token image (512x512
+    frames), a query count that is not a multiple of the 64-row tile, and column-block operands of a fused projection."""
+    import sfv_amd as sfv
+    L = sfv._lib
+    assert L.query("rbvae_attention_ok", 1, hw, C) and not L.query("rbvae_attention_ok", 0, hw, C)
+    g = torch.Generator().manual_seed(80 + hw)
+    qkv = (torch.randn(N * hw, 3 * C, generator=g) * 1.5).bfloat16()
+    q, k, v = (qkv[:, i * C:(i + 1) * C].float().reshape(N, hw, C) for i in range(3))
+    w = torch.softmax(torch.bmm(q, k.transpose(1, 2)) * (int(C) ** (-0.5)), dim=2)
+    ref = torch.bmm(w, v).reshape(N * hw, C)
+    dq = qkv.cuda()
+    o = torch.zeros(N * hw, C, dtype=torch.bfloat16, device="cuda")
+    L.call("rbvae_attention", 1, dq, dq[:, C:], dq[:, 2 * C:], o, N, hw, C, 3 * C, 3 * C, 3 * C, C, float(int(C) ** (-0.5)))
+    got = o.float().cpu()
+    assert torch.isfinite(got).all()
+    assert float((got - ref).norm() / ref.norm()) < 1e-2
+    assert float((got - ref).abs().max()) < 4e-2 * float(ref.abs().max())
+    with pytest.raises(ValueError):
+        L.call("rbvae_attention", 1, dq, dq, dq, o, N, hw + 1, C, 3 * C, 3 * C, 3 * C, C, 1.0)
