@@ -17,6 +17,13 @@ def _setup(dtype, seed=70):
     torch.manual_seed(seed + 1)
     Ld, lat_hw = 32, (8, 8)
     m = sfv.Seq2SeqBinaryVAE(4, 4, Ld, Ld, variant="percep", input_hw=lat_hw, compute_dtype=dtype)
+    # A freshly initialised network maps every 0.18-scaled latent to nearly the same embedding (|h(view 0) - h(view 1)|
+    # ~ 2e-5 at |h| ~ 0.6, measured), which makes the triplet term's gradient -- the DIRECTION of that difference --
+    # ill-conditioned: the f32 oracle itself then sits 2.3e-4 from the f64 one.  A 50x encoder fc gain gives the
+    # embeddings the input sensitivity of a trained model and the comparison its meaning back.
+    sd = m.state_dict()
+    sd["encoder_cnn.fc.weight"] = sd["encoder_cnn.fc.weight"] * 50.0
+    m.load_state_dict(sd)
     params = {k: v.clone().requires_grad_() for k, v in m.state_dict().items()}
     m = m.cuda().eval()
     return sfv, enc.cuda(), enc_params, m, params, Ld, lat_hw
@@ -33,26 +40,37 @@ def test_on_the_fly_triplet_step_matches_oracles_f32():
     # oracle: the reference encoder's arithmetic, then the RBVAE step on its latents
     with torch.no_grad():
         lat = LO.encode(enc_params, frames.reshape(-1, 3, H, W), eps.reshape(-1, 4, *lat_hw)).reshape(B, 2, T, 4, *lat_hw)
-    ref = O.step_losses("percep", params, lat, [U[0], U[1]], tau, r, p, alpha, beta, margin, pair_loss="triplet")
-    ref["total"].backward()
     tr = sfv.FusedTrainer(m, lr=1e-3, alpha=alpha, beta_kl=beta, bernoulli_p=p, noise_ratio=r, margin=margin,
                           device_noise=False, use_graph=False, pair_loss="triplet")
     pipe = sfv.OnTheFlyLatentTrainer(enc, tr, frames_per_chunk=5)          # ragged chunks: 5 + 5 + 2 frames
     got = pipe.step(frames.cuda(), tau, eps=eps.cuda(), U=U.cuda()).cpu().tolist()
     buf = tr.input_buffer(B, T, 4, *lat_hw)
     assert float((buf.cpu() - lat).abs().max()) < 2e-4                      # the latents landed in the step's buffer
+    # the RBVAE half is checked on the latents the device produced, under the device's own ReLU decisions (_gates.py)
+    from _gates import count_ties, device_gates
+    gates, pre = device_gates(tr, B, T), []
+    ref = O.step_losses("percep", params, buf.cpu(), [U[0], U[1]], tau, r, p, alpha, beta, margin, pair_loss="triplet",
+                        gates=gates, pre=pre)
+    ref["total"].backward()
+    assert count_ties(pre, gates, None, 2e-5) <= 5
+    ref_lat = O.step_losses("percep", {k: v.detach() for k, v in params.items()}, lat, [U[0], U[1]], tau, r, p, alpha,
+                            beta, margin, pair_loss="triplet")
+    for k in ("total", "recon", "kl", "pair"):                             # ... and the losses end to end as well
+        assert abs(float(ref[k]) - float(ref_lat[k])) < 2e-4 * max(1.0, abs(float(ref_lat[k])))
     for x, k in zip(got, ("total", "recon", "kl", "pair")):
         assert abs(x - float(ref[k])) < 2e-4 * max(1.0, abs(float(ref[k]))), (k, x, float(ref[k]))
     lay = tr.eng.layout
     for k in lay.names:
         gr = lay.view(tr.gflat, k).cpu().double().reshape(-1)
         rf = params[k].grad.double().reshape(-1)
-        assert float((gr - rf).norm()) <= 2e-3 * max(float(rf.norm()), 1e-7), k
+        # 5e-4: with |h0 - h1| ~ 1e-3 the direction of the positive pair's difference still amplifies the LSTM's
+        # f32 rounding ~50x (f32 oracle vs f64 oracle: 8e-6)
+        assert float((gr - rf).norm()) <= 5e-4 * max(float(rf.norm()), 1e-7), k
     # validation on the same pipeline: hard codes, normalised weights (percep_RBVAE_train.py:590-635)
     with torch.no_grad():
         w = {k: v.detach() for k, v in m.state_dict().items()}
         w = {k: v.cpu() for k, v in w.items()}
-        vref = O.step_losses("percep", w, lat, [U[0], U[1]], 0.3, r, p, alpha, beta, margin, hard=True,
+        vref = O.step_losses("percep", w, buf.cpu(), [U[0], U[1]], 0.3, r, p, alpha, beta, margin, hard=True,
                              validation_norm=True, pair_loss="triplet")
     vgot = pipe.validate(frames.cuda(), 0.3, eps=eps.cuda(), U=U.cuda()).cpu().tolist()
     for x, k in zip(vgot, ("total", "recon", "kl", "pair")):

@@ -347,18 +347,7 @@ def _bench_case(seed):
     return B, T, Ld, hw, item, U, masks
 
 
-def _device_gates(tr, B, T):
-    """The device's ReLU decisions of the last step, as the oracle wants them: [view][site] 0/1 tensors [B*T,C,H,W]
-    (sites: conv1, conv2, deconv0, deconv1 outputs).  The saved activations are relu(x) * mask / 0.8 in NHWC rows,
-    sequences ordered (view, item): a > 0 <=> gate open (where the dropout mask is 0 the gate is irrelevant)."""
-    sv, eng = tr.last_saved, tr.eng
-    (h1, w1), (h2, w2) = eng.g1, eng.g2
-    out = [[], []]
-    for a, (h, w) in ((sv.a1, (h1, w1)), (sv.a2, (h2, w2)), (sv.d1, (h2, w2)), (sv.d2, (h1, w1))):
-        g = (a.float() > 0).view(2, B * T, h, w, -1).permute(0, 1, 4, 2, 3).cpu()
-        out[0].append(g[0])
-        out[1].append(g[1])
-    return out
+from _gates import device_gates as _device_gates, count_ties as _count_ties  # noqa: E402
 
 
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
@@ -389,16 +378,7 @@ def test_bench_shape_step_against_oracle(dtype):
     r64 = O.step_losses("percep", p64, item.double(), [U[0].double(), U[1].double()], 0.7, 0.1, 0.1, 1.0, 1.0, train=True,
                         masks=[[x.double() for x in mm] for mm in masks], gates=gates, pre=pre)
     r64["total"].backward()
-    ties = 0
-    for vw in range(2):
-        for j in range(4):
-            x, live = pre[vw][j], masks[vw][j] > 0
-            differ = ((x > 0) != gates[vw][j]) & live
-            ties += int(differ.sum())
-            if differ.any():
-                # a decision may differ from the oracle's sign only where the pre-activation is within rounding of 0
-                bound = 2e-5 if dtype == "f32" else 0.1
-                assert float(x[differ].abs().max()) < bound, (vw, j, float(x[differ].abs().max()))
+    ties = _count_ties(pre, gates, masks, 2e-5 if dtype == "f32" else 0.1)
     n_act = sum(int((mm[j] > 0).sum()) for mm in masks for j in range(4))
     if dtype == "f32":
         assert ties <= 20, ties
