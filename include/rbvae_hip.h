@@ -192,7 +192,9 @@ int rbvae_colsum(int dtype, const void* X, int P, int C, int ld, float* out, flo
  *    scale (f32 bits, low word) | fast index (high word), inner, dst2]
  * type 0 = pack3, 1 = permute_reduce, 2 = reduce_rows (out[c] = scale*sum_k src[k*slab+c], c < d0*d1*d2),
  * 3 = conv weight pack: src f32 [d0=co][d1=ci][d2=kk<=16] -> dst [co][t][ci] and dst2 [ci][t][co] of `dtype`
- * (nn.Conv2d / nn.ConvTranspose2d weights, percep_RBVAE_model.py:51-57,76-82, in the two GEMM operand orders).
+ * (nn.Conv2d / nn.ConvTranspose2d weights, percep_RBVAE_model.py:51-57,76-82, in the two GEMM operand orders),
+ * 4 = conv weight-gradient reduce: src = rbvae_wgrad_gemm's K-slice slabs [nslab][d0=co][d2=kk<=16][d1=ci] (f32,
+ * ci % 4 == 0), summed in slab order into dst [co][ci][kk] (the torch layout of the weight; scale, accumulate honoured).
  * fast: the logical index consecutive threads walk; inner != 0 (fast == 1, short d2): a thread walks d2 itself.
  * One launch (grid.y = job) replaces the per-tensor launches of a step. */
 int rbvae_run_jobs(const void* jobs_dev, int njobs, int blocks_per_job, void* stream);

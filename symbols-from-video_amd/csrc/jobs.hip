@@ -7,7 +7,8 @@ namespace rbvae {
 // 16 x int64 per job
 struct Job {
     long type;        // 0 pack3 (f32 -> T, strided scatter), 1 permute_reduce (thread per output), 2 reduce_rows (wave per
-                      // output), 3 conv weight [co][ci][kk] f32 -> both GEMM orders [co][t][ci] (dst) and [ci][t][co] (dst2)
+                      // output), 3 conv weight [co][ci][kk] f32 -> both GEMM orders [co][t][ci] (dst) and [ci][t][co] (dst2),
+                      // 4 conv weight-gradient slabs [ks][co][t][ci] -> [co][ci][kk] (d0 = co, d1 = ci, d2 = kk)
     const float* src;
     void* dst;
     long d0, d1, d2;  // logical extents [d0][d1][d2] (the contiguous side is laid out in this order)
@@ -22,72 +23,152 @@ struct Job {
 };
 static_assert(sizeof(Job) == 16 * 8, "job table stride");
 
-// Type 3: one read of a conv / conv-transpose weight [co][ci][kk] (contiguous f32 rows of TCI*kk values)
-// through an LDS tile, written out in both orders the GEMMs use -- [co][t][ci] for the forward GEMM and
-// [ci][t][co] for the backward-data GEMM -- as 64- to 128-byte runs on both sides.
-constexpr int CP_TCO = 16;                             // co per tile: 128 tiles for a 256 x 256 weight
-constexpr int CP_LDSF = CP_TCO * (32 * 9 + 1);        // floats: 32 ci x 9 taps, or 16 ci x 16 taps, +1 pad
-template <typename T, unsigned KK>      // KK = taps as a compile-time constant (index math by constant), 0 = runtime
-__device__ __forceinline__ void conv_pack_tile(const Job& j, float* tile) {
-    const unsigned Co = (unsigned)j.d0, Ci = (unsigned)j.d1, kk = KK ? KK : (unsigned)j.d2;
-    const unsigned TCI = kk <= 9 ? 32u : 16u;
-    const unsigned row = TCI * kk, pitch = row + 1;
-    const unsigned tco = (Co + CP_TCO - 1) / CP_TCO, tci = (Ci + TCI - 1) / TCI;
+// Type 3: a conv / conv-transpose weight [co][ci][kk] (f32 master, rows of ci*kk contiguous values) -> both GEMM orders,
+// [co][t][ci] (dst, forward GEMM) and [ci][t][co] (dst2, backward-data GEMM), in the storage type T.
+// A workgroup owns NCO = 16 / sizeof(T) output channels and ALL of ci x kk: the rows come in by 16-byte loads, sit in
+// LDS in T, and leave as 16-byte stores on both sides -- [co][t][ci] as whole 16-byte runs of ci, [ci][t][co] as the
+// 16-byte run of the workgroup's NCO channels (the per-element 2-byte stores of the first version moved 30 MB in
+// 15 us).  Weights with more than CPK_MAXROW values per channel take the workgroup's rows in pieces of ci.
+constexpr int CPK_MAXROW = 2304;                       // 256 ci x 9 taps (or 144 ci x 16 taps)
+constexpr int CPK_LDS_BYTES = 16 * (CPK_MAXROW + 8);  // NCO rows of T, NCO * sizeof(T) = 16; +8 elements of pad per row
+template <typename T>
+__device__ __forceinline__ void conv_pack_rows(const Job& j, unsigned char* lds_raw) {
+    constexpr unsigned NCO = 16 / sizeof(T), NV = 16 / sizeof(T);
+    typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+    T* tile = (T*)lds_raw;
+    const unsigned Co = (unsigned)j.d0, Ci = (unsigned)j.d1, kk = (unsigned)j.d2;
+    // ci block: a multiple of NV such that cib * kk <= CPK_MAXROW
+    unsigned cib = (CPK_MAXROW / kk) / NV * NV;
+    if (cib > Ci) cib = Ci;
+    const unsigned ncb = (Ci + cib - 1) / cib, ngr = (Co + NCO - 1) / NCO;
+    const unsigned pitch = CPK_MAXROW + 8;
     T* wf = (T*)j.dst;
     T* wd = (T*)j.dst2;
-    for (unsigned t = blockIdx.x; t < tco * tci; t += gridDim.x) {
-        const unsigned co0 = (t / tci) * CP_TCO, ci0 = (t % tci) * TCI;
+    const bool vec_ok = (Ci % NV == 0) && (Co % NCO == 0) && ((cib * kk) % 4 == 0) && ((Ci * kk) % 4 == 0);
+    for (unsigned b = blockIdx.x; b < ngr * ncb; b += gridDim.x) {
+        const unsigned co0 = (b / ncb) * NCO, ci0 = (b % ncb) * cib;
+        const unsigned cn = min(cib, Ci - ci0), row = cn * kk;       // this piece: cn input channels
         __syncthreads();
-        // the tile's rows, six loads per thread in flight at a time (one load per iteration paid a memory round
-        // trip each: 18 of them per tile)
-        constexpr unsigned LB = 6;
-        for (unsigned i0 = threadIdx.x; i0 < CP_TCO * row; i0 += LB * 256) {
-            float v[LB];
-#pragma unroll
-            for (unsigned u = 0; u < LB; ++u) {
-                const unsigned i = i0 + u * 256;
-                const unsigned ic = i < CP_TCO * row ? i : 0;
-                const unsigned r = ic / row, e = ic - r * row;
-                const unsigned c = e / kk;
-                const bool ok = i < CP_TCO * row && co0 + r < Co && ci0 + c < Ci;
-                const float x = j.src[ok ? ((size_t)(co0 + r) * Ci + ci0) * kk + e : 0];
-                v[u] = ok ? x : 0.f;
+        // ---- in: NCO rows of `row` consecutive floats each
+        if (vec_ok) {
+            const unsigned r4 = row / 4;
+            for (unsigned i = threadIdx.x; i < NCO * r4; i += 256) {
+                const unsigned r = i / r4, q = i - r * r4;
+                const float4 v = *(const float4*)(j.src + ((size_t)(co0 + r) * Ci + ci0) * kk + 4 * q);
+                T* d = tile + r * pitch + 4 * q;
+                Elem<T>::store(d, v.x); Elem<T>::store(d + 1, v.y); Elem<T>::store(d + 2, v.z); Elem<T>::store(d + 3, v.w);
             }
+        } else {
+            for (unsigned i = threadIdx.x; i < NCO * row; i += 256) {
+                const unsigned r = i / row, e = i - r * row;
+                const float v = co0 + r < Co ? j.src[((size_t)(co0 + r) * Ci + ci0) * kk + e] : 0.f;
+                Elem<T>::store(tile + r * pitch + e, v);
+            }
+        }
+        __syncthreads();
+        if (vec_ok) {
+            // ---- out 1: wf[co][t][ci0 + c .. + NV): 16-byte chunks, consecutive threads along ci
+            const unsigned cch = cn / NV;
+            for (unsigned i = threadIdx.x; i < NCO * kk * cch; i += 256) {
+                const unsigned cc = i % cch, q = i / cch, tp = q % kk, r = q / kk;
+                __attribute__((aligned(16))) T v[NV];
 #pragma unroll
-            for (unsigned u = 0; u < LB; ++u) {
-                const unsigned i = i0 + u * 256;
-                if (i < CP_TCO * row) {
-                    const unsigned r = i / row, e = i - r * row;
-                    tile[r * pitch + e] = v[u];
+                for (unsigned u = 0; u < NV; ++u) v[u] = tile[r * pitch + (cc * NV + u) * kk + tp];
+                *(u32x4*)(wf + ((size_t)(co0 + r) * kk + tp) * Ci + ci0 + cc * NV) = *(const u32x4*)v;
+            }
+            // ---- out 2: wd[ci][t][co0 .. co0 + NCO): one 16-byte chunk per (ci, t)
+            for (unsigned i = threadIdx.x; i < row; i += 256) {           // i = c * kk + tp, the torch order of a row
+                __attribute__((aligned(16))) T v[NCO];
+#pragma unroll
+                for (unsigned u = 0; u < NCO; ++u) v[u] = tile[u * pitch + i];
+                const unsigned c = i / kk, tp = i - c * kk;
+                *(u32x4*)(wd + ((size_t)(ci0 + c) * kk + tp) * Co + co0) = *(const u32x4*)v;
+            }
+        } else {
+            for (unsigned i = threadIdx.x; i < NCO * row; i += 256) {
+                const unsigned r = i / row, e = i - r * row, c = e / kk, tp = e - c * kk;
+                if (co0 + r < Co) {
+                    const T v = tile[r * pitch + e];
+                    wf[((size_t)(co0 + r) * kk + tp) * Ci + ci0 + c] = v;
+                    wd[((size_t)(ci0 + c) * kk + tp) * Co + co0 + r] = v;
                 }
             }
         }
-        __syncthreads();
-        for (unsigned i = threadIdx.x; i < CP_TCO * row; i += 256) {
-            // [co][t][ci]: ci fastest
-            const unsigned c = i % TCI, q = i / TCI;
-            const unsigned tp = q % kk, r = q / kk;
-            if (co0 + r < Co && ci0 + c < Ci)
-                Elem<T>::store(wf + ((size_t)(co0 + r) * kk + tp) * Ci + ci0 + c, tile[r * pitch + c * kk + tp]);
+    }
+}
+
+// Type 4: the K-slice slabs of a conv / conv-transpose weight gradient, [ks][co][t][ci] f32 (rbvae_wgrad_gemm), summed
+// in slab order into the torch layout [co][ci][t].  A workgroup owns one output channel (and a block of <= CRD_CI input
+// channels): every slab's [t][ci] rows come in by 16-byte loads, all of a thread's loads in flight together, the sums
+// change order through LDS and leave as 16-byte stores of the contiguous [ci][t] row.
+constexpr int CRD_CI = 256, CRD_MAXKK = 16, CRD_ACC = CRD_CI * CRD_MAXKK / 4 / 256;      // float4 accumulators per thread
+__device__ __forceinline__ void conv_reduce_rows(const Job& j, float* tile) {
+    const unsigned Co = (unsigned)j.d0, Ci = (unsigned)j.d1, kk = (unsigned)j.d2, ns = (unsigned)j.nslab;
+    const unsigned ncb = (Ci + CRD_CI - 1) / CRD_CI;
+    float* out = (float*)j.dst;
+    for (unsigned b = blockIdx.x; b < Co * ncb; b += gridDim.x) {
+        const unsigned co = b / ncb, ci0 = (b % ncb) * CRD_CI;
+        const unsigned cn = min((unsigned)CRD_CI, Ci - ci0);       // multiple of 4 (host-checked)
+        const unsigned c4 = cn / 4, nch = kk * c4, pitch = cn + 1;
+        float4 acc[CRD_ACC];
+#pragma unroll
+        for (int a = 0; a < CRD_ACC; ++a) acc[a] = make_float4(0.f, 0.f, 0.f, 0.f);
+        const float* base = j.src + ((size_t)co * kk) * Ci + ci0;
+        for (unsigned k = 0; k < ns; ++k) {                        // slab order: fixed, reproducible
+            const float* p = base + (size_t)k * j.slab;
+            float4 v[CRD_ACC];
+#pragma unroll
+            for (int a = 0; a < CRD_ACC; ++a) {
+                const unsigned i = threadIdx.x + a * 256;
+                const unsigned ic = i < nch ? i : 0, tp = ic / c4, q = ic - tp * c4;
+                v[a] = *(const float4*)(p + (size_t)tp * Ci + 4 * q);
+            }
+#pragma unroll
+            for (int a = 0; a < CRD_ACC; ++a) {
+                acc[a].x += v[a].x; acc[a].y += v[a].y; acc[a].z += v[a].z; acc[a].w += v[a].w;
+            }
         }
-        for (unsigned i = threadIdx.x; i < CP_TCO * row; i += 256) {
-            // [ci][t][co]: co fastest
-            const unsigned r = i % CP_TCO, q = i / CP_TCO;
-            const unsigned tp = q % kk, c = q / kk;
-            if (co0 + r < Co && ci0 + c < Ci)
-                Elem<T>::store(wd + ((size_t)(ci0 + c) * kk + tp) * Co + co0 + r, tile[r * pitch + c * kk + tp]);
+        __syncthreads();
+#pragma unroll
+        for (int a = 0; a < CRD_ACC; ++a) {
+            const unsigned i = threadIdx.x + a * 256;
+            if (i < nch) {
+                const unsigned tp = i / c4, q = i - tp * c4;
+                float* d = tile + tp * pitch + 4 * q;
+                d[0] = acc[a].x * j.scale; d[1] = acc[a].y * j.scale; d[2] = acc[a].z * j.scale; d[3] = acc[a].w * j.scale;
+            }
+        }
+        __syncthreads();
+        // the output row [co][ci0 .. ci0 + cn)[kk] is cn * kk contiguous floats
+        float* orow = out + ((size_t)co * Ci + ci0) * kk;
+        const unsigned n4 = cn * kk / 4;
+        for (unsigned i = threadIdx.x; i < n4; i += 256) {
+            float4 o;
+            float* op = (float*)&o;
+#pragma unroll
+            for (unsigned u = 0; u < 4; ++u) {
+                const unsigned e = 4 * i + u, c = e / kk, tp = e - c * kk;
+                op[u] = tile[tp * pitch + c];
+            }
+            if (j.accumulate) {
+                const float4 w = *(const float4*)(orow + 4 * i);
+                o.x += w.x; o.y += w.y; o.z += w.z; o.w += w.w;
+            }
+            *(float4*)(orow + 4 * i) = o;
         }
     }
 }
 
 __global__ __launch_bounds__(256) void run_jobs_k(const Job* __restrict__ jobs) {
-    __shared__ float cp_tile[CP_LDSF];
+    __shared__ __attribute__((aligned(16))) unsigned char lds_raw[CPK_LDS_BYTES];
+    static_assert(CPK_LDS_BYTES >= (int)sizeof(float) * CRD_MAXKK * (CRD_CI + 1), "the reduce tile fits the pack tile");
     const Job j = jobs[blockIdx.y];
     if (j.type == 3) {
-        const bool f32 = j.dtype == RBVAE_F32;
-        if (j.d2 == 9) { if (f32) conv_pack_tile<float, 9>(j, cp_tile); else conv_pack_tile<bf16_t, 9>(j, cp_tile); }
-        else if (j.d2 == 16) { if (f32) conv_pack_tile<float, 16>(j, cp_tile); else conv_pack_tile<bf16_t, 16>(j, cp_tile); }
-        else { if (f32) conv_pack_tile<float, 0>(j, cp_tile); else conv_pack_tile<bf16_t, 0>(j, cp_tile); }
+        if (j.dtype == RBVAE_F32) conv_pack_rows<float>(j, lds_raw); else conv_pack_rows<bf16_t>(j, lds_raw);
+        return;
+    }
+    if (j.type == 4) {
+        conv_reduce_rows(j, (float*)lds_raw);
         return;
     }
     const unsigned d0 = (unsigned)j.d0, d1 = (unsigned)j.d1, d2 = (unsigned)j.d2;

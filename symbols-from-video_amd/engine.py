@@ -12,6 +12,7 @@ Reference path restated by the kernels this file sequences:
 from __future__ import annotations
 
 import math
+import os
 from dataclasses import dataclass
 from typing import Dict, List, Optional, Sequence, Tuple
 
@@ -138,7 +139,7 @@ def dgrad_classes(k: int) -> Tuple[List[int], int]:
 
 ONE_TAP = [1, 0, 0, 0, 0, 0]
 
-JOB_PACK, JOB_PERMUTE, JOB_ROWS, JOB_CONV_PACK = 0, 1, 2, 3
+JOB_PACK, JOB_PERMUTE, JOB_ROWS, JOB_CONV_PACK, JOB_CONV_REDUCE = 0, 1, 2, 3, 4
 
 
 class JobList:
@@ -172,6 +173,14 @@ class JobList:
         self.rows.append([JOB_CONV_PACK, src.data_ptr(), wf.data_ptr(), co, ci, kk, 0, 0, 0, 1, 0, dtype, 0, 0, 0,
                           wd.data_ptr()])
         self.keep += [src, wf, wd]
+
+    def add_conv_reduce(self, slabs, dst, co, ci, kk, nslab, scale=1.0):
+        """K-slice slabs [nslab][co][kk][ci] of a conv weight gradient -> torch layout [co][ci][kk], coalesced."""
+        import struct
+        bits = struct.unpack("<I", struct.pack("<f", float(scale)))[0]
+        self.rows.append([JOB_CONV_REDUCE, slabs.data_ptr(), dst.data_ptr(), co, ci, kk, 0, 0, 0, nslab, co * kk * ci, 0, 0,
+                          bits, 0, 0])
+        self.keep += [slabs, dst]
 
     def upload(self, device):
         return torch.tensor(self.rows, dtype=torch.int64).to(device)
@@ -315,6 +324,33 @@ class Engine:
             tab = tuple((p.upload(self.device), len(p.rows)) for p in parts) + (jl,)
             self._pack_tab[key] = tab
         return tab
+
+    def pack_group(self, flat: torch.Tensor, group: str):
+        """The packed copies of one optimiser-update group (FusedTrainer's early updates): "dec" = decoder CNN + both LSTM
+        stacks, "mid" = conv3 + encoder fc, "fin" = conv1 + conv2.  The three groups together are pack()."""
+        key = ("group", flat.data_ptr())
+        tab = self._pack_tab.get(key)
+        if tab is None:
+            jl = self._pack_jobs(flat)
+
+            def inside(ptr, t):
+                return t.data_ptr() <= ptr < t.data_ptr() + t.numel() * t.element_size()
+
+            dec = (self.V1f, self.V2f, self.V3p, self.V3f, self.Wdfc, self.WdfcT, self.bdfc, self.wT_enc, self.wT_dec)
+            mid = (self.W3f, self.Wfc, self.WfcT)
+            fin = (self.W1p, self.W2f)
+            parts = {"dec": JobList(), "mid": JobList(), "fin": JobList()}
+            for row in jl.rows:
+                g = next((n for n, ts in (("dec", dec), ("mid", mid), ("fin", fin)) if any(inside(row[2], t) for t in ts)), None)
+                if g is None:
+                    raise RuntimeError("pack job outside every update group")
+                parts[g].rows.append(row)
+            tab = {n: (p.upload(self.device), len(p.rows)) for n, p in parts.items()}
+            tab["_keep"] = jl
+            self._pack_tab[key] = tab
+        t, n = tab[group]
+        if n:
+            L.call("rbvae_run_jobs", t, n, 256)
 
     def pack_begin(self, flat: torch.Tensor):
         if not self._side_on(self.SIDE_PACK) and not self.pack_late_split:
@@ -460,7 +496,13 @@ class Engine:
         ks = max(ks, -(-P // 4096))            # the kernel keeps a K-slice's gather indices in LDS (<= 4096)
         slabs = self._buf(("slabs", tag), ks * Co * taps * Ci)
         L.call("rbvae_wgrad_gemm", self.dt, Dy, In, slabs, idx, self.zero, P, In.numel() // ldi, Co, Ci, ldy, ldi, taps, ks)
-        self._jobs.add(JOB_PERMUTE, slabs, out, dims, strides, nslab=ks, slab=Co * taps * Ci)
+        if (taps > 1 and taps <= 16 and tuple(dims) == (Co, Ci, taps) and tuple(strides) == (taps * Ci, 1, Ci)
+                and Ci % 4 == 0 and os.environ.get("RBVAE_CONV_REDUCE", "1") == "1"):
+            # conv / conv-transpose weight: the coalesced row kernel (16-byte loads of the slabs' [t][ci] rows, LDS
+            # transpose, 16-byte stores of the torch-layout row)
+            self._jobs.add_conv_reduce(slabs, out, Co, Ci, taps, ks)
+        else:
+            self._jobs.add(JOB_PERMUTE, slabs, out, dims, strides, nslab=ks, slab=Co * taps * Ci)
 
     def _colsum(self, dt, X, P, C, ld, out, tag=None):
         """Column sums of a tensor no GEMM epilogue produced: partial kernel now, final reduction as a job."""
@@ -755,7 +797,8 @@ class Engine:
     # ---- backward --------------------------------------------------------------
     def backward(self, flat: torch.Tensor, gflat: torch.Tensor, sv: Saved, g_xr: Optional[torch.Tensor],
                  g_hs: Optional[torch.Tensor], g_z: Optional[torch.Tensor], g_e: Optional[torch.Tensor] = None,
-                 kl_weight: float = 0.0, kl_p: float = 0.5, g_hs_inplace: bool = False, side_first=None, cut=None):
+                 kl_weight: float = 0.0, kl_p: float = 0.5, g_hs_inplace: bool = False, side_first=None, cut=None,
+                 updates=None):
         """Writes every parameter gradient into gflat (same layout as flat).
         g_xr: [S,T,C,H,W] upstream gradient of x_recon (None: use the fused dpre3 of forward()).
         g_hs / g_z: [S,T,L] upstream gradients of h_seq / z_seq (None = 0).
@@ -767,7 +810,14 @@ class Engine:
         cut: optional callable invoked once, on the main stream with every side stream joined, at the point where the
         gradients of decoder_cnn.* and both LSTM stacks (the contiguous tail of gflat from
         layout.offsets["decoder_cnn.fc.weight"]) are final and only the encoder CNN's remain to be computed: the
-        data-parallel trainer ends one graph and starts the next there and all-reduces that tail beside the rest."""
+        data-parallel trainer ends one graph and starts the next there and all-reduces that tail beside the rest.
+        updates: optional {"dec", "mid", "fin"} callables (single-GPU trainer: optimiser update + weight repack of one
+        parameter group each).  "dec" (decoder CNN + both LSTM stacks) and "mid" (conv2, conv3, encoder fc) are issued on
+        the side stream as soon as that group's gradients are final -- behind the decoder's early reduction, resp.
+        behind conv2's weight gradient with the group's own reduction in front -- so they run beside the remaining
+        data-gradient / weight-gradient GEMMs of the main stream; "fin" (conv1; conv2's repack, whose transposed copy the
+        last data-gradient GEMM still reads) follows the final reduction.  Without a side stream all three run at the
+        end.  Safe because nothing of this pass reads a group's weights once its gradients are final."""
         self._join()                       # side-stream work of forward() (after_hs)
         book_with_decoder = (side_first is not None and self.book_with_dec and self._side_on(self.SIDE_DEC_WGRAD)
                              and not self._side_on(self.SIDE_BOOK))
@@ -853,15 +903,18 @@ class Engine:
         # (_conv_idx), built here on the main stream before the fork
         self.prepare(N)
         self._fork(0, self.SIDE_DEC_WGRAD)
-        # with a cut the reductions queued so far (decoder bias sums: their producers ran before the fork) go with the
-        # decoder's early reduction, so that every decoder gradient is final at the cut
+        early_upd = (updates is not None and cut is None and self.main_first and self._side_on(self.SIDE_DEC_WGRAD))
+        # with a cut (or early updates) the reductions queued so far (decoder bias sums: their producers ran before the
+        # fork) go with the decoder's early reduction, so that every decoder gradient is final at the cut
         fork_jobs = None
-        if cut is not None:
+        if cut is not None or early_upd:
             fork_jobs, self._jobs = self._jobs, JobList()
+        mid_jobs = None
+        ev_lstm = ev_mid = None
 
         def issue_decoder_side():
-            early = (self._side_on(self.SIDE_DEC_WGRAD) and self._side_on(self.SIDE_DEC_REDUCE)) or cut is not None
-            main_jobs, self._jobs = self._jobs, (fork_jobs if cut is not None else JobList())
+            early = (self._side_on(self.SIDE_DEC_WGRAD) and self._side_on(self.SIDE_DEC_REDUCE)) or cut is not None or early_upd
+            main_jobs, self._jobs = self._jobs, (fork_jobs if (cut is not None or early_upd) else JobList())
             with self._on_side(0, self.SIDE_DEC_WGRAD):
                 if book_with_decoder:
                     side_first()        # the loss bookkeeping rides the side stream's existing fork: no edge of its own
@@ -872,6 +925,14 @@ class Engine:
                 else:
                     main_jobs.rows += self._jobs.rows
                     main_jobs.keep += self._jobs.keep
+                if early_upd:
+                    side = self._sides[0]
+                    side.wait_event(ev_lstm)            # the LSTM stacks' weight gradients (main stream)
+                    updates["dec"]()
+                    side.wait_event(ev_mid)             # conv2's weight gradient: the last producer of the mid group
+                    self._jobs = mid_jobs
+                    self._run_jobs()
+                    updates["mid"]()
             self._jobs = main_jobs
 
         defer_side = self.main_first and self._side_on(self.SIDE_DEC_WGRAD)
@@ -945,6 +1006,9 @@ class Engine:
                 self._jobs.add(JOB_ROWS, de_sums, G("encoder_cnn.fc.bias"), (1, 1, Ld), (0, 0, 1), nslab=S, slab=Ld)
             else:
                 self._colsum(F32, de, N, Ld, Ld, G("encoder_cnn.fc.bias"), tag=(N, "bfc"))
+            if early_upd:
+                ev_lstm = torch.cuda.Event()
+                ev_lstm.record(torch.cuda.current_stream())
         # --- encoder fc
         if de_pad is None:
             de_pad = tmp("de_pad", N, self.Lp)
@@ -977,7 +1041,13 @@ class Engine:
         # --- conv2
         self._wgrad(da2, sv.a1, self._conv_idx(N, h1, w1, h2, w2), P2, c2, c1, c2, c1, kk,
                     G(f"encoder_cnn.conv.{i1}.weight"), (c2, c1, kk), (kk * c1, 1, c1), tag=(N, "W2"))
-        if self._side_on(self.SIDE_ENC_REDUCE):
+        if early_upd:
+            # the mid group (conv2, conv3, encoder fc) is complete: its reduction, optimiser update and repack go to the
+            # side stream (issued with the deferred side work below); only conv1's pieces remain for the end
+            ev_mid = torch.cuda.Event()
+            ev_mid.record(torch.cuda.current_stream())
+            mid_jobs, self._jobs = self._jobs, JobList()
+        elif self._side_on(self.SIDE_ENC_REDUCE):
             # everything reducible so far (fc, conv3, conv2 slabs; the LSTM-side column sums) goes to the side stream
             # now, beside the last data-gradient GEMM and conv1's weight gradient; only those two's reductions
             # remain for the end of the pass
@@ -996,3 +1066,8 @@ class Engine:
         # every slab / partial-sum reduction of this pass in one launch, once the side stream has caught up
         self._join()
         self._run_jobs()
+        if updates is not None:
+            if not early_upd:
+                updates["dec"]()
+                updates["mid"]()
+            updates["fin"]()

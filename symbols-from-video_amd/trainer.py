@@ -99,6 +99,12 @@ class FusedTrainer:
         # one all-reduce of the whole buffer between the backward graph and the Adam graph.
         self.ddp_overlap = os.environ.get("RBVAE_DDP_OVERLAP", "1") == "1"
         self.fused_pair = os.environ.get("RBVAE_FUSED_PAIR", "1") == "1"
+        # Single GPU: the optimiser update and the weight repack run per parameter group as soon as the group's
+        # gradients are final, on the side stream beside the rest of the backward pass (engine.backward(updates=...)):
+        # the step no longer ends with reduce -> Adam -> (next step) repack in series.  RBVAE_EARLY_UPDATE=0: Adam over the
+        # whole buffer after the backward pass, repack at the start of the next step (the multi-GPU schedule).
+        self.early_update = self.world == 1 and os.environ.get("RBVAE_EARLY_UPDATE", "1") == "1"
+        self._packed_ver = None
 
     # ---- the two halves of a step (plain launches; captured below) ------------------
     def _fwd_bwd(self, x, U, tau, B, T, cut=None, masks=None):
@@ -135,7 +141,7 @@ class FusedTrainer:
         chw = numel // (2 * B * T)
         out = eng.forward(model._flat, x.view(2 * B, T, *x.shape[3:]), U, tau, False, self.r, bool(model.training), masks,
                           seed=self._noise_key, need_grad=True, target=x, recon_gscale=2.0 / numel, kl_p=self.p,
-                          after_hs=pair_term, defer_losses=True, repack=True,
+                          after_hs=pair_term, defer_losses=True, repack=not self.early_update,
                           frame_map=(B * T, T, T * chw, 2 * T * chw, chw), tau_dev=self.tau_dev)
         sse_ws, nparts, inv_n = out["sse"]
         kl_parts, nkl, kl_scale = out["kl"]
@@ -154,9 +160,29 @@ class FusedTrainer:
                    float(b1), float(b2), self.hyper)
 
         eng.backward(model._flat, self.gflat, out["saved"], None, g_hs, None, kl_weight=self.beta_kl, kl_p=self.p,
-                     g_hs_inplace=True, side_first=bookkeeping, cut=cut)
+                     g_hs_inplace=True, side_first=bookkeeping, cut=cut,
+                     updates=self._group_updates() if self.early_update else None)
+
+    def _group_updates(self):
+        """{"dec", "mid", "fin"}: Adam on one contiguous range of the flat buffer + the repack of that range's weights."""
+        eng, flat = self.eng, self.model._flat
+        lay = eng.layout
+        i0, i1, i2 = lay.conv_idx
+        o_c2, o_dec, n = lay.offsets[f"encoder_cnn.conv.{i1}.weight"], lay.offsets["decoder_cnn.fc.weight"], flat.numel()
+        b1, b2 = self.betas
+
+        def upd(lo, hi, group):
+            def run():
+                L.call("rbvae_adam_step", flat[lo:], self.gflat[lo:], self.m[lo:], self.vv[lo:], hi - lo, float(self.lr),
+                       float(b1), float(b2), float(self.eps), 0, 1.0 / self.world, None, self.hyper)
+                eng.pack_group(flat, group)
+            return run
+
+        return {"dec": upd(o_dec, n, "dec"), "mid": upd(o_c2, o_dec, "mid"), "fin": upd(0, o_c2, "fin")}
 
     def _update(self):
+        if self.early_update:
+            return                    # done group by group inside the backward pass
         b1, b2 = self.betas
         L.call("rbvae_adam_step", self.model._flat, self.gflat, self.m, self.vv, self.gflat.numel(), float(self.lr),
                float(b1), float(b2), float(self.eps), 0, 1.0 / self.world, None, self.hyper)
@@ -190,6 +216,13 @@ class FusedTrainer:
             self.eng.seed_dev = self.step_dev
         Ld = model.latent_dim
         self._data_active = from_data
+        if self.early_update:
+            # the step leaves every packed weight copy current; repack here only when the weights changed behind the
+            # trainer's back (first step, load_state_dict, a foreign optimiser)
+            ver = tuple(p._version for p in model._params())
+            if self._packed_ver != ver or model._packed_version != (id(self.eng), ver):
+                self.eng.pack(model._flat)
+                self._packed_ver = ver
         if U is None and not self.device_noise:
             U = torch.rand((2, B * T, Ld)).to(item.device)
         # temperature / lr travel through device scalars: they are NOT part of the graph key
@@ -232,7 +265,10 @@ class FusedTrainer:
                 self._allreduce()
                 g[1].replay()
         self.steps += 1
-        self.model._packed_version = None     # anything else that runs the model before the next step repacks first
+        if self.early_update:
+            self.model._packed_version = (id(self.eng), self._packed_ver)      # the packed copies are current
+        else:
+            self.model._packed_version = None  # anything else that runs the model before the next step repacks first
         return self.losses
 
     def validate(self, item: torch.Tensor, temperature: float, U: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -395,7 +431,7 @@ class FusedTrainer:
         if self._pool is None:
             self._pool = torch.cuda.graph_pool_handle()
         pool = self._pool
-        if self.world == 1 and self.one_graph:
+        if self.world == 1 and (self.one_graph or self.early_update):
             # no collective between backward and Adam: the whole step is one graph launch
             with torch.cuda.graph(g1, pool=pool):
                 self._fwd_bwd(x, U, tau, B, T)

@@ -632,3 +632,44 @@ def test_deconv_last_dgrad_fused(sfv, N, Cout, OH, OW, C1):
     out_c = torch.empty_like(out_a)
     L.call("rbvae_deconv_last_dgrad_fused", 1, dpre, Wp, zero, col_b, gate, out_c, N, Cout, OH, OW, C1, C1, 1.25, None)
     assert torch.equal(out_c.view(torch.int16), out_b.view(torch.int16))
+
+
+def _job_row(kind, src, dst, d0, d1, d2, nslab=1, slab=0, dtype=0, accumulate=0, scale=1.0, dst2=None):
+    import struct
+    bits = struct.unpack("<I", struct.pack("<f", float(scale)))[0]
+    return [kind, src.data_ptr(), dst.data_ptr(), d0, d1, d2, 0, 0, 0, nslab, slab, dtype, accumulate, bits, 0,
+            0 if dst2 is None else dst2.data_ptr()]
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("Co,Ci,kk", [(256, 256, 9), (64, 64, 9), (128, 64, 16), (256, 128, 16), (72, 40, 9), (36, 20, 4)])
+def test_conv_pack_job_both_orders(sfv, dtype, Co, Ci, kk):
+    """rbvae_run_jobs kind 3: f32 weight [co][ci][kk] -> [co][t][ci] and [ci][t][co] in the storage type (16-byte row
+    kernel; (36, 20, 4) takes its element-wise path)."""
+    dt, tdt, _ = DT[dtype]
+    g = torch.Generator().manual_seed(90)
+    w = torch.randn(Co, Ci, kk, generator=g)
+    src = w.cuda()
+    wf = torch.full((Co, kk, Ci), 7.0, dtype=tdt, device="cuda")
+    wd = torch.full((Ci, kk, Co), 7.0, dtype=tdt, device="cuda")
+    tab = torch.tensor([_job_row(3, src, wf, Co, Ci, kk, dtype=dt, dst2=wd)], dtype=torch.int64).cuda()
+    sfv._lib.call("rbvae_run_jobs", tab, 1, 256)
+    assert torch.equal(wf.cpu(), w.permute(0, 2, 1).to(tdt)) and torch.equal(wd.cpu(), w.permute(1, 2, 0).to(tdt))
+
+
+@pytest.mark.parametrize("Co,Ci,kk,ks,acc", [(256, 256, 9, 7, 0), (64, 64, 9, 3, 1), (128, 64, 16, 2, 0), (8, 520, 9, 5, 0),
+                                             (16, 12, 4, 1, 0)])
+def test_conv_reduce_job_matches_permute_reduce(sfv, Co, Ci, kk, ks, acc):
+    """rbvae_run_jobs kind 4 (coalesced rows, LDS transpose) == rbvae_permute_reduce (one thread per output), bit for
+    bit: both add the slabs in slab order."""
+    g = torch.Generator().manual_seed(91)
+    slabs = torch.randn(ks, Co, kk, Ci, generator=g).cuda()
+    base = torch.randn(Co, Ci, kk, generator=g).cuda()
+    ref, out = base.clone(), base.clone()
+    sfv._lib.call("rbvae_permute_reduce", slabs, ks, Co * kk * Ci, ref, Co, Ci, kk, kk * Ci, 1, Ci, 0.5, acc)
+    tab = torch.tensor([_job_row(4, slabs, out, Co, Ci, kk, nslab=ks, slab=Co * kk * Ci, accumulate=acc, scale=0.5)],
+                       dtype=torch.int64).cuda()
+    sfv._lib.call("rbvae_run_jobs", tab, 1, 256)
+    want = slabs.sum(0).permute(0, 2, 1) * 0.5 + (base if acc else 0)
+    assert torch.allclose(out, want, atol=1e-5, rtol=1e-5)
+    assert torch.equal(out, ref)

@@ -17,11 +17,12 @@ for i, r in enumerate(rows):
         rows = rows[:i]
         break
 names = [r["Kernel_Name"] for r in rows]
-marks = [i for i, n in enumerate(names) if "counter_add" in n]
+# one marker per step: the first kernel of a step (the batch gather), else the first conv
+marks = [i for i, n in enumerate(names) if "gather_frames_k" in n]
 if len(marks) < 12:
-    marks = [i for i, n in enumerate(names) if "pack3" in n or "cast_pad_k" in n and False]
+    marks = [i for i, n in enumerate(names) if "conv_first_fused_k<4, 0>" in n or "conv_first_fused_k<3, 0>" in n]
 if len(marks) < 12:
-    marks = [i for i, n in enumerate(names) if "adam_k" in n]
+    marks = [i for i, n in enumerate(names) if "combine_losses_k" in n]
 a, b = marks[-16], marks[-6]          # 10 graph-replayed steps (the last few before the cut are the eager warm-ups of the instrumented leg)
 steps = 10
 agg = collections.OrderedDict()
