@@ -51,12 +51,28 @@ __device__ __forceinline__ void conv_pack_rows(const Job& j, unsigned char* lds_
         __syncthreads();
         // ---- in: NCO rows of `row` consecutive floats each
         if (vec_ok) {
-            const unsigned r4 = row / 4;
-            for (unsigned i = threadIdx.x; i < NCO * r4; i += 256) {
-                const unsigned r = i / r4, q = i - r * r4;
-                const float4 v = *(const float4*)(j.src + ((size_t)(co0 + r) * Ci + ci0) * kk + 4 * q);
-                T* d = tile + r * pitch + 4 * q;
-                Elem<T>::store(d, v.x); Elem<T>::store(d + 1, v.y); Elem<T>::store(d + 2, v.z); Elem<T>::store(d + 3, v.w);
+            // every load of the thread in flight before the first LDS store (a load per loop iteration paid a memory
+            // round trip each: 18 of them per workgroup)
+            const unsigned r4 = row / 4, tot = NCO * r4;
+            constexpr unsigned LB = 9;                                     // loads in flight per thread and batch
+            for (unsigned i0 = threadIdx.x; i0 < tot; i0 += LB * 256) {   // 2 batches (bf16) / 1 (f32) at 256 x 9
+                float4 v[LB];
+#pragma unroll
+                for (unsigned u = 0; u < LB; ++u) {
+                    const unsigned i = i0 + u * 256, ic = i < tot ? i : 0;
+                    const unsigned r = ic / r4, q = ic - r * r4;
+                    v[u] = *(const float4*)(j.src + ((size_t)(co0 + r) * Ci + ci0) * kk + 4 * q);
+                }
+#pragma unroll
+                for (unsigned u = 0; u < LB; ++u) {
+                    const unsigned i = i0 + u * 256;
+                    if (i < tot) {
+                        const unsigned r = i / r4, q = i - r * r4;
+                        T* d = tile + r * pitch + 4 * q;
+                        Elem<T>::store(d, v[u].x); Elem<T>::store(d + 1, v[u].y); Elem<T>::store(d + 2, v[u].z);
+                        Elem<T>::store(d + 3, v[u].w);
+                    }
+                }
             }
         } else {
             for (unsigned i = threadIdx.x; i < NCO * row; i += 256) {
@@ -114,19 +130,38 @@ __device__ __forceinline__ void conv_reduce_rows(const Job& j, float* tile) {
 #pragma unroll
         for (int a = 0; a < CRD_ACC; ++a) acc[a] = make_float4(0.f, 0.f, 0.f, 0.f);
         const float* base = j.src + ((size_t)co * kk) * Ci + ci0;
-        for (unsigned k = 0; k < ns; ++k) {                        // slab order: fixed, reproducible
+        // this thread's chunk offsets inside a slab (the same for every slab)
+        unsigned off[CRD_ACC];
+        const int na = (int)((nch + 255) / 256);                     // uniform: accumulators in use
+#pragma unroll
+        for (int a = 0; a < CRD_ACC; ++a) {
+            const unsigned i = threadIdx.x + a * 256;
+            const unsigned ic = i < nch ? i : 0, tp = ic / c4, q = ic - tp * c4;
+            off[a] = tp * Ci + 4 * q;
+        }
+        unsigned k = 0;
+        for (; k + 2 <= ns; k += 2) {                              // two slabs' loads in flight; added in slab order
+            float4 v[2][CRD_ACC];
+#pragma unroll
+            for (int s4 = 0; s4 < 2; ++s4)
+#pragma unroll
+                for (int a = 0; a < CRD_ACC; ++a)
+                    if (a < na) v[s4][a] = *(const float4*)(base + (size_t)(k + s4) * j.slab + off[a]);
+#pragma unroll
+            for (int s4 = 0; s4 < 2; ++s4)
+#pragma unroll
+                for (int a = 0; a < CRD_ACC; ++a)
+                    if (a < na) { acc[a].x += v[s4][a].x; acc[a].y += v[s4][a].y; acc[a].z += v[s4][a].z; acc[a].w += v[s4][a].w; }
+        }
+        for (; k < ns; ++k) {                                      // slab order: fixed, reproducible
             const float* p = base + (size_t)k * j.slab;
             float4 v[CRD_ACC];
 #pragma unroll
-            for (int a = 0; a < CRD_ACC; ++a) {
-                const unsigned i = threadIdx.x + a * 256;
-                const unsigned ic = i < nch ? i : 0, tp = ic / c4, q = ic - tp * c4;
-                v[a] = *(const float4*)(p + (size_t)tp * Ci + 4 * q);
-            }
+            for (int a = 0; a < CRD_ACC; ++a)
+                if (a < na) v[a] = *(const float4*)(p + off[a]);
 #pragma unroll
-            for (int a = 0; a < CRD_ACC; ++a) {
-                acc[a].x += v[a].x; acc[a].y += v[a].y; acc[a].z += v[a].z; acc[a].w += v[a].w;
-            }
+            for (int a = 0; a < CRD_ACC; ++a)
+                if (a < na) { acc[a].x += v[a].x; acc[a].y += v[a].y; acc[a].z += v[a].z; acc[a].w += v[a].w; }
         }
         __syncthreads();
 #pragma unroll

@@ -254,6 +254,7 @@ class Engine:
         self.main_first = os.environ.get("RBVAE_MAIN_FIRST", "1") == "1"
         self._ks_force = int(os.environ.get("RBVAE_WG_KS", "0"))
         self.book_with_dec = os.environ.get("RBVAE_BOOK_WITH_DEC", "1") == "1"
+        self.wfc_side = os.environ.get("RBVAE_WFC_SIDE", "1") == "1"
         # RBVAE_STREAM_GEMM=1 sends the K = 64 products of the 3/4-channel ends to the row-streaming kernel
         # (rbvae_stream_gemm) instead of the tiled gather GEMM.  Bit-identical results; measured on the bench shapes
         # (tools/abl_stream.py): conv1 forward 17.5 -> 15.4-16.6 us, last-deconv backward (gate + column sums)
@@ -911,6 +912,7 @@ class Engine:
             fork_jobs, self._jobs = self._jobs, JobList()
         mid_jobs = None
         ev_lstm = ev_mid = None
+        side_tail = []                # (event, callable): issued on the side stream behind the decoder's weight gradients
 
         def issue_decoder_side():
             early = (self._side_on(self.SIDE_DEC_WGRAD) and self._side_on(self.SIDE_DEC_REDUCE)) or cut is not None or early_upd
@@ -925,6 +927,13 @@ class Engine:
                 else:
                     main_jobs.rows += self._jobs.rows
                     main_jobs.keep += self._jobs.keep
+                # late side work: launches of the main chain's own products that nothing on that chain waits for; their
+                # reduction jobs join the final reduction
+                self._jobs = main_jobs
+                for ev, fn in side_tail:
+                    self._sides[0].wait_event(ev)
+                    fn()
+                main_jobs = self._jobs
                 if early_upd:
                     side = self._sides[0]
                     side.wait_event(ev_lstm)            # the LSTM stacks' weight gradients (main stream)
@@ -1013,8 +1022,20 @@ class Engine:
         if de_pad is None:
             de_pad = tmp("de_pad", N, self.Lp)
             L.call("rbvae_cast_pad", self.dt, de, de_pad, N, Ld, self.Lp)
-        self._wgrad(de_pad, sv.a3, None, N, self.Lp, self.F3, self.Lp, self.F3, 1, G("encoder_cnn.fc.weight"),
-                    (Ld, c3, g3), (self.F3, 1, c3), tag=(N, "Wfc"))
+        def wfc_wgrad():
+            self._wgrad(de_pad, sv.a3, None, N, self.Lp, self.F3, self.Lp, self.F3, 1, G("encoder_cnn.fc.weight"),
+                        (Ld, c3, g3), (self.F3, 1, c3), tag=(N, "Wfc"))
+
+        # The encoder fc's weight gradient is a 32-workgroup launch nothing on the data-gradient chain waits for: with
+        # the deferred side work it rides the side stream (behind an event on de_pad), so the main chain goes
+        # straight on to the next data-gradient GEMM instead of queueing it behind a full chip (18 us in the step)
+        wfc_on_side = (defer_side and cut is None and not early_upd and self.wfc_side)
+        if wfc_on_side:
+            ev_de = torch.cuda.Event()
+            ev_de.record(torch.cuda.current_stream())
+            side_tail.append((ev_de, wfc_wgrad))
+        else:
+            wfc_wgrad()
         da3 = tmp("da3", P3, c3)
         # the GEMM sees da3 as [N][F3]; its fused column sums [m-tiles][F3] are [m-tiles*g3][c3] rows,
         # so the conv3 bias gradient is one row-reduce job over them

@@ -99,11 +99,13 @@ class FusedTrainer:
         # one all-reduce of the whole buffer between the backward graph and the Adam graph.
         self.ddp_overlap = os.environ.get("RBVAE_DDP_OVERLAP", "1") == "1"
         self.fused_pair = os.environ.get("RBVAE_FUSED_PAIR", "1") == "1"
-        # Single GPU: the optimiser update and the weight repack run per parameter group as soon as the group's
-        # gradients are final, on the side stream beside the rest of the backward pass (engine.backward(updates=...)):
-        # the step no longer ends with reduce -> Adam -> (next step) repack in series.  RBVAE_EARLY_UPDATE=0: Adam over the
-        # whole buffer after the backward pass, repack at the start of the next step (the multi-GPU schedule).
-        self.early_update = self.world == 1 and os.environ.get("RBVAE_EARLY_UPDATE", "1") == "1"
+        # RBVAE_EARLY_UPDATE=1 (single GPU, experiment, off): the optimiser update and the weight repack run per parameter
+        # group as soon as the group's gradients are final, on the side stream beside the rest of the backward pass
+        # (engine.backward(updates=...)), instead of reduce -> Adam -> (next step) repack in series at the step boundary.
+        # Measured on one GPU (tools/sweep_env.sh, same box): 0.475 vs 0.470 ms/step -- the byte-moving kernels and the
+        # GEMMs beside them share the memory system, each slows the other by what the overlap would have saved
+        # (last data-gradient GEMM 32 -> 50 us, Adam on half the buffer 15.5 us instead of 6.5): default = the plain order.
+        self.early_update = self.world == 1 and os.environ.get("RBVAE_EARLY_UPDATE", "0") == "1"
         self._packed_ver = None
 
     # ---- the two halves of a step (plain launches; captured below) ------------------

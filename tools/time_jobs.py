@@ -16,7 +16,7 @@ for _ in range(3):
     tr.step(item, 0.7)
 torch.cuda.synchronize()
 eng = list(model._engines.values())[0]
-names = {0: "pack", 1: "permute_reduce", 2: "reduce_rows", 3: "conv_pack"}
+names = {0: "pack", 1: "permute_reduce", 2: "reduce_rows", 3: "conv_pack", 4: "conv_reduce"}
 def time_tab(label, tab, n, jl):
     """GPU-side duration of the whole table and of every job alone: the launches are queued behind a device-side
     sleep, so the event pairs bracket kernels, not host launch latency."""
@@ -32,7 +32,7 @@ def time_tab(label, tab, n, jl):
         return [a.elapsed_time(b) * 1e3 for a, b in evs]
     timed([(tab, n)])
     whole = timed([(tab, n)] * 3)
-    each = timed([(tab[i:], 1) for i in range(n)])
+    each = timed([(tab[i:i + 1].contiguous(), 1) for i in range(n)])
     print(f"{label}: {n} jobs, all together {min(whole):.1f} us (event pair overhead ~4.8 us included)")
     for i, r in enumerate(jl.rows):
         print(f"  job {i:2d} {names[r[0]]:15s} dims=({r[3]},{r[4]},{r[5]}) strides=({r[6]},{r[7]},{r[8]}) nslab={r[9]} fast={r[13] >> 32} inner={r[14]}: {each[i]:6.1f} us")
