@@ -244,13 +244,15 @@ def forward(variant: str, p: Dict[str, Tensor], x: Tensor, U: Tensor,
 
 
 def encode(variant: str, p: Dict[str, Tensor], x: Tensor, U: Tensor,
-           temperature: float = 0.5, hard: bool = False, noise_ratio: float = 0.1) -> Tensor:
-    """Seq2SeqBinaryVAE.encode (percep_RBVAE_model.py:172-191)."""
+           temperature: float = 0.5, hard: bool = False, noise_ratio: float = 0.1, train: bool = False,
+           masks: Optional[Sequence[Tensor]] = None) -> Tensor:
+    """Seq2SeqBinaryVAE.encode (percep_RBVAE_model.py:172-191).  The reference's encode() calls self.encoder_cnn in
+    whatever mode the module is in: train=True = its two Dropout layers live (explicit keep-masks in `masks`)."""
     v = VARIANTS[variant]
     B, T, C, H, W = x.shape
     L = p["encoder_cnn.fc.bias"].shape[0]
     r = noise_ratio if v.noise_ratio_arg else 1.0
-    e = encoder_cnn(v, p, x.reshape(B * T, C, H, W), False, None)
+    e = encoder_cnn(v, p, x.reshape(B * T, C, H, W), train, masks)
     hs = lstm_stack(e.reshape(B, T, L), p, "encoder_rnn", v.lstm_layers)
     z = binarize(hs.reshape(B * T, L), U, temperature, hard, r, v.eps)
     return z.reshape(B, T, L)

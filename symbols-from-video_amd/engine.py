@@ -255,6 +255,8 @@ class Engine:
         self._ks_force = int(os.environ.get("RBVAE_WG_KS", "0"))
         self.book_with_dec = os.environ.get("RBVAE_BOOK_WITH_DEC", "1") == "1"
         self.wfc_side = os.environ.get("RBVAE_WFC_SIDE", "1") == "1"
+        self.lstm_wgrad_tail = os.environ.get("RBVAE_LSTM_WGRAD_TAIL", "1") == "1"
+        self.tail_wgrads = int(os.environ.get("RBVAE_TAIL_WGRADS", "0"))
         # RBVAE_STREAM_GEMM=1 sends the K = 64 products of the 3/4-channel ends to the row-streaming kernel
         # (rbvae_stream_gemm) instead of the tiled gather GEMM.  Bit-identical results; measured on the bench shapes
         # (tools/abl_stream.py): conv1 forward 17.5 -> 15.4-16.6 us, last-deconv backward (gate + column sums)
@@ -1006,11 +1008,24 @@ class Engine:
             L.call("rbvae_binarize_kl_bwd", dz, sv.y, sv.z, de, 0, N, Ld, float(sv.tau), None, 0.0, None, 0.5, 1e-10, 0)
             if g_e is not None:
                 de = de + g_e.reshape(N, Ld)
-        # LSTM weight gradients (few workgroups, latency bound) ride the side stream beside the encoder CNN backward
-        self._side_wait_main(0, self.SIDE_LSTM_WGRAD)
-        with self._on_side(0, self.SIDE_LSTM_WGRAD):
+        # Side-stream tail (behind the decoder's weight gradients, each piece behind an event on its inputs): launches
+        # of the main chain's products that nothing on the chain waits for
+        tail_ok = defer_side and cut is None and not early_upd
+
+        def lstm_wgrads():
             L.call("rbvae_lstm_wgrad_pair", dG, sv.hs_dec, sv.hp_dec, G("decoder_rnn.lstm.weight_ih_l0"),
                    dGe, sv.hs_enc, sv.hp_enc, G("encoder_rnn.lstm.weight_ih_l0"), S, T, Ld, nl, 0)
+
+        lstm_on_tail = tail_ok and self.lstm_wgrad_tail and not self._side_on(self.SIDE_LSTM_WGRAD)
+        if lstm_on_tail:
+            ev_bptt = torch.cuda.Event()
+            ev_bptt.record(torch.cuda.current_stream())
+            side_tail.append((ev_bptt, lstm_wgrads))
+        # (RBVAE_SIDE bit 16: the older form -- the side stream waits for the whole main stream at this point)
+        self._side_wait_main(0, self.SIDE_LSTM_WGRAD)
+        with self._on_side(0, self.SIDE_LSTM_WGRAD):
+            if not lstm_on_tail:
+                lstm_wgrads()
             if de_sums is not None and g_e is None:
                 self._jobs.add(JOB_ROWS, de_sums, G("encoder_cnn.fc.bias"), (1, 1, Ld), (0, 0, 1), nslab=S, slab=Ld)
             else:
@@ -1029,7 +1044,7 @@ class Engine:
         # The encoder fc's weight gradient is a 32-workgroup launch nothing on the data-gradient chain waits for: with
         # the deferred side work it rides the side stream (behind an event on de_pad), so the main chain goes
         # straight on to the next data-gradient GEMM instead of queueing it behind a full chip (18 us in the step)
-        wfc_on_side = (defer_side and cut is None and not early_upd and self.wfc_side)
+        wfc_on_side = tail_ok and self.wfc_side
         if wfc_on_side:
             ev_de = torch.cuda.Event()
             ev_de.record(torch.cuda.current_stream())
@@ -1044,9 +1059,20 @@ class Engine:
         self._gemm(de_pad, self.WfcT, da3, None, sv.a3 if v.simple_order else None, None, N, 1, 1, 1, 1, 1, 1, 1, 1,
                    self.Lp, self.F3, self.Lp, self.F3, 1, "one", colsum_ws=ws3)
         self._jobs.add(JOB_ROWS, ws3, G(f"encoder_cnn.conv.{i2}.bias"), (1, 1, c3), (0, 0, 1), nslab=mt * g3, slab=c3)
+        def on_tail(bit, fn):
+            """Encoder weight gradient `bit` of RBVAE_TAIL_WGRADS: on the side stream's tail behind an event on its
+            inputs (the data-gradient chain then runs ahead), else here on the main stream."""
+            if tail_ok and (self.tail_wgrads & bit):
+                ev = torch.cuda.Event()
+                ev.record(torch.cuda.current_stream())
+                side_tail.append((ev, fn))
+            else:
+                fn()
+
         # --- conv3
-        self._wgrad(da3, sv.a2, self._conv_idx(N, h2, w2, h3, w3), P3, c3, c2, c3, c2, kk,
-                    G(f"encoder_cnn.conv.{i2}.weight"), (c3, c2, kk), (kk * c2, 1, c2), tag=(N, "W3"))
+        idx3, idx2 = self._conv_idx(N, h2, w2, h3, w3), self._conv_idx(N, h1, w1, h2, w2)
+        on_tail(1, lambda: self._wgrad(da3, sv.a2, idx3, P3, c3, c2, c3, c2, kk, G(f"encoder_cnn.conv.{i2}.weight"),
+                                       (c3, c2, kk), (kk * c2, 1, c2), tag=(N, "W3")))
         da2 = tmp("da2", P2, c2)
         self._gemm(da3, self.W3d, da2, None, sv.a2, None, N, h3, w3, h3, w3, 1, h2, w2, 2, c3, c2, c3, c2, kk, "dgrad",
                    scale=gs, bias_grad=G(f"encoder_cnn.conv.{i1}.bias"), tag=(N, "da2"))
@@ -1060,8 +1086,8 @@ class Engine:
             self._join()
             cut()
         # --- conv2
-        self._wgrad(da2, sv.a1, self._conv_idx(N, h1, w1, h2, w2), P2, c2, c1, c2, c1, kk,
-                    G(f"encoder_cnn.conv.{i1}.weight"), (c2, c1, kk), (kk * c1, 1, c1), tag=(N, "W2"))
+        on_tail(2, lambda: self._wgrad(da2, sv.a1, idx2, P2, c2, c1, c2, c1, kk, G(f"encoder_cnn.conv.{i1}.weight"),
+                                       (c2, c1, kk), (kk * c1, 1, c1), tag=(N, "W2")))
         if early_upd:
             # the mid group (conv2, conv3, encoder fc) is complete: its reduction, optimiser update and repack go to the
             # side stream (issued with the deferred side work below); only conv1's pieces remain for the end
@@ -1080,8 +1106,9 @@ class Engine:
         self._gemm(da2, self.W2d, da1, None, sv.a1, None, N, h2, w2, h2, w2, 1, h1, w1, 2, c2, c1, c2, c1, kk, "dgrad",
                    scale=gs, bias_grad=G(f"encoder_cnn.conv.{i0}.bias"), tag=(N, "da1"))
         # --- conv1 (1-tap GEMM over the saved im2col columns)
-        self._wgrad(da1, sv.col1, None, P1, c1, self.K1, c1, self.K1, 1, G(f"encoder_cnn.conv.{i0}.weight"),
-                    (c1, self.in_ch, kk), (self.K1, 1, self.in_ch), tag=(N, "W1"))
+        on_tail(4, lambda: self._wgrad(da1, sv.col1, None, P1, c1, self.K1, c1, self.K1, 1,
+                                       G(f"encoder_cnn.conv.{i0}.weight"), (c1, self.in_ch, kk),
+                                       (self.K1, 1, self.in_ch), tag=(N, "W1")))
         if defer_side:
             issue_decoder_side()
         # every slab / partial-sum reduction of this pass in one launch, once the side stream has caught up

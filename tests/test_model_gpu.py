@@ -136,12 +136,35 @@ def test_bf16_mode_tracks_f32(sfv, name):
     for k in ("total", "recon", "kl", "pair"):
         ref = float(g[f"loss/{k}"])
         assert abs(res[k].item() - ref) < 2e-2 * max(abs(ref), 1.0), (k, res[k].item(), ref)
-    res["total"].backward()
-    worst = 0.0
-    for k, p in zip(m.state_dict().keys(), m.parameters()):
-        n_ref = float(g[f"gradnorm/{k}"])
-        worst = max(worst, abs(float(p.grad.double().norm()) - n_ref) / max(n_ref, 1e-9))
-    assert worst < 0.1, worst
+    # Gradients -- direction, not just norm: the same case through the fused trainer (which exposes the device's ReLU
+    # decisions, tests/_gates.py) against the f64 oracle under those decisions, every tensor by relative L2.  bf16
+    # storage resolves thousands of ReLU ties differently from an f32 run; against a reference that does not share them
+    # a 128-element LSTM bias of norm 1e-6 moves by 30 % (measured), which says nothing about the kernels.
+    from importlib import import_module
+    from _gates import count_ties, device_gates
+    FusedTrainer = import_module("symbols-from-video_amd.trainer").FusedTrainer
+    _, m2 = build(sfv, g, dtype="bf16")
+    m2.train(train)
+    w0 = {k: v.detach().cpu().clone() for k, v in m2.state_dict().items()}
+    B, T = item.shape[0], item.shape[2]
+    tr = FusedTrainer(m2, lr=1e-3, alpha=float(g["meta/alpha"]), beta_kl=float(g["meta/beta"]),
+                      bernoulli_p=float(g["meta/bern_p"]), noise_ratio=float(g["meta/noise_ratio"]),
+                      margin=float(g["meta/margin"]), device_noise=False, use_graph=False)
+    tr.step(item, float(g["meta/tau"]), U=torch.stack(U), dropout_masks=masks)
+    gates, pre = device_gates(tr, B, T), []
+    p64 = {k: v.double().requires_grad_() for k, v in w0.items()}
+    r64 = O.step_losses(variant, p64, item.cpu().double(), [u.cpu().double() for u in U], float(g["meta/tau"]),
+                        float(g["meta/noise_ratio"]), float(g["meta/bern_p"]), float(g["meta/alpha"]), float(g["meta/beta"]),
+                        float(g["meta/margin"]), train=train,
+                        masks=None if masks is None else [[x.double() for x in mm] for mm in masks], gates=gates, pre=pre)
+    r64["total"].backward()
+    ties = count_ties(pre, gates, masks, 0.1)
+    lay, worst = tr.eng.layout, ("", 0.0)
+    for k in lay.names:
+        a, b = lay.view(tr.gflat, k).cpu().double().reshape(-1), p64[k].grad.reshape(-1)
+        worst = max(worst, (k, float((a - b).norm() / max(float(b.norm()), 1e-30))), key=lambda t: t[1])
+    print(f"bf16 {name}: {ties} ReLU ties, worst gradient rel-L2 {worst[1]:.2e} ({worst[0]})")
+    assert worst[1] < 1.5e-2, worst            # measured 5.3e-3 / 4.8e-3
 
 
 def test_encode_codes_and_api(sfv):
@@ -152,7 +175,31 @@ def test_encode_codes_and_api(sfv):
     z = m.encode(item[:, 0], temperature=float(g["meta/tau"]), hard=True, noise_ratio=float(g["meta/noise_ratio"]),
                  u=torch.from_numpy(g["U0"]).cuda())
     assert z.shape == g["z0"].shape and set(np.unique(z.cpu().numpy())) <= {0.0, 1.0}
-    assert (z.cpu().numpy() != g["z0"]).mean() < 0.01
+    # bit-exact wherever the binarisation's pre-activation h + r * logistic noise is not within rounding of zero
+    r, U_ = float(g["meta/noise_ratio"]), g["U0"]
+    margin = np.abs(g["h0"].reshape(U_.shape) + r * (np.log(U_ + 1e-8) - np.log(1 - U_ + 1e-8))).reshape(g["z0"].shape)
+    safe = margin > 1e-4
+    assert safe.mean() > 0.99 and np.array_equal(z.cpu().numpy()[safe], g["z0"][safe])
+    # like the reference's encode(), the encoder CNN follows the module's mode: after .train() its Dropout layers are live
+    m.train()
+    zt = m.encode(item[:, 0], temperature=float(g["meta/tau"]), hard=True, noise_ratio=r,
+                  u=torch.from_numpy(g["U0"]).cuda())
+    zt2 = m.encode(item[:, 0], temperature=float(g["meta/tau"]), hard=True, noise_ratio=r,
+                   u=torch.from_numpy(g["U0"]).cuda())
+    assert not torch.equal(zt, z) and not torch.equal(zt, zt2)          # dropout on: different codes, fresh masks per call
+    # ... and with explicit keep-masks it is the oracle's train-mode encode (soft codes, 2e-5)
+    gen = torch.Generator().manual_seed(5)
+    N = item.shape[0] * item.shape[2]
+    c1 = m._layout.shapes["encoder_cnn.conv.0.weight"][0]
+    h, w = m.input_hw
+    masks = [(torch.rand(N, c1, h // 2, w // 2, generator=gen) >= 0.2).float(),
+             (torch.rand(N, c1, h // 4, w // 4, generator=gen) >= 0.2).float()]
+    zs = m.encode(item[:, 0], temperature=0.6, hard=False, noise_ratio=r, u=torch.from_numpy(g["U0"]).cuda(),
+                  dropout_masks=masks)
+    params = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    zo = O.encode(variant, params, item[:, 0].cpu(), torch.from_numpy(g["U0"]), 0.6, False, r, train=True, masks=masks)
+    np.testing.assert_allclose(zs.cpu().numpy(), zo.numpy(), atol=2e-5)
+    m.eval()
     z1 = m.encode(item[:1, 0, :1], temperature=0.2, hard=True)          # B = T = 1 like the eval scripts
     assert z1.shape == (1, 1, m.latent_dim)
     with pytest.raises(RuntimeError):
