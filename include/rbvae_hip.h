@@ -279,8 +279,12 @@ int rbvae_skinny_linear_parts(int dtype, const void* A, const void* B, const flo
  * wT (optional): transposed weight copies [layers][ih|hh][L][4L] for coalesced loads. */
 int rbvae_lstm_fwd(const float* wblk, const float* wT, float* hs_all, float* hprev, float* acts, float* cs, int S,
                    int T, int L, int layers, void* stream);
-int rbvae_lstm_bwd(const float* wblk, const float* acts, const float* cs, const float* g_top, float* dG, float* dx,
-                   int S, int T, int L, int layers, void* stream);
+int rbvae_lstm_bwd(const float* wblk, const float* wT, const float* acts, const float* cs, const float* g_top, float* dG,
+                   float* dx, int S, int T, int L, int layers, void* stream);
+/* Kernels by size: L <= 32 -- one thread group per LAYER with its weight rows in registers, cells along anti-diagonals
+ * (T + layers - 1 dependent steps); 32 < L <= 128 (the reference's latent_dim 50 / 75 / 100, best_models.txt) -- layer by
+ * layer, a gate row shared by two lanes (eight lanes per hidden unit in the backward pass), the input half W_ih x_t of
+ * every time step computed in one batch off the dependent chain. */
 /* Extended forms that take over the small kernels around the stacks (wavefront kernel only: L <= 32,
  * layers * roundup64(4L) <= 1024, else RBVAE_E_INVALID):
  *  - in_parts / g_top_parts: the stack input (forward) / top-layer gradient (backward) as `nparts` K-split slabs of

@@ -241,6 +241,236 @@ __device__ __forceinline__ void lds_barrier() {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
+// ---------------------------------------------------------------------------------------------
+// 32 < L <= 128 (the reference's sweeps and best models use latent_dim 50 / 75 / 100): one workgroup per sequence,
+// layer by layer.  A layer's two weight matrices do not fit one thread's registers any more (2L values per gate row),
+// and all layers' do not fit a CU, so the work is cut the other way:
+//   * the input half  W_ih x_t  does not depend on the recurrence: it is computed for ALL time steps first
+//     (T x 4L dot products, the weights of that half in registers), then the registers are reloaded with W_hh
+//     and only  W_hh h_{t-1}  sits on the dependent chain;
+//   * one lane per gate row, L <= 128 weights in its registers, at most 512 threads (two waves per SIMD: a 256-register
+//     budget -- with two lanes per row and 1024 threads the 128-register budget spilled, and every spill reload in
+//     the time loop waited, through the shared vmcnt counter, for the step's global stores: 2.3 us per step).
+// The layer-sequential kernel this replaces for these sizes read its weights from memory inside the time loop
+// (L > 64) or spilled them (L <= 64): 3.76 ms per fused step at L = 100 against 0.46 ms at L = 32.
+// Vector rows (x_t, h_t) live in LDS at a stride of 128 floats, zero-filled, so 16-byte reads past L see zeros (the
+// weights there are zero too).
+// ---------------------------------------------------------------------------------------------
+constexpr int BIG_VS = 128;      // LDS stride of a vector row
+constexpr int BIG_W = 128;       // weights per lane
+
+// NCH = 16-byte chunks per dot product, a compile-time constant: with a run-time bound every chunk sat in its own basic
+// block and its LDS read was waited for on the spot (a dependent LDS round trip per chunk); now the reads of eight
+// chunks are in flight together.
+template <int NCH>
+__device__ __forceinline__ float big_dot(const float (&w)[BIG_W], const float* __restrict__ vec) {
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    constexpr int CH = NCH > 28 ? 4 : 8;           // reads in flight (the full 128-weight rows leave fewer registers)
+#pragma unroll
+    for (int i0 = 0; i0 < NCH; i0 += CH) {
+        float4 v[CH];
+#pragma unroll
+        for (int i = 0; i < CH; ++i)
+            if (i0 + i < NCH) v[i] = *(const float4*)(vec + 4 * (i0 + i));
+#pragma unroll
+        for (int i = 0; i < CH; ++i)
+            if (i0 + i < NCH) {
+                a0 = fmaf(w[4 * (i0 + i)], v[i].x, a0); a1 = fmaf(w[4 * (i0 + i) + 1], v[i].y, a1);
+                a2 = fmaf(w[4 * (i0 + i) + 2], v[i].z, a2); a3 = fmaf(w[4 * (i0 + i) + 3], v[i].w, a3);
+            }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    return (a0 + a1) + (a2 + a3);
+}
+
+// w[i] = base[i * step] for i < n (else 0): unconditional loads on clamped (always valid) indices, eight in flight,
+// then a select -- a predicated load per element became a chain of dependent memory round trips
+template <int NCH>
+__device__ __forceinline__ void big_load_w(float (&w)[BIG_W], const float* __restrict__ base, int step, int n, bool on) {
+    int n1 = max(n, 1) - 1;
+    // opaque to the optimiser: otherwise the 128 clamped 64-bit addresses are computed once outside the layer loop and
+    // live (spilled) across the time loops
+    asm volatile("" : "+v"(n1));
+#pragma unroll
+    for (int i0 = 0; i0 < 4 * NCH; i0 += 8) {
+        float v[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = base[min(i0 + i, n1) * step];
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            if (i0 + i < 4 * NCH) w[i0 + i] = (on && i0 + i < n) ? v[i] : 0.f;
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+template <int NCH>
+__global__ __launch_bounds__(512) void lstm_fwd_big_k(const float* __restrict__ wblk, const float* __restrict__ wT,
+                                                      float* __restrict__ hs_all, float* __restrict__ hprev,
+                                                      float* __restrict__ acts, float* __restrict__ cs, int S, int T,
+                                                      int L, int layers, int RP) {
+    RBVAE_RAISE_PRIO();
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* xin = sm;                         // [T][BIG_VS]
+    float* hout = xin + T * BIG_VS;          // [T][BIG_VS]
+    float* hcur = hout + T * BIG_VS;         // [BIG_VS]
+    float* gates = hcur + BIG_VS;            // [RP]
+    float* gx = gates + RP;                  // [T][RP]: W_ih x_t + b_ih + b_hh
+    const int tid = threadIdx.x, j = tid, s = blockIdx.x;
+    const bool row = j < 4 * L;
+    const int jc = row ? j : 0;
+    const bool is_g = j >= 2 * L && j < 3 * L;
+    for (int i = tid; i < (2 * T + 1) * BIG_VS; i += blockDim.x) sm[i] = 0.f;
+    __syncthreads();
+    for (int i = tid; i < T * L; i += blockDim.x) xin[(i / L) * BIG_VS + i % L] = hs_all[((long)s * T) * L + i];
+    float w[BIG_W];
+    for (int l = 0; l < layers; ++l) {
+        const float* wl = wblk + l * lstm_layer_floats(L);
+        const float bsum = row ? wl[8l * L * L + j] + wl[8l * L * L + 4 * L + j] : 0.f;
+        auto load_w = [&](int which) {
+            const float* base = wT ? wT + ((long)(l * 2 + which) * L) * 4 * L + jc
+                                   : wl + (long)which * 4 * L * L + (long)jc * L;
+            big_load_w<NCH>(w, base, wT ? 4 * L : 1, L, row);
+        };
+        load_w(0);
+        __syncthreads();                     // xin complete (the input, or the layer below)
+#pragma unroll 1
+        for (int t = 0; t < T; ++t) {
+            const float a = big_dot<NCH>(w, xin + t * BIG_VS);
+            if (row) gx[t * RP + j] = a + bsum;
+        }
+        load_w(1);
+        if (tid < BIG_VS) hcur[tid] = 0.f;
+        float c = 0.f;
+        __syncthreads();
+#pragma unroll 1
+        for (int t = 0; t < T; ++t) {
+            const float a = big_dot<NCH>(w, hcur);
+            const long o = (((long)l * S + s) * T + t);
+            if (row) {
+                const float pre = gx[t * RP + j] + a;
+                const float av = is_g ? fast_tanh(pre) : fast_sigmoid(pre);
+                gates[j] = av;
+                if (acts) acts[o * 4 * L + j] = av;
+            }
+            lds_barrier();
+            if (tid < L) {
+                const float ig = gates[tid], fg = gates[L + tid], gg = gates[2 * L + tid], og = gates[3 * L + tid];
+                const float hp = hcur[tid];
+                c = fmaf(fg, c, ig * gg);
+                const float h = og * fast_tanh(c);
+                if (acts) {
+                    cs[o * L + tid] = c;
+                    hprev[o * L + tid] = hp;
+                }
+                hout[t * BIG_VS + tid] = h;
+                hcur[tid] = h;
+                hs_all[(((long)(l + 1) * S + s) * T + t) * L + tid] = h;
+            }
+            lds_barrier();
+        }
+        float* tmp = xin; xin = hout; hout = tmp;
+    }
+}
+
+// BPTT of the same: a hidden unit (column of W) is shared by FOUR adjacent lanes (L <= 128 gate rows each).  Per time
+// step only  W_hh^T dG_{t+1}  is on the dependent chain; the input gradients  W_ih^T dG_t  of all time steps follow in
+// one batch per layer.  dG rows sit in LDS in four 132-float segments (one per lane of a group: conflict-free 16-byte
+// reads).
+constexpr int BIG_SEG = 132;
+template <int NCH>
+__global__ __launch_bounds__(512) void lstm_bwd_big_k(const float* __restrict__ wblk, const float* __restrict__ wT,
+                                                      const float* __restrict__ acts, const float* __restrict__ cs,
+                                                      const float* __restrict__ g_top, float* __restrict__ dG,
+                                                      float* __restrict__ dx, int S, int T, int L, int layers) {
+    RBVAE_RAISE_PRIO();
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* dhout = sm;                       // [T][BIG_VS] gradient wrt this layer's outputs
+    float* dxin = dhout + T * BIG_VS;        // [T][BIG_VS] gradient wrt this layer's inputs
+    float* dhrec = dxin + T * BIG_VS;        // [BIG_VS]
+    float* dgall = dhrec + BIG_VS;           // [T][4 * BIG_SEG] gate gradients of every time step
+    constexpr int DS = 4 * BIG_SEG;
+    const int tid = threadIdx.x, k = tid >> 2, p = tid & 3, s = blockIdx.x;
+    const int RPP = (L + 3) & ~3;            // gate rows per lane of a group: 4L / 4, rounded up to a multiple of 4
+    const int r0 = p * RPP;
+    const int nrow = min(max(4 * L - r0, 0), RPP);
+    const bool col = k < L;
+    const int kc = col ? k : 0;
+    auto seg = [&](int r) { return (r / RPP) * BIG_SEG + r % RPP; };
+    for (int i = tid; i < (2 * T + 1) * BIG_VS + T * DS; i += blockDim.x) sm[i] = 0.f;
+    __syncthreads();
+    for (int i = tid; i < T * L; i += blockDim.x) dhout[(i / L) * BIG_VS + i % L] = g_top[((long)s * T) * L + i];
+    float w[BIG_W];
+    for (int l = layers - 1; l >= 0; --l) {
+        const float* wl = wblk + l * lstm_layer_floats(L);
+        auto load_w = [&](int which) {       // w[i] = W_which[r0 + i][k]
+            // from the row-major block, not from wT: a wave's 16 hidden units x 4 row groups then read four 64-byte runs
+            // per instruction; through wT every lane would walk its own cache line (64 lines per instruction: the
+            // weight reloads alone took ~50 us of a 160 us launch at L = 100)
+            const float* base = wl + (long)which * 4 * L * L + (long)min(r0, 4 * L - 1) * L + kc;
+            big_load_w<NCH>(w, base, L, nrow, col);
+        };
+        load_w(1);
+        if (tid < BIG_VS) dhrec[tid] = 0.f;
+        float dc_next = 0.f;
+        // the saved gates / cell states of step t are loaded one step ahead (as loads inside the step they put a
+        // memory round trip on the dependent chain of every time step)
+        const int uu = tid < L ? tid : 0;
+        const long ob = ((long)l * S + s) * T;
+        float n_ig, n_fg, n_gg, n_og, n_c, n_cp;
+        {
+            const float* ap = acts + (ob + T - 1) * 4 * L;
+            n_ig = ap[uu]; n_fg = ap[L + uu]; n_gg = ap[2 * L + uu]; n_og = ap[3 * L + uu];
+            n_c = cs[(ob + T - 1) * L + uu];
+            n_cp = cs[(ob + max(T - 2, 0)) * L + uu];
+        }
+        __syncthreads();
+#pragma unroll 1
+        for (int t = T - 1; t >= 0; --t) {
+            const long o = ob + t;
+            const float ig = n_ig, fg = n_fg, gg = n_gg, og = n_og, c = n_c, cprev = t > 0 ? n_cp : 0.f;
+            {
+                const int tn = max(t - 1, 0);
+                const float* ap = acts + (ob + tn) * 4 * L;
+                n_ig = ap[uu]; n_fg = ap[L + uu]; n_gg = ap[2 * L + uu]; n_og = ap[3 * L + uu];
+                n_c = n_cp;
+                n_cp = cs[(ob + max(tn - 1, 0)) * L + uu];
+            }
+            if (tid < L) {
+                const int u = tid;
+                const float tc = fast_tanh(c);
+                const float dh = dhout[t * BIG_VS + u] + dhrec[u];
+                const float dc = dc_next + dh * og * (1.f - tc * tc);
+                const float d_o = dh * tc * og * (1.f - og);
+                const float d_i = dc * gg * ig * (1.f - ig);
+                const float d_f = dc * cprev * fg * (1.f - fg);
+                const float d_g = dc * ig * (1.f - gg * gg);
+                dc_next = dc * fg;
+                float* dl = dgall + t * DS;
+                dl[seg(u)] = d_i; dl[seg(L + u)] = d_f; dl[seg(2 * L + u)] = d_g; dl[seg(3 * L + u)] = d_o;
+                float* gp = dG + o * 4 * L;
+                gp[u] = d_i; gp[L + u] = d_f; gp[2 * L + u] = d_g; gp[3 * L + u] = d_o;
+            }
+            lds_barrier();
+            float a = big_dot<NCH>(w, dgall + t * DS + p * BIG_SEG);
+            a += __shfl_xor(a, 1, 64);
+            a += __shfl_xor(a, 2, 64);
+            if (p == 0 && col) dhrec[k] = a;
+            lds_barrier();
+        }
+        load_w(0);
+#pragma unroll 1
+        for (int t = 0; t < T; ++t) {
+            float a = big_dot<NCH>(w, dgall + t * DS + p * BIG_SEG);
+            a += __shfl_xor(a, 1, 64);
+            a += __shfl_xor(a, 2, 64);
+            if (p == 0 && col) dxin[t * BIG_VS + k] = a;
+        }
+        __syncthreads();
+        float* tmp = dhout; dhout = dxin; dxin = tmp;
+    }
+    for (int i = tid; i < T * L; i += blockDim.x) dx[((long)s * T) * L + i] = dhout[(i / L) * BIG_VS + i % L];
+}
+
 template <int LMAX, bool VEC, bool EXACT>       // EXACT: L == LMAX (every bound check folds away)
 __global__ __launch_bounds__(1024) void lstm_fwd_wave_k(const float* __restrict__ wblk, const float* __restrict__ wT,
                                                         float* __restrict__ hs_all,
@@ -891,6 +1121,21 @@ static int lstm_fwd_impl(const float* wblk, const float* wT, float* hs_all, floa
         return RBVAE_OK;
     }
     RBVAE_CHECK_ARG(!in_parts && !cast_out, "lstm_fwd_ex: only the wavefront kernel (L <= 32, layers * roundup64(4L) <= 1024) sums input slabs / writes a cast copy");
+    if (L > 32) {
+        // two lanes per gate row, the input half batched over time (lstm_fwd_big_k)
+        const int RP = ((4 * L + 63) / 64) * 64;
+        const size_t blds = (size_t)((2 * T + 1) * BIG_VS + RP + T * RP) * sizeof(float);
+        RBVAE_CHECK_ARG(blds <= 64 * 1024, "lstm_fwd: T=%d too long for L=%d", T, L);
+        const int nch = (L + 3) / 4;                              // 16-byte chunks of a weight row
+#define FWD_BIG(N) hipLaunchKernelGGL(lstm_fwd_big_k<N>, dim3(S), dim3(RP), blds, st, wblk, wT, hs_all, hprev, acts, cs, \
+                                      S, T, L, layers, RP)
+        if (nch <= 10) FWD_BIG(10); else if (nch <= 13) FWD_BIG(13); else if (nch <= 16) FWD_BIG(16);
+        else if (nch <= 19) FWD_BIG(19); else if (nch <= 22) FWD_BIG(22); else if (nch <= 25) FWD_BIG(25);
+        else if (nch <= 28) FWD_BIG(28); else FWD_BIG(32);
+#undef FWD_BIG
+        RBVAE_CHECK_LAUNCH("lstm_fwd_big");
+        return RBVAE_OK;
+    }
     if (L <= 32)
         hipLaunchKernelGGL(lstm_fwd_k<32>, dim3(S), dim3(threads), lds, st, wblk, hs_all, hprev, acts, cs, S, T, L, layers);
     else if (L <= 64)
@@ -959,8 +1204,8 @@ int rbvae_lstm_pair_fwd(const float* wblk_enc, const float* wT_enc, const float*
     return RBVAE_OK;
 }
 
-static int lstm_bwd_impl(const float* wblk, const float* acts, const float* cs, const float* g_top, float* dG, float* dx,
-                         int S, int T, int L, int layers, int nparts, long part_stride, void* cast_out, int cast_dtype,
+static int lstm_bwd_impl(const float* wblk, const float* wT, const float* acts, const float* cs, const float* g_top,
+                         float* dG, float* dx, int S, int T, int L, int layers, int nparts, long part_stride, void* cast_out, int cast_dtype,
                          int cast_ld, float* dx_colsum, const BinBwd& bb, void* stream) {
     RBVAE_CHECK_ARG(wblk && acts && cs && g_top && dG && dx && S > 0 && T > 0 && L > 0 && layers > 0,
                     "lstm_bwd: bad arguments");
@@ -986,6 +1231,20 @@ static int lstm_bwd_impl(const float* wblk, const float* acts, const float* cs, 
         return RBVAE_OK;
     }
     RBVAE_CHECK_ARG(nparts == 1 && !cast_out && !dx_colsum && !bb.on, "lstm_bwd_ex: only the wavefront kernel (L <= 32, layers * roundup64(4L) <= 1024) sums gradient slabs / writes a cast copy");
+    if (L > 32) {
+        const int KP = ((L + 15) / 16) * 16;
+        const size_t blds = (size_t)((2 * T + 1) * BIG_VS + T * 4 * BIG_SEG) * sizeof(float);
+        RBVAE_CHECK_ARG(blds <= 64 * 1024, "lstm_bwd: T=%d too long for L=%d", T, L);
+        const int nch = (L + 3) / 4;                              // 16-byte chunks of a lane's gate rows
+#define BWD_BIG(N) hipLaunchKernelGGL(lstm_bwd_big_k<N>, dim3(S), dim3(4 * KP), blds, st, wblk, wT, acts, cs, g_top, dG, \
+                                      dx, S, T, L, layers)
+        if (nch <= 10) BWD_BIG(10); else if (nch <= 13) BWD_BIG(13); else if (nch <= 16) BWD_BIG(16);
+        else if (nch <= 19) BWD_BIG(19); else if (nch <= 22) BWD_BIG(22); else if (nch <= 25) BWD_BIG(25);
+        else if (nch <= 28) BWD_BIG(28); else BWD_BIG(32);
+#undef BWD_BIG
+        RBVAE_CHECK_LAUNCH("lstm_bwd_big");
+        return RBVAE_OK;
+    }
     if (L <= 32)
         hipLaunchKernelGGL(lstm_bwd_k<32>, dim3(S), dim3(threads), lds, st, wblk, acts, cs, g_top, dG, dx, S, T, L, layers);
     else if (L <= 64)
@@ -996,16 +1255,16 @@ static int lstm_bwd_impl(const float* wblk, const float* acts, const float* cs, 
     return RBVAE_OK;
 }
 
-int rbvae_lstm_bwd(const float* wblk, const float* acts, const float* cs, const float* g_top, float* dG, float* dx,
-                   int S, int T, int L, int layers, void* stream) {
-    return lstm_bwd_impl(wblk, acts, cs, g_top, dG, dx, S, T, L, layers, 1, 0, nullptr, 0, 0, nullptr, BinBwd{}, stream);
+int rbvae_lstm_bwd(const float* wblk, const float* wT, const float* acts, const float* cs, const float* g_top, float* dG,
+                   float* dx, int S, int T, int L, int layers, void* stream) {
+    return lstm_bwd_impl(wblk, wT, acts, cs, g_top, dG, dx, S, T, L, layers, 1, 0, nullptr, 0, 0, nullptr, BinBwd{}, stream);
 }
 
 int rbvae_lstm_bwd_ex(const float* wblk, const float* acts, const float* cs, const float* g_top_parts, int nparts,
                       long part_stride, float* dG, float* dx, void* cast_out, int cast_dtype, int cast_ld,
                       float* dx_colsum, int S, int T, int L, int layers, void* stream) {
     RBVAE_CHECK_ARG(nparts >= 1 && (nparts == 1 || part_stride >= (long)S * T * L), "lstm_bwd_ex: bad slabs");
-    return lstm_bwd_impl(wblk, acts, cs, g_top_parts, dG, dx, S, T, L, layers, nparts, part_stride, cast_out, cast_dtype,
+    return lstm_bwd_impl(wblk, nullptr, acts, cs, g_top_parts, dG, dx, S, T, L, layers, nparts, part_stride, cast_out, cast_dtype,
                          cast_ld, dx_colsum, BinBwd{}, stream);
 }
 
@@ -1020,7 +1279,7 @@ int rbvae_lstm_bwd_bin(const float* wblk, const float* acts, const float* cs, co
     bb.klw = kl_weight / (float)((long)S * T);
     bb.lp = kl_weight != 0.f ? logf(kl_p) : 0.f; bb.l1p = kl_weight != 0.f ? logf(1.0f - kl_p) : 0.f;
     bb.keps = kl_eps; bb.clamp = kl_clamp; bb.on = 1;
-    return lstm_bwd_impl(wblk, acts, cs, g_z, dG, dx, S, T, L, layers, 1, 0, cast_out, cast_dtype, cast_ld, dx_colsum, bb,
+    return lstm_bwd_impl(wblk, nullptr, acts, cs, g_z, dG, dx, S, T, L, layers, 1, 0, cast_out, cast_dtype, cast_ld, dx_colsum, bb,
                          stream);
 }
 

@@ -238,6 +238,7 @@ class Engine:
         self._bufs: Dict = {}          # persistent backward temporaries, keyed by (N, tag)
         self._bwd_tab: Dict = {}       # uploaded reduce-job tables, keyed by their signature
         self._jobs: Optional[JobList] = None
+        self._wg_cus = 256
         self._sides: List[Optional[torch.cuda.Stream]] = [None, None]
         # weight-gradient work of the decoder runs on a side stream beside the LSTM backward chain (RBVAE_OVERLAP=0:
         # everything in issue order on one stream)
@@ -257,6 +258,7 @@ class Engine:
         self.wfc_side = os.environ.get("RBVAE_WFC_SIDE", "1") == "1"
         self.lstm_wgrad_tail = os.environ.get("RBVAE_LSTM_WGRAD_TAIL", "1") == "1"
         self.tail_wgrads = int(os.environ.get("RBVAE_TAIL_WGRADS", "0"))
+        self.side_wg_cap = os.environ.get("RBVAE_SIDE_WG_CAP", "1") == "1"
         # RBVAE_STREAM_GEMM=1 sends the K = 64 products of the 3/4-channel ends to the row-streaming kernel
         # (rbvae_stream_gemm) instead of the tiled gather GEMM.  Bit-identical results; measured on the bench shapes
         # (tools/abl_stream.py): conv1 forward 17.5 -> 15.4-16.6 us, last-deconv backward (gate + column sums)
@@ -492,7 +494,10 @@ class Engine:
         blocks = -(-Co // 128) * -(-Ci // (128 if Ci > 64 else 64)) * taps
         # K-slices: one round of workgroups on the 256 CUs, each with >= 256 pixels, and at most ~16 MB of f32
         # slabs to reduce afterwards
-        ks = max(1, min(256 // max(blocks, 1), P // 256 if P >= 256 else 1,
+        # (self._wg_cus: the CUs this launch can count on -- beside the LSTM backward kernels, which hold one CU per
+        # sequence and whose registers leave no room for a second workgroup there, a 252-workgroup grid ran in two
+        # rounds: 31 -> 43 us)
+        ks = max(1, min(self._wg_cus // max(blocks, 1), P // 256 if P >= 256 else 1,
                         max(1, (4 << 20) // (Co * taps * Ci))))
         if self._ks_force and blocks >= 8:
             ks = self._ks_force                 # RBVAE_WG_KS: experiment switch (K-slices of the multi-tile weight gradients)
@@ -881,6 +886,14 @@ class Engine:
 
         # ... then its weight / bias gradients, beside the LSTM chain when overlap is on
         def decoder_wgrads():
+            if self._side_on(self.SIDE_DEC_WGRAD) and self.side_wg_cap:
+                self._wg_cus = max(64, 256 - min(S, 128))     # the LSTM backward kernels run beside these: S workgroups
+            try:
+                decoder_wgrads_()
+            finally:
+                self._wg_cus = 256
+
+        def decoder_wgrads_():
             if g_xr is None and sv.b3_parts is not None:
                 ws_b3, nb3 = sv.b3_parts
                 self._jobs.add(JOB_ROWS, ws_b3[nb3:], G(f"decoder_cnn.deconv.{i2}.bias"), (1, 1, oc), (0, 0, 1), nslab=nb3,
@@ -965,7 +978,7 @@ class Engine:
             L.call("rbvae_lstm_bwd_ex", wdec, sv.acts_dec, sv.cs_dec, dds, self.fc_split, N * Ld, dG, d_in_dec, None, 0, 0,
                    None, S, T, Ld, nl)
         else:
-            L.call("rbvae_lstm_bwd", wdec, sv.acts_dec, sv.cs_dec, dds, dG, d_in_dec, S, T, Ld, nl)
+            L.call("rbvae_lstm_bwd", wdec, self.wT_dec, sv.acts_dec, sv.cs_dec, dds, dG, d_in_dec, S, T, Ld, nl)
         de = tmp("de", N, Ld, dtype=f32)
         if not v.simple_order:
             # z -> binarise backward (+ fused KL) -> gradient of h_seq
@@ -998,13 +1011,13 @@ class Engine:
                     L.call("rbvae_lstm_bwd_ex", wenc, sv.acts_enc, sv.cs_enc, dh, 1, 0, dGe, de, de_pad, self.dt, self.Lp,
                            de_sums, S, T, Ld, nl)
                 else:
-                    L.call("rbvae_lstm_bwd", wenc, sv.acts_enc, sv.cs_enc, dh, dGe, de, S, T, Ld, nl)
+                    L.call("rbvae_lstm_bwd", wenc, self.wT_enc, sv.acts_enc, sv.cs_enc, dh, dGe, de, S, T, Ld, nl)
         else:
             de_pad = None
             de_sums = None
             # decoder stack input = encoder stack output
             dz = tmp("dz", N, Ld, dtype=f32)
-            L.call("rbvae_lstm_bwd", wenc, sv.acts_enc, sv.cs_enc, d_in_dec, dGe, dz, S, T, Ld, nl)
+            L.call("rbvae_lstm_bwd", wenc, self.wT_enc, sv.acts_enc, sv.cs_enc, d_in_dec, dGe, dz, S, T, Ld, nl)
             L.call("rbvae_binarize_kl_bwd", dz, sv.y, sv.z, de, 0, N, Ld, float(sv.tau), None, 0.0, None, 0.5, 1e-10, 0)
             if g_e is not None:
                 de = de + g_e.reshape(N, Ld)

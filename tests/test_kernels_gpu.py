@@ -202,8 +202,10 @@ def test_skinny_linear_and_colsum(sfv, dtype):
         assert rel(out.cpu(), X.float().sum(0)) < 1e-5
 
 
-@pytest.mark.parametrize("L,layers,S,T", [(32, 4, 5, 8), (25, 2, 3, 5), (64, 2, 2, 3), (100, 1, 2, 4)])
-def test_lstm_forward_backward(sfv, L, layers, S, T):
+@pytest.mark.parametrize("L,layers,S,T", [(32, 4, 5, 8), (25, 2, 3, 5), (64, 2, 2, 3), (100, 1, 2, 4), (50, 4, 3, 8),
+                                          (75, 2, 2, 9), (100, 4, 2, 17), (128, 2, 3, 5), (33, 3, 2, 2), (36, 1, 1, 1)])
+@pytest.mark.parametrize("use_wT", [False, True])
+def test_lstm_forward_backward(sfv, L, layers, S, T, use_wT):
     g = torch.Generator().manual_seed(5)
     names = []
     p = {}
@@ -221,10 +223,14 @@ def test_lstm_forward_backward(sfv, L, layers, S, T):
     hs[0] = x.detach().cuda()
     hp, cs, acts = torch.empty(layers, S, T, L, device="cuda"), torch.empty(layers, S, T, L, device="cuda"), \
         torch.empty(layers, S, T, 4 * L, device="cuda")
-    sfv._lib.call("rbvae_lstm_fwd", wblk, None, hs, hp, acts, cs, S, T, L, layers)
+    wT_arg = None
+    if use_wT:       # [layers][ih | hh][L][4L]: the transposed copies the engine keeps for coalesced weight loads
+        wT_arg = torch.stack([torch.stack([p[f"r.lstm.{nm}_l{l}"].detach().t().contiguous() for nm in ("weight_ih", "weight_hh")])
+                              for l in range(layers)]).cuda()
+    sfv._lib.call("rbvae_lstm_fwd", wblk, wT_arg, hs, hp, acts, cs, S, T, L, layers)
     np.testing.assert_allclose(hs[layers].cpu().numpy(), y.detach().numpy(), atol=2e-6)
     dG, dx = torch.empty(layers, S, T, 4 * L, device="cuda"), torch.empty(S, T, L, device="cuda")
-    sfv._lib.call("rbvae_lstm_bwd", wblk, acts, cs, gt.cuda(), dG, dx, S, T, L, layers)
+    sfv._lib.call("rbvae_lstm_bwd", wblk, wT_arg, acts, cs, gt.cuda(), dG, dx, S, T, L, layers)
     np.testing.assert_allclose(dx.cpu().numpy(), x.grad.numpy(), atol=2e-6, rtol=1e-4)
     gb = torch.empty_like(wblk)
     sfv._lib.call("rbvae_lstm_wgrad", dG, hs, hp, gb, S, T, L, layers, 0)
@@ -437,7 +443,7 @@ def test_split_fc_slabs_feed_the_lstm_kernels(sfv):
             assert torch.equal(pad, dx)
             np.testing.assert_allclose(sums.cpu().numpy(), dx.view(S, T, L).sum(1).cpu().numpy(), atol=1e-5)
         else:
-            sfv._lib.call("rbvae_lstm_bwd", wblk, a0, c0, gparts.sum(0).contiguous(), dG, dx, S, T, L, layers)
+            sfv._lib.call("rbvae_lstm_bwd", wblk, None, a0, c0, gparts.sum(0).contiguous(), dG, dx, S, T, L, layers)
         outs.append((dG, dx))
     np.testing.assert_allclose(outs[1][0].cpu().numpy(), outs[0][0].cpu().numpy(), atol=1e-5)
     np.testing.assert_allclose(outs[1][1].cpu().numpy(), outs[0][1].cpu().numpy(), atol=1e-5)

@@ -17,7 +17,7 @@ dG = torch.randn(layers, S, T, 4 * L, device="cuda"); dx = torch.empty(S, T, L, 
 gb = torch.empty_like(wblk)
 wT = torch.randn(layers, 2, L, 4 * L, device="cuda") * 0.1
 print("lstm_fwd  ", timeit(lambda: L_.call("rbvae_lstm_fwd", wblk, None, hs, hp, acts, cs, S, T, L, layers)))
-print("lstm_bwd  ", timeit(lambda: L_.call("rbvae_lstm_bwd", wblk, acts, cs, gt, dG, dx, S, T, L, layers)))
+print("lstm_bwd  ", timeit(lambda: L_.call("rbvae_lstm_bwd", wblk, None, acts, cs, gt, dG, dx, S, T, L, layers)))
 print("lstm_wgrad", timeit(lambda: L_.call("rbvae_lstm_wgrad", dG, hs, hp, gb, S, T, L, layers, 0)))
 for S2 in (1, 8, 128):
     hs2 = torch.randn(layers + 1, S2, T, L, device="cuda"); hp2 = torch.empty(layers, S2, T, L, device="cuda"); cs2 = torch.empty_like(hp2); ac2 = torch.empty(layers, S2, T, 4 * L, device="cuda")
