@@ -42,6 +42,49 @@ def allreduce_mean_(flat: torch.Tensor, group=None):
     return flat
 
 
+class GradReducer:
+    """The data-parallel exchange step of the fused trainer: the flat f32 gradient buffer summed over the ranks (the
+    1/world factor is folded into the Adam kernel), as ONE all-reduce, or as two buckets cut where the backward pass
+    finishes them:
+
+      tail = flat[cut:]   decoder CNN + both LSTM stacks -- final when the encoder CNN's backward pass starts
+      head = flat[:cut]   encoder CNN                     -- final at the end of the pass
+
+    start_tail() launches the tail's all-reduce asynchronously (RCCL runs it on its own stream, beside the HIP graph
+    that computes the head's gradients); finish() all-reduces the head and makes the current stream wait for both.
+    Bucket order = reverse layer order, as SURVEY.md 8e asks; the cut sits where the side stream's work is done
+    when the main chain arrives (engine.backward(cut=...)), so it costs no idle time."""
+
+    def __init__(self, gflat: torch.Tensor, cut: int, group=None):
+        self.gflat, self.cut, self.group = gflat, int(cut), group
+        self.world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
+        if not 0 < self.cut < gflat.numel() or self.cut % 4:
+            raise ValueError(f"bucket cut {cut} outside the buffer or not 16-byte aligned")
+
+    @property
+    def tail(self) -> torch.Tensor:
+        return self.gflat[self.cut:]
+
+    @property
+    def head(self) -> torch.Tensor:
+        return self.gflat[:self.cut]
+
+    def reduce_all(self):
+        if self.world > 1:
+            dist.all_reduce(self.gflat, op=dist.ReduceOp.SUM, group=self.group)
+
+    def start_tail(self):
+        if self.world > 1:
+            return dist.all_reduce(self.tail, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        return None
+
+    def finish(self, work):
+        if self.world > 1:
+            dist.all_reduce(self.head, op=dist.ReduceOp.SUM, group=self.group)
+            if work is not None:
+                work.wait()
+
+
 def broadcast_(flat: torch.Tensor, src=0, group=None):
     """Make every rank start from rank `src`'s parameters."""
     if dist.is_initialized() and dist.get_world_size(group) > 1:

@@ -254,6 +254,8 @@ class Engine:
         # first; created second, the main chain paid the cross-queue hand-off (~10 us idle at every fork).
         self.main_first = os.environ.get("RBVAE_MAIN_FIRST", "1") == "1"
         self._ks_force = int(os.environ.get("RBVAE_WG_KS", "0"))
+        self._ks_small = int(os.environ.get("RBVAE_WG_KS_SMALL", "3"))
+        self._ks_narrow = int(os.environ.get("RBVAE_WG_KS_NARROW", "0"))
         self.book_with_dec = os.environ.get("RBVAE_BOOK_WITH_DEC", "1") == "1"
         self.wfc_side = os.environ.get("RBVAE_WFC_SIDE", "1") == "1"
         self.lstm_wgrad_tail = os.environ.get("RBVAE_LSTM_WGRAD_TAIL", "1") == "1"
@@ -501,6 +503,13 @@ class Engine:
                         max(1, (4 << 20) // (Co * taps * Ci))))
         if self._ks_force and blocks >= 8:
             ks = self._ks_force                 # RBVAE_WG_KS: experiment switch (K-slices of the multi-tile weight gradients)
+        if self._ks_small and blocks >= 8 and P <= 4096:
+            # the 4096-pixel layers (conv3 / first deconv at the bench shape): 3 K-slices of 22 steps instead of 7 of 9
+            # -- 7 MB of slabs per weight instead of 16.5 MB; same GPU, 2 runs each: 0.4738 (7) / 0.4665 (4) /
+            # 0.4659 (3) / 0.472 (2) ms per step
+            ks = min(ks, self._ks_small)
+        if self._ks_narrow and blocks < 8:
+            ks = min(ks, self._ks_narrow)       # RBVAE_WG_KS_NARROW: the 64-column weight gradients (first conv, last deconv)
         ks = max(ks, -(-P // 4096))            # the kernel keeps a K-slice's gather indices in LDS (<= 4096)
         slabs = self._buf(("slabs", tag), ks * Co * taps * Ci)
         L.call("rbvae_wgrad_gemm", self.dt, Dy, In, slabs, idx, self.zero, P, In.numel() // ldi, Co, Ci, ldy, ldi, taps, ks)

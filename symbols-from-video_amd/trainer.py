@@ -107,6 +107,7 @@ class FusedTrainer:
         # (last data-gradient GEMM 32 -> 50 us, Adam on half the buffer 15.5 us instead of 6.5): default = the plain order.
         self.early_update = self.world == 1 and os.environ.get("RBVAE_EARLY_UPDATE", "0") == "1"
         self._packed_ver = None
+        self._red = None
 
     # ---- the two halves of a step (plain launches; captured below) ------------------
     def _fwd_bwd(self, x, U, tau, B, T, cut=None, masks=None):
@@ -257,11 +258,10 @@ class FusedTrainer:
             g[0].replay()
             if len(g) == 3:
                 # tail (decoder CNN + LSTM gradients) on the collective's stream beside the encoder CNN's backward graph
-                tail, head = self._grad_buckets()
-                w = dist.all_reduce(tail, group=self.pg, async_op=True)
+                red = self._reducer()
+                w = red.start_tail()
                 g[1].replay()
-                dist.all_reduce(head, group=self.pg)
-                w.wait()
+                red.finish(w)
                 g[2].replay()
             elif g[1] is not None:
                 self._allreduce()
@@ -407,15 +407,17 @@ class FusedTrainer:
             self.lr_dev.fill_(float(self.lr))
             self._lr_host = float(self.lr)
 
+    def _reducer(self):
+        """The gradient exchange (ddp.GradReducer): buckets cut at decoder_cnn.fc.weight -- everything from there on
+        (decoder CNN, both LSTM stacks) is final at the backward pass's cut, the encoder CNN at its end."""
+        if self._red is None:
+            from .ddp import GradReducer
+            self._red = GradReducer(self.gflat, self.model._layout.offsets["decoder_cnn.fc.weight"], self.pg)
+        return self._red
+
     def _allreduce(self):
         if self.world > 1:
-            dist.all_reduce(self.gflat, group=self.pg)
-
-    def _grad_buckets(self):
-        """(tail, head) views of the flat gradient: tail = decoder_cnn.* and both LSTM stacks (final at the backward
-        pass's cut), head = encoder_cnn.* (final at its end)."""
-        o = self.eng.layout.offsets["decoder_cnn.fc.weight"]
-        return self.gflat[o:], self.gflat[:o]
+            self._reducer().reduce_all()
 
     def _capture(self, x, U, tau, B, T):
         # two eager warm-up steps on a side stream (allocator + lazy kernel attributes), then capture.

@@ -50,7 +50,15 @@ def _worker(rank, world, port, q):
     gflat = torch.zeros(lay.total)
     for k in lay.names:
         lay.view(gflat, k).copy_(p[k].grad)
+    # the product schedule: two buckets cut where the backward pass finishes them (tail first, asynchronously), and the
+    # one-all-reduce form -- both must equal the plain mean
+    g_b, g_1 = gflat.clone(), gflat.clone()
+    red = ddp.GradReducer(g_b, lay.offsets["decoder_cnn.fc.weight"])
+    assert red.world == world and red.tail.numel() + red.head.numel() == lay.total
+    red.finish(red.start_tail())
+    ddp.GradReducer(g_1, lay.offsets["decoder_cnn.fc.weight"]).reduce_all()
     ddp.allreduce_mean_(gflat)
+    assert torch.equal(g_b / world, gflat) and torch.equal(g_1 / world, gflat)
     if rank == 0:
         q.put((flat.clone(), gflat.clone()))
     dist.barrier()
