@@ -239,10 +239,10 @@ class Engine:
         self._bwd_tab: Dict = {}       # uploaded reduce-job tables, keyed by their signature
         self._jobs: Optional[JobList] = None
         self._wg_cus = 256
+        self._job_blocks = int(os.environ.get("RBVAE_JOB_BLOCKS", "256"))      # workgroups per job of a batched job launch
         self._sides: List[Optional[torch.cuda.Stream]] = [None, None]
         # weight-gradient work of the decoder runs on a side stream beside the LSTM backward chain (RBVAE_OVERLAP=0:
         # everything in issue order on one stream)
-        import os
         self.overlap = os.environ.get("RBVAE_OVERLAP", "1") == "1"
         self.pack_late_split = os.environ.get("RBVAE_PACK_LATE", "0") == "1" or bool(int(os.environ.get("RBVAE_SIDE", "14")) & 128)
         # default 14 = pair term + decoder weight gradients + their reductions (same-GPU sweep, ms/step: 14 0.547,
@@ -312,7 +312,7 @@ class Engine:
             jl = self._pack_jobs(flat)
             tab = (jl.upload(self.device), len(jl.rows), jl)
             self._pack_tab[key] = tab
-        L.call("rbvae_run_jobs", tab[0], tab[1], 256)
+        L.call("rbvae_run_jobs", tab[0], tab[1], self._job_blocks)
 
     def _pack_split(self, flat: torch.Tensor):
         """pack() cut by when the copies are first read in a fused step: `first` (the first conv, current
@@ -357,7 +357,7 @@ class Engine:
             self._pack_tab[key] = tab
         t, n = tab[group]
         if n:
-            L.call("rbvae_run_jobs", t, n, 256)
+            L.call("rbvae_run_jobs", t, n, self._job_blocks)
 
     def pack_begin(self, flat: torch.Tensor):
         if not self._side_on(self.SIDE_PACK) and not self.pack_late_split:
@@ -366,8 +366,8 @@ class Engine:
         first, early, _, _ = self._pack_split(flat)
         self._fork(1, self.SIDE_PACK)
         with self._on_side(1, self.SIDE_PACK):
-            L.call("rbvae_run_jobs", early[0], early[1], 256)
-        L.call("rbvae_run_jobs", first[0], first[1], 256)
+            L.call("rbvae_run_jobs", early[0], early[1], self._job_blocks)
+        L.call("rbvae_run_jobs", first[0], first[1], self._job_blocks)
 
     def pack_late(self, flat: torch.Tensor):
         late = self._pack_split(flat)[2]
@@ -376,7 +376,7 @@ class Engine:
         bit = self.SIDE_PACK_LATE if (self.side_mask & self.SIDE_PACK_LATE) else self.SIDE_PACK
         self._fork(1, bit)
         with self._on_side(1, bit):
-            L.call("rbvae_run_jobs", late[0], late[1], 256)
+            L.call("rbvae_run_jobs", late[0], late[1], self._job_blocks)
 
     def pack_end(self):
         self._join(1)
@@ -569,7 +569,7 @@ class Engine:
         if tab is None:
             tab = (jl.upload(self.device), len(jl.rows), jl)
             self._bwd_tab[sig] = tab
-        L.call("rbvae_run_jobs", tab[0], tab[1], 256)
+        L.call("rbvae_run_jobs", tab[0], tab[1], self._job_blocks)
 
     def _E(self, *shape, dtype=None):
         return torch.empty(*shape, dtype=dtype or self.tdt, device=self.device)
@@ -901,6 +901,7 @@ class Engine:
                 decoder_wgrads_()
             finally:
                 self._wg_cus = 256
+        self._job_blocks = int(os.environ.get("RBVAE_JOB_BLOCKS", "256"))      # workgroups per job of a batched job launch
 
         def decoder_wgrads_():
             if g_xr is None and sv.b3_parts is not None:
