@@ -69,3 +69,43 @@ def test_batch_gathers_into_the_trainer_input_buffer():
     assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
     with pytest.raises(ValueError):
         ds.batch(idx, out=torch.empty(2, 2, 3, 4, 16, 16, device="cuda"))
+
+
+def test_planned_epoch_trains_from_the_resident_table():
+    """FusedTrainer.set_data(table, plan) + step(None): the batch of every step is gathered inside the captured step
+    from the HBM-resident table by the device step counter -- same losses and weights, bit for bit, as feeding
+    ds.batch(...) of the same items by hand; the plan wraps around; a new epoch's plan keeps the graph."""
+    import sfv_amd as sfv
+    Ld, hw, B = 32, (16, 16), 2
+    segs = [(0, 40), (40, 80), (80, 120)]
+    g = torch.Generator().manual_seed(13)
+    table = torch.randn(120, 4, *hw, generator=g)
+    res = []
+    for planned in (False, True):
+        random.seed(6)
+        ds = sfv.DeviceStatePairDataset(table, segs, 0.1, 0.1, mode="train", device="cuda")
+        order = torch.randperm(len(ds), generator=torch.Generator().manual_seed(14))
+        plan = ds.plan(order, B)
+        assert plan.shape == (len(ds) // B, B, 2, 3) and plan.dtype == torch.int64
+        torch.manual_seed(15)
+        m = sfv.Seq2SeqBinaryVAE(4, 4, Ld, Ld, variant="percep", input_hw=hw, compute_dtype="f32").cuda().train()
+        tr = sfv.FusedTrainer(m, device_noise=True, use_graph=True, seed=16)
+        losses = []
+        nb = plan.shape[0]
+        if planned:
+            tr.set_data(ds.table, plan)
+        for i in range(nb + 2):                                   # two steps past the end: the plan wraps
+            if planned:
+                losses.append(tr.step(None, 0.8).clone())
+            else:
+                items = order[(i % nb) * B:(i % nb + 1) * B].tolist()
+                losses.append(tr.step(ds.batch(items), 0.8).clone())
+        if planned:
+            # next epoch: a new shuffle of the same shape goes into the same device buffer, no re-capture
+            tr.set_data(ds.table, ds.plan(order.flip(0), B))
+            tr.step(None, 0.8)
+            assert len(tr._graphs) == 1
+            with pytest.raises(ValueError):
+                tr.set_data(ds.table, plan + 1000)
+        res.append((torch.stack(losses), None))
+    assert torch.equal(res[0][0], res[1][0])
