@@ -7,16 +7,23 @@
 // never leave the registers.
 //
 // Layout (gfx950, bf16 storage, f32 accumulation, v_mfma_f32_16x16x32_bf16):
-//   * 4 waves, wave w owns query rows 16w..16w+15; its Q fragments (C/32 x 8 bf16 per lane) and its output
-//     accumulators (C/16 tiles x 4 f32 per lane) stay in registers for the whole key loop (64 + 128 VGPRs at C = 512);
+//   * a 64-query tile per 4-wave workgroup, two workgroups per CU (one's tile transfer and barriers hide behind the
+//     other's products; the 128-query / 8-wave form, which feeds twice the products from every staged tile, measured
+//     slower: 503 vs 387 us at 4 x 4096 tokens, tools/time_attn.py); wave w owns query rows 16w..16w+15; its Q
+//     fragments (C/32 x 8 bf16 per lane) and its output accumulators (C/16 tiles x 4 f32 per lane) stay in registers
+//     for the whole key loop (64 + 128 VGPRs at C = 512);
+//   * K / V tiles are staged by LDS-DMA at C = 512 (one row = one 1-KiB instruction, no registers, a wave's 16 rows in
+//     flight together);
 //   * K and V tiles [32 keys][C] go through LDS with 16-byte-padded rows (conflict-free ds_read_b128 for the K
 //     fragments; V fragments, which need 8 consecutive KEYS per lane, by ds_read_b64_tr_b16 -- no transposed copy of V
 //     in memory);
 //   * the probabilities change from accumulator layout to A-operand layout through a 1.25 KB per-wave LDS patch;
 //   * exp2 with the scale folded in; the row sums are taken over the bf16-rounded probabilities the PV product uses;
 //   * the output accumulators are only rescaled when a row maximum moved (wave-uniform test).
-// ~72 KB of LDS per workgroup at C = 512: two workgroups per CU overlap each other's tile loads and barriers.
+// ~72 KB of LDS per workgroup at C = 512.  Measured (MI355X, bf16): 4 x 4096 tokens (512x512 frames) 387 us = 355 TFLOP/s,
+// the three-launch form 393 us; 8 x 1024 tokens (256x256) 104 us against 329 us.
 #include "common.h"
+#include <stdlib.h>
 
 namespace rbvae {
 
@@ -25,18 +32,19 @@ typedef __attribute__((ext_vector_type(4))) short s16x4_t;
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
 
-constexpr int AT_BQ = 64, AT_BK = 32, AT_PAD = 8;
+constexpr int AT_BK = 32, AT_PAD = 8;
 
-template <int D>
-__global__ __launch_bounds__(256, 2) void attn_flash_k(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
+template <int D, int AT_BQ>
+__global__ __launch_bounds__(4 * AT_BQ, AT_BQ == 64 ? 2 : 1) void attn_flash_k(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
                                                        const bf16_t* __restrict__ V, bf16_t* __restrict__ O, int hw,
                                                        int ldq, int ldk, int ldv, int ldo, float scale_log2e) {
+    constexpr int AT_WAVES = AT_BQ / 16;
     constexpr int LD = D + AT_PAD;                 // LDS row stride of the K / V tiles (elements)
     constexpr int PLD = AT_BK + AT_PAD;            // row stride of the probability patch
     extern __shared__ __attribute__((aligned(16))) bf16_t smem[];
     bf16_t* sK = smem;
     bf16_t* sV = sK + AT_BK * LD;
-    bf16_t* sP = sV + AT_BK * LD;                  // [4][16][PLD]
+    bf16_t* sP = sV + AT_BK * LD;                  // [AT_WAVES][16][PLD]
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, m = l & 15, g = l >> 4;
     const long img = (long)blockIdx.y * hw;
     const int q0 = blockIdx.x * AT_BQ + 16 * w;
@@ -61,12 +69,27 @@ __global__ __launch_bounds__(256, 2) void attn_flash_k(const bf16_t* __restrict_
         // ---- stage the K and V tiles: a wave moves one 2*D-byte row per instruction --------------------------------
         __syncthreads();                            // everyone is done with the previous tiles
         constexpr int CPR = D / 8;                  // 16-byte chunks per row
-        for (int i = tid; i < AT_BK * CPR; i += 256) {
-            const int r = i / CPR, cch = i - r * CPR;
-            const u32x4_t kv = *(const u32x4_t*)(K + (img + k0 + r) * ldk + 8 * cch);
-            const u32x4_t vv = *(const u32x4_t*)(V + (img + k0 + r) * ldv + 8 * cch);
-            *(u32x4_t*)(sK + r * LD + 8 * cch) = kv;
-            *(u32x4_t*)(sV + r * LD + 8 * cch) = vv;
+        if constexpr (CPR == 64) {
+            // a row is exactly one LDS-DMA instruction (64 lanes x 16 bytes, lane-linear destination): no registers, and
+            // all of a wave's 8 rows are in flight together.  (Through registers the loop became a load-wait-store
+            // chain of four dependent L2 round trips per tile: 4.3 us per 32-key tile at 4096 tokens.)
+            for (int r = w; r < AT_BK; r += AT_WAVES) {
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(K + (img + k0 + r) * ldk + 8 * l),
+                                                 (__attribute__((address_space(3))) void*)(sK + r * LD), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(V + (img + k0 + r) * ldv + 8 * l),
+                                                 (__attribute__((address_space(3))) void*)(sV + r * LD), 16, 0, 0);
+            }
+            // every wave's own transfers have landed before it arrives at the barrier (the compiler only guards a
+            // wave's OWN later LDS reads)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else {
+            for (int i = tid; i < AT_BK * CPR; i += 64 * AT_WAVES) {
+                const int r = i / CPR, cch = i - r * CPR;
+                const u32x4_t kv = *(const u32x4_t*)(K + (img + k0 + r) * ldk + 8 * cch);
+                const u32x4_t vv = *(const u32x4_t*)(V + (img + k0 + r) * ldv + 8 * cch);
+                *(u32x4_t*)(sK + r * LD + 8 * cch) = kv;
+                *(u32x4_t*)(sV + r * LD + 8 * cch) = vv;
+            }
         }
         __syncthreads();
         // ---- scores S[q][key] for 2 x 16 keys ------------------------------------------------------------------------
@@ -137,19 +160,31 @@ __global__ __launch_bounds__(256, 2) void attn_flash_k(const bf16_t* __restrict_
     }
 }
 
-template <int D>
-static int launch_attn(const void* Q, const void* K, const void* V, void* O, int N, int hw, int ldq, int ldk, int ldv,
-                       int ldo, float scale, hipStream_t st) {
-    const size_t lds = (size_t)(2 * AT_BK * (D + AT_PAD) + 4 * 16 * (AT_BK + AT_PAD)) * sizeof(bf16_t);
+template <int D, int AT_BQ>
+static int launch_attn_bq(const void* Q, const void* K, const void* V, void* O, int N, int hw, int ldq, int ldk, int ldv,
+                          int ldo, float scale, hipStream_t st) {
+    constexpr int AT_WAVES = AT_BQ / 16;
+    const size_t lds = (size_t)(2 * AT_BK * (D + AT_PAD) + AT_WAVES * 16 * (AT_BK + AT_PAD)) * sizeof(bf16_t);
     static bool attr = false;
     if (!attr) {
-        if (hipFuncSetAttribute((const void*)attn_flash_k<D>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        if (hipFuncSetAttribute((const void*)attn_flash_k<D, AT_BQ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return fail(RBVAE_E_LAUNCH, "attention: cannot reserve %zu bytes of LDS", lds);
         attr = true;
     }
-    hipLaunchKernelGGL(attn_flash_k<D>, dim3(cdiv(hw, AT_BQ), N), dim3(256), lds, st, (const bf16_t*)Q, (const bf16_t*)K,
-                       (const bf16_t*)V, (bf16_t*)O, hw, ldq, ldk, ldv, ldo, scale * 1.4426950408889634f);
+    hipLaunchKernelGGL((attn_flash_k<D, AT_BQ>), dim3(cdiv(hw, AT_BQ), N), dim3(64 * AT_WAVES), lds, st, (const bf16_t*)Q,
+                       (const bf16_t*)K, (const bf16_t*)V, (bf16_t*)O, hw, ldq, ldk, ldv, ldo, scale * 1.4426950408889634f);
     return RBVAE_OK;
+}
+
+// Query tile: 64 rows (4 waves, two workgroups per CU: one's tile transfer and barriers hide behind the other's
+// products) or 128 rows (8 waves, one per CU: every staged K / V tile feeds twice the products).  RBVAE_ATTN_BQ picks;
+// default chosen by measurement (tools/time_attn.py).
+template <int D>
+static int launch_attn(const void* Q, const void* K, const void* V, void* O, int N, int hw, int ldq, int ldk, int ldv,
+                       int ldo, float scale, hipStream_t st) {
+    static const int bq = getenv("RBVAE_ATTN_BQ") ? atoi(getenv("RBVAE_ATTN_BQ")) : 64;
+    if (bq == 128) return launch_attn_bq<D, 128>(Q, K, V, O, N, hw, ldq, ldk, ldv, ldo, scale, st);
+    return launch_attn_bq<D, 64>(Q, K, V, O, N, hw, ldq, ldk, ldv, ldo, scale, st);
 }
 
 }  // namespace rbvae
