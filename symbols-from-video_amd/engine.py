@@ -261,6 +261,7 @@ class Engine:
         self.lstm_wgrad_tail = os.environ.get("RBVAE_LSTM_WGRAD_TAIL", "1") == "1"
         self.tail_wgrads = int(os.environ.get("RBVAE_TAIL_WGRADS", "0"))
         self.side_wg_cap = os.environ.get("RBVAE_SIDE_WG_CAP", "1") == "1"
+        self.mid_reduce = os.environ.get("RBVAE_MID_REDUCE", "0") == "1"
         # RBVAE_STREAM_GEMM=1 sends the K = 64 products of the 3/4-channel ends to the row-streaming kernel
         # (rbvae_stream_gemm) instead of the tiled gather GEMM.  Bit-identical results; measured on the bench shapes
         # (tools/abl_stream.py): conv1 forward 17.5 -> 15.4-16.6 us, last-deconv backward (gate + column sums)
@@ -1117,6 +1118,18 @@ class Engine:
             ev_mid = torch.cuda.Event()
             ev_mid.record(torch.cuda.current_stream())
             mid_jobs, self._jobs = self._jobs, JobList()
+        elif tail_ok and self.mid_reduce:
+            # RBVAE_MID_REDUCE=1: everything reducible so far (conv3 / conv2 slabs, bias sums) is reduced on the side
+            # stream's tail, beside the last data-gradient GEMM; the final launch keeps conv1's and the fc's pieces
+            ev_m = torch.cuda.Event()
+            ev_m.record(torch.cuda.current_stream())
+            mid_only, self._jobs = self._jobs, JobList()
+
+            def run_mid():
+                saved, self._jobs = self._jobs, mid_only
+                self._run_jobs()
+                self._jobs = saved
+            side_tail.append((ev_m, run_mid))
         elif self._side_on(self.SIDE_ENC_REDUCE):
             # everything reducible so far (fc, conv3, conv2 slabs; the LSTM-side column sums) goes to the side stream
             # now, beside the last data-gradient GEMM and conv1's weight gradient; only those two's reductions

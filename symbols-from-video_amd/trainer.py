@@ -108,6 +108,11 @@ class FusedTrainer:
         self.early_update = self.world == 1 and os.environ.get("RBVAE_EARLY_UPDATE", "0") == "1"
         self._packed_ver = None
         self._red = None
+        # RBVAE_PREFETCH_DATA=1: gather the NEXT step's batch on the side stream during the backward pass instead of at
+        # the start of the step.  Measured (same box, 2 x 2 runs): 0.4542 vs 0.4508 ms/step -- the 5.6 us gather already
+        # hides in the gap between two graph launches -- so it is off.
+        self.prefetch_data = os.environ.get("RBVAE_PREFETCH_DATA", "0") == "1"
+        self._primed = False          # set_data mode: the input buffer holds the batch of the coming step
 
     # ---- the two halves of a step (plain launches; captured below) ------------------
     def _fwd_bwd(self, x, U, tau, B, T, cut=None, masks=None):
@@ -134,11 +139,16 @@ class FusedTrainer:
                 L.call("rbvae_contrast_term_fwd", h0, h1, B, T, Ld, pair)
                 L.call("rbvae_contrast_term_bwd", h0, h1, B, T, Ld, float(self.alpha), None, g_hs[:B], g_hs[B:])
 
-        if self._data is not None and self._data_active:
-            # the batch of this step: gathered from the HBM-resident table by the device step counter (inside the graph)
+        data_mode = self._data is not None and self._data_active
+
+        def gather_batch():
+            # batch (device step counter % n_batches) of the plan, gathered from the HBM-resident table
             table, plan, _, _ = self._data
             L.call("rbvae_gather_frames", table, table.shape[0], plan, plan.shape[1], plan.shape[0], self.step_dev,
                    table[0].numel(), x)
+
+        if data_mode and not self.prefetch_data:
+            gather_batch()
         # dropout follows the module's mode like the reference (model.train() in train_one_epoch, :501)
         # x is the item batch [B, 2, T, C, H, W] as it is; frame (v, b, t) = sequence v*B + b, state t
         chw = numel // (2 * B * T)
@@ -161,6 +171,10 @@ class FusedTrainer:
             L.call("rbvae_combine_losses", sse_ws, nparts, inv_n, None, kl_parts, nkl, kl_scale, *pargs,
                    float(self.beta_kl), float(self.alpha), self.losses, self.step_dev, float(self.lr), self.lr_dev,
                    float(b1), float(b2), self.hyper)
+            if data_mode and self.prefetch_data:
+                # the NEXT step's batch (the counter has just advanced): the forward pass is done with the input buffer,
+                # so the gather rides the side stream beside the backward pass instead of opening the next step
+                gather_batch()
 
         eng.backward(model._flat, self.gflat, out["saved"], None, g_hs, None, kl_weight=self.beta_kl, kl_p=self.p,
                      g_hs_inplace=True, side_first=bookkeeping, cut=cut,
@@ -246,15 +260,26 @@ class FusedTrainer:
             from .model import _mask_to_rows
             masks = [torch.cat([_mask_to_rows(dropout_masks[0][j].to(self.dev)),
                                 _mask_to_rows(dropout_masks[1][j].to(self.dev))]) for j in range(4)]
-        if not self.use_graph or self.instrument is not None or masks is not None:
+        graph = None
+        if self.use_graph and self.instrument is None and masks is None:
+            graph = self._graphs.get(key)
+            if graph is None:
+                graph = self._capture(st["x"], Uarg, float(temperature), B, T)
+                self._graphs[key] = graph
+                self._primed = False      # the capture's warm-up steps gathered ahead and were rolled back
+        if from_data and self.prefetch_data and not self._primed:
+            # first step of a plan (or after anything else used the buffer): gather this step's batch now; from here on
+            # every step gathers its successor's
+            table, plan, _, _ = self._data
+            L.call("rbvae_gather_frames", table, table.shape[0], plan, plan.shape[1], plan.shape[0], self.step_dev,
+                   table[0].numel(), st["x"])
+        self._primed = from_data and self.prefetch_data
+        if graph is None:
             self._fwd_bwd(st["x"], Uarg, float(temperature), B, T, masks=masks)
             self._allreduce()
             self._update()
         else:
-            g = self._graphs.get(key)
-            if g is None:
-                g = self._capture(st["x"], Uarg, float(temperature), B, T)
-                self._graphs[key] = g
+            g = graph
             g[0].replay()
             if len(g) == 3:
                 # tail (decoder CNN + LSTM gradients) on the collective's stream beside the encoder CNN's backward graph
@@ -382,6 +407,7 @@ class FusedTrainer:
         else:
             self._data = (table, flat, B, T)
             self._graphs = {k: g for k, g in self._graphs.items() if not k[4]}
+        self._primed = False
     _data_active = False
 
     def input_buffer(self, B: int, T: int, C: int, H: int, W: int) -> torch.Tensor:
