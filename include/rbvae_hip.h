@@ -305,7 +305,7 @@ int rbvae_lstm_bwd_ex(const float* wblk, const float* acts, const float* cs, con
  * launch: the arithmetic of rbvae_lstm_fwd(enc) + rbvae_binarize_kl_fwd_parts + rbvae_lstm_fwd(dec), with the same
  * optional slab input / cast output as the _ex forms.  hs_dec slot 0 receives z; kl_parts[s] (may be NULL) = KL sum
  * of sequence s (S parts; mean = sum / (S*T)).  rbvae_lstm_pair_fwd_ok tells whether the shape is covered
- * (L <= 32, L % 4 == 0, 2 * layers * roundup64(4L) <= 1024). */
+ * (L <= 32, 2 * layers * roundup64(4L) <= 1024). */
 int rbvae_lstm_pair_fwd_ok(int T, int L, int layers);
 int rbvae_lstm_pair_fwd(const float* wblk_enc, const float* wT_enc, const float* wblk_dec, const float* wT_dec,
                         float* hs_enc, float* hprev_enc, float* acts_enc, float* cs_enc, float* hs_dec,

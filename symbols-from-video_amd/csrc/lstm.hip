@@ -609,17 +609,22 @@ struct PairArgs {
     int S, T, L, layers, G;
 };
 
-template <int LMAX, bool EXACT>
+// LC: compile-time length of the dot products (a multiple of 4 with roundup4(L) == LC), 0 = the run-time L: with a
+// run-time bound every 16-byte chunk sits in its own basic block
+template <int LMAX, bool EXACT, int LC = 0>
 __global__ __launch_bounds__(1024) void lstm_pair_fwd_k(const PairArgs p) {
     RBVAE_RAISE_PRIO();
     const int L = EXACT ? LMAX : p.L;
     const int T = p.T, S = p.S, layers = p.layers, G = p.G;
     const float inv_tau_src = p.tau_dev ? p.tau_dev[0] : p.tau;   // uniform: one scalar load at the top of the kernel
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    float* hbuf = sm;                                    // [2][layers+1][T][L]: stack, slot, time
-    float* gates = hbuf + 2 * (layers + 1) * T * L;      // [2*layers][4L] activated gates
-    float* nbuf = gates + 2 * layers * 4 * L;            // [T][L] noise term of the binarisation
-    float* red = nbuf + T * L;                           // [16] block reduction
+    // LDS rows of L values sit at a stride of LS = roundup4(L) with zero padding, so the 16-byte reads of the dot
+    // products stay aligned for any L (the reference's most common latent_dim is 25)
+    const int LS = EXACT ? LMAX : ((L + 3) & ~3);
+    float* hbuf = sm;                                    // [2][layers+1][T][LS]: stack, slot, time
+    float* gates = hbuf + 2 * (layers + 1) * T * LS;     // [2*layers][4L] activated gates
+    float* nbuf = gates + 2 * layers * 4 * L;            // [T][LS] noise term of the binarisation
+    float* red = nbuf + T * LS;                          // [16] block reduction
     const int q = threadIdx.x / G, j = threadIdx.x - q * G;         // global layer index, gate row
     const int stack = q >= layers, l = q - (stack ? layers : 0);
     const int s = blockIdx.x;
@@ -629,7 +634,7 @@ __global__ __launch_bounds__(1024) void lstm_pair_fwd_k(const PairArgs p) {
     float* hprev = stack ? p.hp_d : p.hp_e;
     float* acts = stack ? p.acts_d : p.acts_e;
     float* cs = stack ? p.cs_d : p.cs_e;
-    float* hb = hbuf + stack * (layers + 1) * T * L;     // this stack's slots
+    float* hb = hbuf + stack * (layers + 1) * T * LS;    // this stack's slots
     // this thread's weight rows first: their loads are in flight while the input is staged
     const float* wblk = stack ? p.wblk_d : p.wblk_e;
     const float* wT = stack ? p.wT_d : p.wT_e;
@@ -673,10 +678,11 @@ __global__ __launch_bounds__(1024) void lstm_pair_fwd_k(const PairArgs p) {
         v += np > 3 ? a3 : 0.f;
         for (int k = 4; k < np; ++k) v += ip[k * st];
         if (parts) p.hs_e[o] = v;
-        hbuf[i] = v;
+        const int li = EXACT ? i : (i / L) * LS + i % L;
+        hbuf[li] = v;
         const unsigned long long seed = p.seed + (p.seed_dev ? sdev * 0x9E3779B97F4A7C15ull : 0ull);
         const float u = p.U ? uin : (float)(hash_u32(seed, (unsigned long long)o) >> 8) * (1.0f / 16777216.0f);
-        nbuf[i] = p.ratio * (logf(u + p.neps) - logf(1.0f - u + p.neps));
+        nbuf[li] = p.ratio * (logf(u + p.neps) - logf(1.0f - u + p.neps));
     }
     if (p.cast_out) {
         const int pw = p.cast_ld - L;
@@ -687,21 +693,23 @@ __global__ __launch_bounds__(1024) void lstm_pair_fwd_k(const PairArgs p) {
     }
     float c = 0.f;
     // every slot but the encoder input is read (times a zero factor) before it is written: keep them finite
-    for (int i = T * L + threadIdx.x; i < 2 * (layers + 1) * T * L; i += blockDim.x) hbuf[i] = 0.f;
+    // (and the padding of the input rows: read by the last 16-byte chunk of a dot product)
+    for (int i = threadIdx.x; i < 2 * (layers + 1) * T * LS; i += blockDim.x)
+        if (i >= T * LS || (!EXACT && i % LS >= L)) hbuf[i] = 0.f;
     __syncthreads();
     const int ndiag = T + 2 * layers - 1;
     for (int d = 0; d < ndiag; ++d) {
         const int t = d - q;
         const bool active = t >= 0 && t < T;
         if (active && row) {
-            const float* xt = hb + (l * T + t) * L;
-            const float* hp = hb + ((l + 1) * T + (t > 0 ? t - 1 : 0)) * L;
+            const float* xt = hb + (l * T + t) * LS;
+            const float* hp = hb + ((l + 1) * T + (t > 0 ? t - 1 : 0)) * LS;
             const float hscale = t > 0 ? 1.f : 0.f;
             float a0 = bsum, a1 = 0.f, a2 = 0.f, a3 = 0.f;
             float b0 = 0.f, b1 = 0.f, b2 = 0.f, b3 = 0.f;
 #pragma unroll
             for (int k = 0; k < LMAX; k += 4) {
-                if (k < L) {
+                if (LC ? k < LC : k < L) {
                     const float4 xv = *(const float4*)(xt + k), hv = *(const float4*)(hp + k);
                     a0 = fmaf(wih[k], xv.x, a0); a1 = fmaf(wih[k + 1], xv.y, a1);
                     a2 = fmaf(wih[k + 2], xv.z, a2); a3 = fmaf(wih[k + 3], xv.w, a3);
@@ -718,10 +726,10 @@ __global__ __launch_bounds__(1024) void lstm_pair_fwd_k(const PairArgs p) {
         if (active && j < L) {
             const float* gl = gates + q * 4 * L;
             const float ig = gl[j], fg = gl[L + j], gg = gl[2 * L + j], og = gl[3 * L + j];
-            const float hpv = t > 0 ? hb[((l + 1) * T + t - 1) * L + j] : 0.f;
+            const float hpv = t > 0 ? hb[((l + 1) * T + t - 1) * LS + j] : 0.f;
             c = fmaf(fg, c, ig * gg);        // explicit: the same rounding in every kernel that runs this cell
             const float h = og * fast_tanh(c);
-            hb[((l + 1) * T + t) * L + j] = h;
+            hb[((l + 1) * T + t) * LS + j] = h;
             const long o = (((long)l * S + s) * T + t);
             if (acts) {
                 cs[o * L + j] = c;
@@ -731,11 +739,11 @@ __global__ __launch_bounds__(1024) void lstm_pair_fwd_k(const PairArgs p) {
             if (q == layers - 1) {
                 // binary_concrete_logits on the encoder's output (percep_RBVAE_model.py:17-44): z feeds the decoder stack
                 const long e = ((long)s * T + t) * L + j;
-                const float y = sigmoidf_((h + nbuf[t * L + j]) / inv_tau_src);
+                const float y = sigmoidf_((h + nbuf[t * LS + j]) / inv_tau_src);
                 const float zz = p.hard ? (y > 0.5f ? 1.0f : 0.0f) : y;
                 p.y_soft[e] = y;
                 p.hs_d[e] = zz;
-                hbuf[(layers + 1) * T * L + t * L + j] = zz;          // decoder stack, slot 0
+                hbuf[(layers + 1) * T * LS + t * LS + j] = zz;        // decoder stack, slot 0
             }
             if (p.cast_out && q == 2 * layers - 1) {
                 const long oc = ((long)s * T + t) * p.cast_ld + j;
@@ -748,7 +756,8 @@ __global__ __launch_bounds__(1024) void lstm_pair_fwd_k(const PairArgs p) {
         // KL of this sequence's T*L codes (kl_binary_concrete on the sample, percep_RBVAE_train.py:528), off the
         // dependent chain: one element per thread, fixed-order block sum
         float a = 0.f;
-        for (int i = threadIdx.x; i < T * L; i += blockDim.x) a += kl_elem(hbuf[(layers + 1) * T * L + i], p.lp, p.l1p, p.keps, p.clamp);
+        for (int i = threadIdx.x; i < T * L; i += blockDim.x)
+            a += kl_elem(hbuf[(layers + 1) * T * LS + (EXACT ? i : (i / L) * LS + i % L)], p.lp, p.l1p, p.keps, p.clamp);
         const float tot = block_sum(a, red);
         if (threadIdx.x == 0) p.kl_parts[s] = tot;
     }
@@ -1161,8 +1170,9 @@ int rbvae_lstm_fwd_ex(const float* wblk, const float* wT, float* hs_all, float* 
 
 int rbvae_lstm_pair_fwd_ok(int T, int L, int layers) {
     const int threads = ((4 * L + 63) / 64) * 64;
-    const size_t lds = (size_t)(2 * (layers + 1) * T * L + 2 * layers * 4 * L + T * L + 16) * sizeof(float);
-    return L <= 32 && L % 4 == 0 && 2 * layers * threads <= 1024 && lds <= 64 * 1024;
+    const int LS = (L + 3) & ~3;
+    const size_t lds = (size_t)(2 * (layers + 1) * T * LS + 2 * layers * 4 * L + T * LS + 16) * sizeof(float);
+    return L <= 32 && 2 * layers * threads <= 1024 && lds <= 64 * 1024;
 }
 
 int rbvae_lstm_pair_fwd(const float* wblk_enc, const float* wT_enc, const float* wblk_dec, const float* wT_dec,
@@ -1195,9 +1205,12 @@ int rbvae_lstm_pair_fwd(const float* wblk_enc, const float* wT_enc, const float*
     a.cast_out = cast_out; a.cast_bf16 = cast_dtype == RBVAE_BF16; a.cast_ld = cast_ld;
     const int threads = ((4 * L + 63) / 64) * 64;
     a.S = S; a.T = T; a.L = L; a.layers = layers; a.G = threads;
-    const size_t lds = (size_t)(2 * (layers + 1) * T * L + 2 * layers * 4 * L + T * L + 16) * sizeof(float);
+    const int LS = (L + 3) & ~3;
+    const size_t lds = (size_t)(2 * (layers + 1) * T * LS + 2 * layers * 4 * L + T * LS + 16) * sizeof(float);
     if (L == 32)
         hipLaunchKernelGGL((lstm_pair_fwd_k<32, true>), dim3(S), dim3(2 * layers * threads), lds, (hipStream_t)stream, a);
+    else if (LS == 28)      // latent_dim 25 (the reference's most common) .. 28
+        hipLaunchKernelGGL((lstm_pair_fwd_k<32, false, 28>), dim3(S), dim3(2 * layers * threads), lds, (hipStream_t)stream, a);
     else
         hipLaunchKernelGGL((lstm_pair_fwd_k<32, false>), dim3(S), dim3(2 * layers * threads), lds, (hipStream_t)stream, a);
     RBVAE_CHECK_LAUNCH("lstm_pair_fwd");

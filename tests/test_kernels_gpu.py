@@ -454,7 +454,8 @@ def test_split_fc_slabs_feed_the_lstm_kernels(sfv):
                       64, 1, torch.zeros(2, 6, 64, device="cuda"), 2, 6 * 64, None, 0, 0)
 
 
-@pytest.mark.parametrize("L,layers,S,T,hard", [(32, 4, 5, 8, 0), (32, 2, 3, 5, 1), (24, 2, 4, 9, 0)])
+@pytest.mark.parametrize("L,layers,S,T,hard", [(32, 4, 5, 8, 0), (32, 2, 3, 5, 1), (24, 2, 4, 9, 0), (25, 4, 3, 8, 0), (25, 2, 2, 5, 1),
+                                               (7, 2, 2, 3, 0), (30, 4, 2, 17, 0)])
 def test_lstm_pair_forward_equals_three_launches(sfv, L, layers, S, T, hard):
     """rbvae_lstm_pair_fwd (encoder stack -> binarise -> decoder stack, one wavefront) against rbvae_lstm_fwd +
     rbvae_binarize_kl_fwd_parts + rbvae_lstm_fwd: every saved tensor to f32 rounding (2e-6), hard codes equal
