@@ -335,6 +335,14 @@ int rbvae_lstm_wgrad_pair(const float* dG_a, const float* hs_a, const float* hpr
 int rbvae_gather_frames(const float* table, long table_rows, const long* plan, int rows, int n_batches,
                         const unsigned long long* counter_dev, long frame_elems, float* out, void* stream);
 
+/* The majority vote of calculate_state_consistency (percep_RBVAE_train.py:473-497: np.unique(axis=0, return_counts) +
+ * argmax per state) on the device: codes [F][L] (binary, L <= 128) are packed to 128-bit keys (element 0 most
+ * significant: key order = np.unique's row order, ties go to the smallest), out[s] = {frames of state s that carry the
+ * state's most common code, frames of state s}.  labels [F] int32 in [0, n_states); keys_ws: 16 F bytes (16-byte
+ * aligned), counts_ws: F ints. */
+int rbvae_state_vote(const float* codes, const int* labels, int F, int L, int n_states, void* keys_ws, int* counts_ws,
+                     int* out, void* stream);
+
 /* torch.optim.Adam defaults (percep_RBVAE_train.py:753,553) on a flat f32 buffer; g is scaled by gscale
  * first.  The step number comes from `step` or, when step_dev != NULL, from a device counter that the call
  * first ADVANCES by one (then hyper_ws, 2 floats, receives the bias-correction terms): graph-replay safe.

@@ -170,6 +170,22 @@ def consistency_from_codes(codes: torch.Tensor, labels, n_states: int):
     """percep_RBVAE_train.py:473-497 on a device tensor of {0,1} codes [F, L]: per state the share of frames
     equal to the state's most common code (ties: lexicographically smallest, like np.unique), then the
     count-weighted mean.  Returns (weighted_avg, percentages)."""
+    if codes.is_cuda:
+        # the device path: 128-bit keys + vote kernels (csrc/eval.hip), one tiny result copy
+        from . import _lib as L
+        F, Ld = codes.shape
+        if F == 0:
+            return 0, [0.0] * n_states
+        lab = torch.as_tensor(np.asarray(labels), dtype=torch.int32).to(codes.device)
+        keys = torch.empty(F, 4, dtype=torch.int32, device=codes.device)
+        cnt = torch.empty(F, dtype=torch.int32, device=codes.device)
+        out = torch.empty(n_states, 2, dtype=torch.int32, device=codes.device)
+        L.call("rbvae_state_vote", codes.float().contiguous(), lab, F, Ld, n_states, keys, cnt, out)
+        res = out.cpu().numpy()
+        pct = [float(b / n) if n > 0 else 0.0 for b, n in res]
+        total = int(res[:, 1].sum())
+        return (float(np.dot(pct, res[:, 1]) / total) if total > 0 else 0), pct
+    # host tensors (the reference's own np.unique path, percep_RBVAE_train.py:473-497)
     labels = torch.as_tensor(np.asarray(labels), device=codes.device)
     pct: List[float] = []
     counts: List[int] = []

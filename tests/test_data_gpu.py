@@ -109,3 +109,28 @@ def test_planned_epoch_trains_from_the_resident_table():
                 tr.set_data(ds.table, plan + 1000)
         res.append((torch.stack(losses), None))
     assert torch.equal(res[0][0], res[1][0])
+
+
+@pytest.mark.parametrize("F,L,n_states", [(300, 6, 6), (2500, 25, 9), (700, 128, 3), (64, 33, 5)])
+def test_device_majority_vote_equals_np_unique(F, L, n_states):
+    """rbvae_state_vote (128-bit keys, device vote) == the oracle's np.unique + argmax (percep_RBVAE_train.py:473-497),
+    including ties between equally common codes (smallest row wins), an empty state, and 128-bit codes."""
+    import sfv_amd as sfv
+    gen = torch.Generator().manual_seed(F + L)
+    # few distinct codes per state so that counts collide: draw from a small pool of prototype rows
+    pool = (torch.rand(7, L, generator=gen) > 0.5).float()
+    codes = pool[torch.randint(0, 7, (F,), generator=gen)]
+    flip = torch.rand(F, L, generator=gen) < 0.01
+    codes = torch.where(flip, 1 - codes, codes)
+    labels = torch.randint(0, n_states - 1, (F,), generator=gen).numpy()      # the last state stays empty
+    # force an exact tie in state 0: two codes with the same count
+    idx0 = np.where(labels == 0)[0]
+    if len(idx0) >= 4:
+        half = len(idx0) // 2
+        codes[idx0[:half]] = pool[0]
+        codes[idx0[half:2 * half]] = pool[1]
+        codes[idx0[2 * half:]] = pool[2]
+    avg, pct = sfv.consistency_from_codes(codes.cuda(), labels, n_states)
+    ravg, rpct = O.state_consistency(codes.numpy(), labels, n_states)
+    assert abs(avg - ravg) < 1e-12 and np.allclose(pct, rpct), (pct, rpct)
+    assert pct[n_states - 1] == 0.0
