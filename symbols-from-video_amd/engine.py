@@ -262,6 +262,10 @@ class Engine:
         self.tail_wgrads = int(os.environ.get("RBVAE_TAIL_WGRADS", "0"))
         self.side_wg_cap = os.environ.get("RBVAE_SIDE_WG_CAP", "1") == "1"
         self.mid_reduce = os.environ.get("RBVAE_MID_REDUCE", "0") == "1"
+        # RBVAE_WFC_SWAP=1: the encoder fc's weight gradient with rows / columns swapped (full 128-row tiles on the 64-column
+        # kernel instance).  Same box, 2 x 2 runs: 0.4696 (swapped) vs 0.4666 ms/step -- the launch rides the side tail
+        # either way -- so the plain form stays.
+        self.wfc_swap = os.environ.get("RBVAE_WFC_SWAP", "0") == "1"
         # RBVAE_STREAM_GEMM=1 sends the K = 64 products of the 3/4-channel ends to the row-streaming kernel
         # (rbvae_stream_gemm) instead of the tiled gather GEMM.  Bit-identical results; measured on the bench shapes
         # (tools/abl_stream.py): conv1 forward 17.5 -> 15.4-16.6 us, last-deconv backward (gate + column sums)
@@ -1062,8 +1066,15 @@ class Engine:
             de_pad = tmp("de_pad", N, self.Lp)
             L.call("rbvae_cast_pad", self.dt, de, de_pad, N, Ld, self.Lp)
         def wfc_wgrad():
-            self._wgrad(de_pad, sv.a3, None, N, self.Lp, self.F3, self.Lp, self.F3, 1, G("encoder_cnn.fc.weight"),
-                        (Ld, c3, g3), (self.F3, 1, c3), tag=(N, "Wfc"))
+            if self.Lp <= 64 and self.wfc_swap:
+                # roles swapped: rows = the F3 flatten positions (full 128-row tiles), columns = the <= 64 padded logits
+                # (the 64-column instance) -- as [Lp rows] x [F3 columns] half of every 128 x 128 tile was padding.
+                # Slab element (f, l) -> torch (l, c, g) with f = g * c3 + c (NHWC-flat position)
+                self._wgrad(sv.a3, de_pad, None, N, self.F3, self.Lp, self.F3, self.Lp, 1, G("encoder_cnn.fc.weight"),
+                            (Ld, c3, g3), (1, self.Lp, c3 * self.Lp), tag=(N, "Wfc"))
+            else:
+                self._wgrad(de_pad, sv.a3, None, N, self.Lp, self.F3, self.Lp, self.F3, 1, G("encoder_cnn.fc.weight"),
+                            (Ld, c3, g3), (self.F3, 1, c3), tag=(N, "Wfc"))
 
         # The encoder fc's weight gradient is a 32-workgroup launch nothing on the data-gradient chain waits for: with
         # the deferred side work it rides the side stream (behind an event on de_pad), so the main chain goes
