@@ -195,6 +195,8 @@ int rbvae_colsum(int dtype, const void* X, int P, int C, int ld, float* out, flo
  * (nn.Conv2d / nn.ConvTranspose2d weights, percep_RBVAE_model.py:51-57,76-82, in the two GEMM operand orders),
  * 4 = conv weight-gradient reduce: src = rbvae_wgrad_gemm's K-slice slabs [nslab][d0=co][d2=kk<=16][d1=ci] (f32,
  * ci % 4 == 0), summed in slab order into dst [co][ci][kk] (the torch layout of the weight; scale, accumulate honoured).
+ * 5 = batch gather (rbvae_gather_frames as a job: src = table, dst = out, d0 = rows, d1 = n_batches, d2 = float4 per frame,
+ * s0 = plan pointer, s1 = counter pointer or 0, s2 = table rows) -- shares the launch of the step's weight repack.
  * fast: the logical index consecutive threads walk; inner != 0 (fast == 1, short d2): a thread walks d2 itself.
  * One launch (grid.y = job) replaces the per-tensor launches of a step. */
 int rbvae_run_jobs(const void* jobs_dev, int njobs, int blocks_per_job, void* stream);

@@ -8,7 +8,9 @@ namespace rbvae {
 struct Job {
     long type;        // 0 pack3 (f32 -> T, strided scatter), 1 permute_reduce (thread per output), 2 reduce_rows (wave per
                       // output), 3 conv weight [co][ci][kk] f32 -> both GEMM orders [co][t][ci] (dst) and [ci][t][co] (dst2),
-                      // 4 conv weight-gradient slabs [ks][co][t][ci] -> [co][ci][kk] (d0 = co, d1 = ci, d2 = kk)
+                      // 4 conv weight-gradient slabs [ks][co][t][ci] -> [co][ci][kk] (d0 = co, d1 = ci, d2 = kk),
+                      // 5 batch gather: dst[r] = src[plan[(*counter % d1) * d0 + r]] (d0 rows of d2 float4; s0 = plan, s1 = counter
+                      //   pointer or 0, s2 = table rows)
     const float* src;
     void* dst;
     long d0, d1, d2;  // logical extents [d0][d1][d2] (the contiguous side is laid out in this order)
@@ -204,6 +206,22 @@ __global__ __launch_bounds__(256) void run_jobs_k(const Job* __restrict__ jobs) 
     }
     if (j.type == 4) {
         conv_reduce_rows(j, (float*)lds_raw);
+        return;
+    }
+    if (j.type == 5) {
+        // batch gather from the HBM-resident latent table (rbvae_gather_frames as a job, so that it shares the launch of
+        // the step's weight repack): dst[r] = src[plan[(counter % n_batches) * rows + r]], 16 bytes per lane
+        const long rows = j.d0, nb = j.d1, vec = j.d2, table_rows = j.s2;
+        const long* plan = (const long*)j.s0;
+        const unsigned long long* counter = (const unsigned long long*)j.s1;
+        const long b = counter ? (long)(counter[0] % (unsigned long long)nb) : 0;
+        const float4* table = (const float4*)j.src;
+        float4* out = (float4*)j.dst;
+        for (long r = blockIdx.x; r < rows; r += gridDim.x) {
+            long src = plan[b * rows + r];
+            if (src < 0 || src >= table_rows) src = 0;
+            for (long i = threadIdx.x; i < vec; i += 256) out[r * vec + i] = table[src * vec + i];
+        }
         return;
     }
     const unsigned d0 = (unsigned)j.d0, d1 = (unsigned)j.d1, d2 = (unsigned)j.d2;

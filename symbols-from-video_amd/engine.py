@@ -139,7 +139,7 @@ def dgrad_classes(k: int) -> Tuple[List[int], int]:
 
 ONE_TAP = [1, 0, 0, 0, 0, 0]
 
-JOB_PACK, JOB_PERMUTE, JOB_ROWS, JOB_CONV_PACK, JOB_CONV_REDUCE = 0, 1, 2, 3, 4
+JOB_PACK, JOB_PERMUTE, JOB_ROWS, JOB_CONV_PACK, JOB_CONV_REDUCE, JOB_GATHER = 0, 1, 2, 3, 4, 5
 
 
 class JobList:
@@ -239,6 +239,7 @@ class Engine:
         self._bwd_tab: Dict = {}       # uploaded reduce-job tables, keyed by their signature
         self._jobs: Optional[JobList] = None
         self._wg_cus = 256
+        self.first_launch_jobs = None  # extra job rows for the repack launch at the start of a forward(repack=True)
         self._job_blocks = int(os.environ.get("RBVAE_JOB_BLOCKS", "256"))      # workgroups per job of a batched job launch
         self._sides: List[Optional[torch.cuda.Stream]] = [None, None]
         # weight-gradient work of the decoder runs on a side stream beside the LSTM backward chain (RBVAE_OVERLAP=0:
@@ -309,12 +310,15 @@ class Engine:
         self.wT_enc = torch.zeros(nl, 2, Ld, 4 * Ld, dtype=torch.float32, device=self.device)   # [k][gate row]
         self.wT_dec = torch.zeros(nl, 2, Ld, 4 * Ld, dtype=torch.float32, device=self.device)
 
-    def pack(self, flat: torch.Tensor):
-        """f32 parameters (reference layouts) -> the packed T copies the GEMMs read (one launch)."""
-        key = flat.data_ptr()
+    def pack(self, flat: torch.Tensor, extra_rows=None):
+        """f32 parameters (reference layouts) -> the packed T copies the GEMMs read (one launch).
+        extra_rows: further job rows for the same launch (the fused trainer's batch gather, JOB_GATHER)."""
+        key = (flat.data_ptr(), tuple(map(tuple, extra_rows)) if extra_rows else None)
         tab = self._pack_tab.get(key)
         if tab is None:
             jl = self._pack_jobs(flat)
+            if extra_rows:
+                jl.rows = [list(r) for r in extra_rows] + jl.rows       # first: its blocks start first
             tab = (jl.upload(self.device), len(jl.rows), jl)
             self._pack_tab[key] = tab
         L.call("rbvae_run_jobs", tab[0], tab[1], self._job_blocks)
@@ -364,10 +368,15 @@ class Engine:
         if n:
             L.call("rbvae_run_jobs", t, n, self._job_blocks)
 
+    def _pack_one_launch(self) -> bool:
+        return not self._side_on(self.SIDE_PACK) and not self.pack_late_split
+
     def pack_begin(self, flat: torch.Tensor):
         if not self._side_on(self.SIDE_PACK) and not self.pack_late_split:
-            self.pack(flat)                 # nothing leaves the main stream: one launch for every copy
+            self.pack(flat, self.first_launch_jobs)     # nothing leaves the main stream: one launch for every copy
             return
+        if self.first_launch_jobs:
+            raise RuntimeError("extra first-launch jobs need the one-launch repack (RBVAE_SIDE bit 1 / RBVAE_PACK_LATE off)")
         first, early, _, _ = self._pack_split(flat)
         self._fork(1, self.SIDE_PACK)
         with self._on_side(1, self.SIDE_PACK):

@@ -113,6 +113,7 @@ class FusedTrainer:
         # hides in the gap between two graph launches -- so it is off.
         self.prefetch_data = os.environ.get("RBVAE_PREFETCH_DATA", "0") == "1"
         self._primed = False          # set_data mode: the input buffer holds the batch of the coming step
+        self.gather_in_pack = os.environ.get("RBVAE_GATHER_IN_PACK", "1") == "1"
 
     # ---- the two halves of a step (plain launches; captured below) ------------------
     def _fwd_bwd(self, x, U, tau, B, T, cut=None, masks=None):
@@ -147,8 +148,17 @@ class FusedTrainer:
             L.call("rbvae_gather_frames", table, table.shape[0], plan, plan.shape[1], plan.shape[0], self.step_dev,
                    table[0].numel(), x)
 
+        eng.first_launch_jobs = None
         if data_mode and not self.prefetch_data:
-            gather_batch()
+            if self.gather_in_pack and not self.early_update and eng._pack_one_launch():
+                # the gather rides the launch of the weight repack that opens the step (one launch less on the chain)
+                table, plan, _, _ = self._data
+                from .engine import JOB_GATHER
+                eng.first_launch_jobs = [[JOB_GATHER, table.data_ptr(), x.data_ptr(), plan.shape[1], plan.shape[0],
+                                          table[0].numel() // 4, plan.data_ptr(), self.step_dev.data_ptr(), table.shape[0],
+                                          1, 0, 0, 0, 0, 0, 0]]
+            else:
+                gather_batch()
         # dropout follows the module's mode like the reference (model.train() in train_one_epoch, :501)
         # x is the item batch [B, 2, T, C, H, W] as it is; frame (v, b, t) = sequence v*B + b, state t
         chw = numel // (2 * B * T)
