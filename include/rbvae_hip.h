@@ -197,6 +197,12 @@ int rbvae_colsum(int dtype, const void* X, int P, int C, int ld, float* out, flo
  * ci % 4 == 0), summed in slab order into dst [co][ci][kk] (the torch layout of the weight; scale, accumulate honoured).
  * 5 = batch gather (rbvae_gather_frames as a job: src = table, dst = out, d0 = rows, d1 = n_batches, d2 = float4 per frame,
  * s0 = plan pointer, s1 = counter pointer or 0, s2 = table rows) -- shares the launch of the step's weight repack.
+ * 6 / 7 = torch.optim.Adam update (percep_RBVAE_train.py:553) of one parameter tensor inside the job launch: src points
+ * into the flat parameter buffer, `inner` holds a pointer to the optimiser context (8 x int64: w, g, m, v base pointers,
+ * hyper pointer [lr/(1-b1^t), sqrt(1-b2^t)], then f32 pairs (1-b1, b2), (1-b2, eps), (gscale, 0)); kind 6 also writes the
+ * tensor's packed copies from the new values: dst with strides (s0, s1, s2) in type dtype & 255 and optionally dst2 with
+ * strides (nslab, slab, accumulate) in type dtype >> 8.  Kind 3 with `inner` set updates the conv weight rows it packs.
+ * A table of these jobs is the optimiser step AND the weight repack of a training step in one launch.
  * fast: the logical index consecutive threads walk; inner != 0 (fast == 1, short d2): a thread walks d2 itself.
  * One launch (grid.y = job) replaces the per-tensor launches of a step. */
 int rbvae_run_jobs(const void* jobs_dev, int njobs, int blocks_per_job, void* stream);

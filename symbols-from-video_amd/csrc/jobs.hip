@@ -10,7 +10,9 @@ struct Job {
                       // output), 3 conv weight [co][ci][kk] f32 -> both GEMM orders [co][t][ci] (dst) and [ci][t][co] (dst2),
                       // 4 conv weight-gradient slabs [ks][co][t][ci] -> [co][ci][kk] (d0 = co, d1 = ci, d2 = kk),
                       // 5 batch gather: dst[r] = src[plan[(*counter % d1) * d0 + r]] (d0 rows of d2 float4; s0 = plan, s1 = counter
-                      //   pointer or 0, s2 = table rows)
+                      //   pointer or 0, s2 = table rows),
+                      // 6 / 7 Adam update of a parameter tensor (+ its packed copies for 6), `inner` = AdamCtx*; kind 3 with
+                      //   `inner` set updates the conv weight rows it packs
     const float* src;
     void* dst;
     long d0, d1, d2;  // logical extents [d0][d1][d2] (the contiguous side is laid out in this order)
@@ -25,12 +27,44 @@ struct Job {
 };
 static_assert(sizeof(Job) == 16 * 8, "job table stride");
 
+// Optimiser context of the fused update jobs (kinds 3 with `inner` set, 6, 7): torch.optim.Adam on the flat buffers, the
+// arithmetic of adam_k (layout.hip) element for element.  w / g / m / v are the BASES of the flat parameter, gradient
+// and moment buffers; a job's src points into w and addresses the other three at the same offset.
+struct AdamCtx {
+    float* w; const float* g; float* m; float* v;
+    const float* hyper;                 // [step size lr / (1 - b1^t), sqrt(1 - b2^t)] (rbvae_combine_losses)
+    float one_m_b1, b2, one_m_b2, eps, gscale, pad_;
+};
+static_assert(sizeof(AdamCtx) == 8 * 8, "adam context layout (8 x int64 on the host side)");
+
+__device__ __forceinline__ float adam_value(float w, float g, float& m, float& v, const AdamCtx& c, float step_size,
+                                            float bc2_sqrt) {
+    const float gi = g * c.gscale;
+    const float m0 = m;
+    const float mi = m0 + c.one_m_b1 * (gi - m0);
+    const float vi = v * c.b2 + (c.one_m_b2 * gi) * gi;
+    m = mi;
+    v = vi;
+    const float denom = sqrtf(vi) / bc2_sqrt + c.eps;
+    return w - step_size * (mi / denom);
+}
+// update element `off` of the flat buffers in place, return the new weight
+__device__ __forceinline__ float adam_at(const AdamCtx& c, long off, float step_size, float bc2_sqrt) {
+    float m = c.m[off], v = c.v[off];
+    const float w = adam_value(c.w[off], c.g[off], m, v, c, step_size, bc2_sqrt);
+    c.m[off] = m; c.v[off] = v; c.w[off] = w;
+    return w;
+}
+
 // Type 3: a conv / conv-transpose weight [co][ci][kk] (f32 master, rows of ci*kk contiguous values) -> both GEMM orders,
 // [co][t][ci] (dst, forward GEMM) and [ci][t][co] (dst2, backward-data GEMM), in the storage type T.
 // A workgroup owns NCO = 16 / sizeof(T) output channels and ALL of ci x kk: the rows come in by 16-byte loads, sit in
 // LDS in T, and leave as 16-byte stores on both sides -- [co][t][ci] as whole 16-byte runs of ci, [ci][t][co] as the
 // 16-byte run of the workgroup's NCO channels (the per-element 2-byte stores of the first version moved 30 MB in
 // 15 us).  Weights with more than CPK_MAXROW values per channel take the workgroup's rows in pieces of ci.
+#ifndef CPK_CIB
+#define CPK_CIB 64
+#endif
 constexpr int CPK_MAXROW = 2304;                       // 256 ci x 9 taps (or 144 ci x 16 taps)
 constexpr int CPK_LDS_BYTES = 16 * (CPK_MAXROW + 8);  // NCO rows of T, NCO * sizeof(T) = 16; +8 elements of pad per row
 template <typename T>
@@ -42,17 +76,55 @@ __device__ __forceinline__ void conv_pack_rows(const Job& j, unsigned char* lds_
     // ci block: a multiple of NV such that cib * kk <= CPK_MAXROW
     unsigned cib = (CPK_MAXROW / kk) / NV * NV;
     if (cib > Ci) cib = Ci;
+    // pieces of 64 input channels: 4x the workgroups for a 256-channel weight (128 per weight; with whole rows the
+    // fused optimiser update ran on 32 workgroups per weight and took 35 us longer than the unfused step)
+    if (cib > CPK_CIB && Ci % CPK_CIB == 0) cib = CPK_CIB;
     const unsigned ncb = (Ci + cib - 1) / cib, ngr = (Co + NCO - 1) / NCO;
     const unsigned pitch = CPK_MAXROW + 8;
     T* wf = (T*)j.dst;
     T* wd = (T*)j.dst2;
     const bool vec_ok = (Ci % NV == 0) && (Co % NCO == 0) && ((cib * kk) % 4 == 0) && ((Ci * kk) % 4 == 0);
+    // fused optimiser update (j.inner = AdamCtx*): the block updates exactly the master rows it packs, so the packed
+    // copies are written from the new values without a second pass (and without a launch of their own)
+    const AdamCtx* actx = (const AdamCtx*)j.inner;
+    float step_size = 0.f, bc2_sqrt = 1.f;
+    if (actx) { step_size = actx->hyper[0]; bc2_sqrt = actx->hyper[1]; }
     for (unsigned b = blockIdx.x; b < ngr * ncb; b += gridDim.x) {
         const unsigned co0 = (b / ncb) * NCO, ci0 = (b % ncb) * cib;
         const unsigned cn = min(cib, Ci - ci0), row = cn * kk;       // this piece: cn input channels
         __syncthreads();
         // ---- in: NCO rows of `row` consecutive floats each
-        if (vec_ok) {
+        if (vec_ok && actx) {
+            const unsigned r4 = row / 4, tot = NCO * r4;
+            constexpr unsigned AB = 3;                                     // 3 x (w, g, m, v) float4 in flight per thread
+            for (unsigned i0 = threadIdx.x; i0 < tot; i0 += AB * 256) {
+                float4 w4[AB], g4[AB], m4[AB], v4[AB];
+                long off[AB];
+#pragma unroll
+                for (unsigned u = 0; u < AB; ++u) {
+                    const unsigned i = i0 + u * 256, ic = i < tot ? i : 0;
+                    const unsigned r = ic / r4, q = ic - r * r4;
+                    off[u] = (j.src - actx->w) + ((long)(co0 + r) * Ci + ci0) * kk + 4 * q;
+                    w4[u] = *(const float4*)(actx->w + off[u]); g4[u] = *(const float4*)(actx->g + off[u]);
+                    m4[u] = *(const float4*)(actx->m + off[u]); v4[u] = *(const float4*)(actx->v + off[u]);
+                }
+#pragma unroll
+                for (unsigned u = 0; u < AB; ++u) {
+                    const unsigned i = i0 + u * 256;
+                    if (i < tot) {
+                        float4 w = w4[u], m = m4[u], v = v4[u];
+                        w.x = adam_value(w.x, g4[u].x, m.x, v.x, *actx, step_size, bc2_sqrt);
+                        w.y = adam_value(w.y, g4[u].y, m.y, v.y, *actx, step_size, bc2_sqrt);
+                        w.z = adam_value(w.z, g4[u].z, m.z, v.z, *actx, step_size, bc2_sqrt);
+                        w.w = adam_value(w.w, g4[u].w, m.w, v.w, *actx, step_size, bc2_sqrt);
+                        *(float4*)(actx->w + off[u]) = w; *(float4*)(actx->m + off[u]) = m; *(float4*)(actx->v + off[u]) = v;
+                        const unsigned r = i / r4, q = i - r * r4;
+                        T* d = tile + r * pitch + 4 * q;
+                        Elem<T>::store(d, w.x); Elem<T>::store(d + 1, w.y); Elem<T>::store(d + 2, w.z); Elem<T>::store(d + 3, w.w);
+                    }
+                }
+            }
+        } else if (vec_ok) {
             // every load of the thread in flight before the first LDS store (a load per loop iteration paid a memory
             // round trip each: 18 of them per workgroup)
             const unsigned r4 = row / 4, tot = NCO * r4;
@@ -79,7 +151,11 @@ __device__ __forceinline__ void conv_pack_rows(const Job& j, unsigned char* lds_
         } else {
             for (unsigned i = threadIdx.x; i < NCO * row; i += 256) {
                 const unsigned r = i / row, e = i - r * row;
-                const float v = co0 + r < Co ? j.src[((size_t)(co0 + r) * Ci + ci0) * kk + e] : 0.f;
+                float v = 0.f;
+                if (co0 + r < Co) {
+                    const size_t so = ((size_t)(co0 + r) * Ci + ci0) * kk + e;
+                    v = actx ? adam_at(*actx, (j.src - actx->w) + (long)so, step_size, bc2_sqrt) : j.src[so];
+                }
                 Elem<T>::store(tile + r * pitch + e, v);
             }
         }
@@ -206,6 +282,29 @@ __global__ __launch_bounds__(256) void run_jobs_k(const Job* __restrict__ jobs) 
     }
     if (j.type == 4) {
         conv_reduce_rows(j, (float*)lds_raw);
+        return;
+    }
+    if (j.type == 6 || j.type == 7) {
+        // 6: optimiser update of a parameter tensor [d0][d1][d2] + its packed copies: dst (strides s0, s1, s2, type
+        //    dtype & 255) and optionally dst2 (strides nslab, slab, accumulate; type dtype >> 8); 7: update only.
+        // One thread per master element, consecutive threads on consecutive elements (w, g, m, v move coalesced).
+        const AdamCtx c = *(const AdamCtx*)j.inner;
+        const float step_size = c.hyper[0], bc2_sqrt = c.hyper[1];
+        const unsigned d1 = (unsigned)j.d1, d2 = (unsigned)j.d2;
+        const long n = j.d0 * j.d1 * j.d2, base = j.src - c.w;
+        const int t1 = (int)(j.dtype & 255), t2 = (int)((j.dtype >> 8) & 255);
+        for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+            const float w = adam_at(c, base + i, step_size, bc2_sqrt);
+            if (j.type == 6) {
+                const unsigned i2 = (unsigned)(i % d2), r = (unsigned)(i / d2), i1 = r % d1, i0 = r / d1;
+                const size_t o1 = i0 * (size_t)j.s0 + i1 * (size_t)j.s1 + i2 * (size_t)j.s2;
+                if (t1 == RBVAE_F32) ((float*)j.dst)[o1] = w; else ((bf16_t*)j.dst)[o1] = f32_to_bf16(w);
+                if (j.dst2) {
+                    const size_t o2 = i0 * (size_t)j.nslab + i1 * (size_t)j.slab + i2 * (size_t)j.accumulate;
+                    if (t2 == RBVAE_F32) ((float*)j.dst2)[o2] = w; else ((bf16_t*)j.dst2)[o2] = f32_to_bf16(w);
+                }
+            }
+        }
         return;
     }
     if (j.type == 5) {

@@ -139,7 +139,7 @@ def dgrad_classes(k: int) -> Tuple[List[int], int]:
 
 ONE_TAP = [1, 0, 0, 0, 0, 0]
 
-JOB_PACK, JOB_PERMUTE, JOB_ROWS, JOB_CONV_PACK, JOB_CONV_REDUCE, JOB_GATHER = 0, 1, 2, 3, 4, 5
+JOB_PACK, JOB_PERMUTE, JOB_ROWS, JOB_CONV_PACK, JOB_CONV_REDUCE, JOB_GATHER, JOB_ADAM_PACK, JOB_ADAM = 0, 1, 2, 3, 4, 5, 6, 7
 
 
 class JobList:
@@ -367,6 +367,56 @@ class Engine:
         t, n = tab[group]
         if n:
             L.call("rbvae_run_jobs", t, n, self._job_blocks)
+
+    def update_jobs(self, flat, gflat, m, v, hyper, betas, eps, gscale, extra_rows=None):
+        """Optimiser step + weight repack of a training step as ONE batched job launch: every parameter tensor is a job
+        that applies torch.optim.Adam to its slice of the flat buffers (the arithmetic of rbvae_adam_step) and writes
+        the tensor's packed copies from the new values while it holds them -- kind 3 (conv weights: the block updates
+        the rows it packs), kind 6 (generic scatter to one or two copies), kind 7 (no packed copy: biases).
+        Returns (device table, n_jobs); cached per buffer set."""
+        import struct
+        key = ("update", flat.data_ptr(), gflat.data_ptr(), m.data_ptr(), v.data_ptr(), hyper.data_ptr(), tuple(betas),
+               float(eps), float(gscale), tuple(map(tuple, extra_rows)) if extra_rows else None)
+        tab = self._pack_tab.get(key)
+        if tab is not None:
+            return tab[0], tab[1]
+        f2 = lambda a, b: struct.unpack("<q", struct.pack("<ff", float(a), float(b)))[0]
+        b1, b2 = betas
+        ctx = torch.tensor([flat.data_ptr(), gflat.data_ptr(), m.data_ptr(), v.data_ptr(), hyper.data_ptr(),
+                            f2(1.0 - b1, b2), f2(1.0 - b2, eps), f2(gscale, 0.0)], dtype=torch.int64).to(self.device)
+        jl = self._pack_jobs(flat)
+        by_src: Dict[int, List[List[int]]] = {}
+        for row in jl.rows:
+            by_src.setdefault(row[1], []).append(row)
+        lay = self.layout
+        rows: List[List[int]] = [list(r) for r in extra_rows] if extra_rows else []
+        cp = ctx.data_ptr()
+        for name in lay.names:
+            src = lay.view(flat, name)
+            n = src.numel()
+            packs = by_src.pop(src.data_ptr(), [])
+            if len(packs) == 1 and packs[0][0] == JOB_CONV_PACK:
+                r = list(packs[0])
+                r[14] = cp
+                rows.append(r)
+            elif packs and all(p_[0] == JOB_PACK for p_ in packs) and len(packs) <= 2:
+                a = packs[0]
+                bq = packs[1] if len(packs) == 2 else None
+                if bq is not None and tuple(bq[3:6]) != tuple(a[3:6]):
+                    raise RuntimeError(f"{name}: its two packed copies walk different logical shapes")
+                t2 = bq[11] if bq is not None else 0
+                rows.append([JOB_ADAM_PACK, a[1], a[2], a[3], a[4], a[5], a[6], a[7], a[8],
+                             bq[6] if bq is not None else 0, bq[7] if bq is not None else 0, a[11] | (t2 << 8),
+                             bq[8] if bq is not None else 0, 0, cp, bq[2] if bq is not None else 0])
+            elif not packs:
+                rows.append([JOB_ADAM, src.data_ptr(), 0, n, 1, 1, 0, 0, 0, 0, 0, 0, 0, 0, cp, 0])
+            else:
+                raise RuntimeError(f"{name}: unsupported pack job combination for the fused update")
+        if by_src:
+            raise RuntimeError("pack jobs whose source is not a parameter tensor")
+        t = torch.tensor(rows, dtype=torch.int64).to(self.device)
+        self._pack_tab[key] = (t, len(rows), ctx, jl)
+        return t, len(rows)
 
     def _pack_one_launch(self) -> bool:
         return not self._side_on(self.SIDE_PACK) and not self.pack_late_split

@@ -112,6 +112,12 @@ class FusedTrainer:
         # the start of the step.  Measured (same box, 2 x 2 runs): 0.4542 vs 0.4508 ms/step -- the 5.6 us gather already
         # hides in the gap between two graph launches -- so it is off.
         self.prefetch_data = os.environ.get("RBVAE_PREFETCH_DATA", "0") == "1"
+        # The optimiser step AND the weight repack as ONE batched job launch (engine.update_jobs): every parameter tensor's
+        # job applies Adam to its slice of the flat buffers and writes the packed copies from the new values while it
+        # holds them; in set_data mode the same launch gathers the next step's batch.  The step then opens directly with
+        # the first convolution: no repack launch, no gather launch, no separate Adam launch.
+        # RBVAE_FUSED_UPDATE=0: rbvae_adam_step at the end, repack (+ gather) job launch at the start of the next step.
+        self.fused_update = os.environ.get("RBVAE_FUSED_UPDATE", "1") == "1" and not self.early_update
         self._primed = False          # set_data mode: the input buffer holds the batch of the coming step
         self.gather_in_pack = os.environ.get("RBVAE_GATHER_IN_PACK", "1") == "1"
 
@@ -149,14 +155,12 @@ class FusedTrainer:
                    table[0].numel(), x)
 
         eng.first_launch_jobs = None
-        if data_mode and not self.prefetch_data:
+        if data_mode and not self._gather_ahead():
             if self.gather_in_pack and not self.early_update and eng._pack_one_launch():
                 # the gather rides the launch of the weight repack that opens the step (one launch less on the chain)
                 table, plan, _, _ = self._data
                 from .engine import JOB_GATHER
-                eng.first_launch_jobs = [[JOB_GATHER, table.data_ptr(), x.data_ptr(), plan.shape[1], plan.shape[0],
-                                          table[0].numel() // 4, plan.data_ptr(), self.step_dev.data_ptr(), table.shape[0],
-                                          1, 0, 0, 0, 0, 0, 0]]
+                eng.first_launch_jobs = [self._gather_row(x)]
             else:
                 gather_batch()
         # dropout follows the module's mode like the reference (model.train() in train_one_epoch, :501)
@@ -164,7 +168,7 @@ class FusedTrainer:
         chw = numel // (2 * B * T)
         out = eng.forward(model._flat, x.view(2 * B, T, *x.shape[3:]), U, tau, False, self.r, bool(model.training), masks,
                           seed=self._noise_key, need_grad=True, target=x, recon_gscale=2.0 / numel, kl_p=self.p,
-                          after_hs=pair_term, defer_losses=True, repack=not self.early_update,
+                          after_hs=pair_term, defer_losses=True, repack=not (self.early_update or self.fused_update),
                           frame_map=(B * T, T, T * chw, 2 * T * chw, chw), tau_dev=self.tau_dev)
         sse_ws, nparts, inv_n = out["sse"]
         kl_parts, nkl, kl_scale = out["kl"]
@@ -181,7 +185,7 @@ class FusedTrainer:
             L.call("rbvae_combine_losses", sse_ws, nparts, inv_n, None, kl_parts, nkl, kl_scale, *pargs,
                    float(self.beta_kl), float(self.alpha), self.losses, self.step_dev, float(self.lr), self.lr_dev,
                    float(b1), float(b2), self.hyper)
-            if data_mode and self.prefetch_data:
+            if data_mode and self.prefetch_data and not self.fused_update:
                 # the NEXT step's batch (the counter has just advanced): the forward pass is done with the input buffer,
                 # so the gather rides the side stream beside the backward pass instead of opening the next step
                 gather_batch()
@@ -207,9 +211,28 @@ class FusedTrainer:
 
         return {"dec": upd(o_dec, n, "dec"), "mid": upd(o_c2, o_dec, "mid"), "fin": upd(0, o_c2, "fin")}
 
+    def _gather_ahead(self) -> bool:
+        """set_data mode: is the batch of a step gathered by its predecessor (so that the first step must be primed)?"""
+        return self.prefetch_data or self.fused_update
+
+    def _gather_row(self, x):
+        table, plan, _, _ = self._data
+        from .engine import JOB_GATHER
+        return [JOB_GATHER, table.data_ptr(), x.data_ptr(), plan.shape[1], plan.shape[0], table[0].numel() // 4,
+                plan.data_ptr(), self.step_dev.data_ptr(), table.shape[0], 1, 0, 0, 0, 0, 0, 0]
+
     def _update(self):
         if self.early_update:
             return                    # done group by group inside the backward pass
+        if self.fused_update:
+            extra = None
+            if self._data is not None and self._data_active:
+                B, T = self._data[2], self._data[3]
+                extra = [self._gather_row(self._static[(B, T)]["x"])]      # the next step's batch (the counter has advanced)
+            tab, n = self.eng.update_jobs(self.model._flat, self.gflat, self.m, self.vv, self.hyper, self.betas, self.eps,
+                                          1.0 / self.world, extra)
+            L.call("rbvae_run_jobs", tab, n, self.eng._job_blocks)
+            return
         b1, b2 = self.betas
         L.call("rbvae_adam_step", self.model._flat, self.gflat, self.m, self.vv, self.gflat.numel(), float(self.lr),
                float(b1), float(b2), float(self.eps), 0, 1.0 / self.world, None, self.hyper)
@@ -243,7 +266,7 @@ class FusedTrainer:
             self.eng.seed_dev = self.step_dev
         Ld = model.latent_dim
         self._data_active = from_data
-        if self.early_update:
+        if self.early_update or self.fused_update:
             # the step leaves every packed weight copy current; repack here only when the weights changed behind the
             # trainer's back (first step, load_state_dict, a foreign optimiser)
             ver = tuple(p._version for p in model._params())
@@ -277,13 +300,13 @@ class FusedTrainer:
                 graph = self._capture(st["x"], Uarg, float(temperature), B, T)
                 self._graphs[key] = graph
                 self._primed = False      # the capture's warm-up steps gathered ahead and were rolled back
-        if from_data and self.prefetch_data and not self._primed:
+        if from_data and self._gather_ahead() and not self._primed:
             # first step of a plan (or after anything else used the buffer): gather this step's batch now; from here on
             # every step gathers its successor's
             table, plan, _, _ = self._data
             L.call("rbvae_gather_frames", table, table.shape[0], plan, plan.shape[1], plan.shape[0], self.step_dev,
                    table[0].numel(), st["x"])
-        self._primed = from_data and self.prefetch_data
+        self._primed = from_data and self._gather_ahead()
         if graph is None:
             self._fwd_bwd(st["x"], Uarg, float(temperature), B, T, masks=masks)
             self._allreduce()
@@ -302,7 +325,7 @@ class FusedTrainer:
                 self._allreduce()
                 g[1].replay()
         self.steps += 1
-        if self.early_update:
+        if self.early_update or self.fused_update:
             self.model._packed_version = (id(self.eng), self._packed_ver)      # the packed copies are current
         else:
             self.model._packed_version = None  # anything else that runs the model before the next step repacks first
