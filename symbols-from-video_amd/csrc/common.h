@@ -67,6 +67,20 @@ __device__ __forceinline__ float block_sum(float v, float* red) {
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 
+// torch.optim.Adam on one element (percep_RBVAE_train.py:753,553): g is scaled by gscale, m / v are updated in place,
+// the new weight is returned.  step_size = lr / (1 - b1^t), bc2_sqrt = sqrt(1 - b2^t).  Explicit fma placement: every
+// kernel that updates parameters (adam_k, the fused update jobs) rounds identically.
+__device__ __forceinline__ float adam_update(float w, float g, float& m, float& v, float one_m_b1, float b2, float one_m_b2,
+                                             float eps, float gscale, float step_size, float bc2_sqrt) {
+    const float gi = g * gscale;
+    const float mi = fmaf(one_m_b1, gi - m, m);
+    const float vi = fmaf(one_m_b2 * gi, gi, v * b2);
+    m = mi;
+    v = vi;
+    const float denom = sqrtf(vi) / bc2_sqrt + eps;
+    return fmaf(-step_size, mi / denom, w);
+}
+
 // KL(Bernoulli(q) || Bernoulli(p)) per element, q = sigmoid(v) (percep_RBVAE_train.py:59-70); lp = log p, l1p = log(1-p)
 __device__ __forceinline__ float kl_elem(float v, float lp, float l1p, float eps, int clamp) {
     float q = sigmoidf_(v);

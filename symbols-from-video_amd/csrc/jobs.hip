@@ -39,14 +39,7 @@ static_assert(sizeof(AdamCtx) == 8 * 8, "adam context layout (8 x int64 on the h
 
 __device__ __forceinline__ float adam_value(float w, float g, float& m, float& v, const AdamCtx& c, float step_size,
                                             float bc2_sqrt) {
-    const float gi = g * c.gscale;
-    const float m0 = m;
-    const float mi = m0 + c.one_m_b1 * (gi - m0);
-    const float vi = v * c.b2 + (c.one_m_b2 * gi) * gi;
-    m = mi;
-    v = vi;
-    const float denom = sqrtf(vi) / bc2_sqrt + c.eps;
-    return w - step_size * (mi / denom);
+    return adam_update(w, g, m, v, c.one_m_b1, c.b2, c.one_m_b2, c.eps, c.gscale, step_size, bc2_sqrt);
 }
 // update element `off` of the flat buffers in place, return the new weight
 __device__ __forceinline__ float adam_at(const AdamCtx& c, long off, float step_size, float bc2_sqrt) {

@@ -482,14 +482,10 @@ __global__ void adam_k(float* __restrict__ w, const float* __restrict__ g, float
                        float eps, float bc2_sqrt, float gscale, const float* __restrict__ hyper) {
     if (hyper) { step_size = hyper[0]; bc2_sqrt = hyper[1]; }
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
-        const float gi = g[i] * gscale;
-        const float m0 = m[i];
-        const float mi = m0 + one_m_b1 * (gi - m0);
-        const float vi = v[i] * b2 + (one_m_b2 * gi) * gi;
+        float mi = m[i], vi = v[i];
+        w[i] = adam_update(w[i], g[i], mi, vi, one_m_b1, b2, one_m_b2, eps, gscale, step_size, bc2_sqrt);
         m[i] = mi;
         v[i] = vi;
-        const float denom = sqrtf(vi) / bc2_sqrt + eps;
-        w[i] = w[i] - step_size * (mi / denom);
     }
 }
 

@@ -680,3 +680,44 @@ def test_conv_reduce_job_matches_permute_reduce(sfv, Co, Ci, kk, ks, acc):
     want = slabs.sum(0).permute(0, 2, 1) * 0.5 + (base if acc else 0)
     assert torch.allclose(out, want, atol=1e-5, rtol=1e-5)
     assert torch.equal(out, ref)
+
+
+@pytest.mark.parametrize("variant,in_ch,dtype,Ld,hw", [("percep", 4, "bf16", 32, (16, 16)), ("percep", 4, "f32", 25, (16, 24)),
+                                                        ("contrastive", 3, "bf16", 50, (32, 16))])
+def test_fused_update_jobs_equal_adam_plus_pack(sfv, variant, in_ch, dtype, Ld, hw):
+    """Engine.update_jobs (optimiser step + weight repack as one batched job launch: kinds 3 / 6 / 7 with an Adam context)
+    against rbvae_adam_step followed by Engine.pack: parameters, both moments and every packed copy bit for bit."""
+    from importlib import import_module
+    E = import_module("symbols-from-video_amd.engine")
+    g = torch.Generator().manual_seed(95)
+    packed = ("W1p", "W2f", "W2d", "W3f", "W3d", "Wfc", "WfcT", "Wdfc", "WdfcT", "bdfc", "V1f", "V1d", "V2f", "V2d", "V3p",
+              "V3f", "wT_enc", "wT_dec")
+    res = []
+    for fused in (False, True):
+        eng = E.Engine(variant, in_ch, in_ch, Ld, hw, dtype, torch.device("cuda", 0))
+        n = eng.layout.total
+        gen = torch.Generator().manual_seed(96)
+        flat = (torch.randn(n, generator=gen) * 0.1).cuda()
+        grad = (torch.randn(n, generator=gen) * 0.01).cuda()
+        m = (torch.randn(n, generator=gen) * 0.01).cuda()
+        v = (torch.rand(n, generator=gen) * 1e-4).cuda()
+        step = torch.tensor([6], dtype=torch.int64, device="cuda")
+        hyper = torch.zeros(2, device="cuda")
+        one = torch.ones(1, device="cuda")
+        out4 = torch.empty(4, device="cuda")
+        # the bias-correction terms as the trainer prepares them (step 7)
+        sfv._lib.call("rbvae_combine_losses", None, 0, 0.0, one, one, 0, 0.0, one, 0, 0.0, 0.0, 1.0, 1.0, out4, step, 2e-3, None,
+                      0.9, 0.999, hyper)
+        if fused:
+            tab, nj = eng.update_jobs(flat, grad, m, v, hyper, (0.9, 0.999), 1e-8, 0.5)
+            sfv._lib.call("rbvae_run_jobs", tab, nj, 256)
+        else:
+            sfv._lib.call("rbvae_adam_step", flat, grad, m, v, n, 2e-3, 0.9, 0.999, 1e-8, 0, 0.5, None, hyper)
+            eng.pack(flat)
+        torch.cuda.synchronize()
+        lay = eng.layout
+        # (the alignment gaps between tensors belong to no parameter: the fused jobs do not touch them)
+        pv = {f"{t}/{nm}": lay.view(buf, nm).clone() for t, buf in (("w", flat), ("m", m), ("v", v)) for nm in lay.names}
+        res.append({**pv, **{k: getattr(eng, k).clone() for k in packed}})
+    for k in res[0]:
+        assert torch.equal(res[0][k], res[1][k]), k
