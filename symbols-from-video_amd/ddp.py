@@ -78,6 +78,17 @@ class GradReducer:
             return dist.all_reduce(self.tail, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         return None
 
+    def start_head(self):
+        if self.world > 1:
+            return dist.all_reduce(self.head, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        return None
+
+    @staticmethod
+    def wait(work):
+        """Make the current stream wait for an asynchronous all-reduce (no host block with RCCL)."""
+        if work is not None:
+            work.wait()
+
     def finish(self, work):
         if self.world > 1:
             dist.all_reduce(self.head, op=dist.ReduceOp.SUM, group=self.group)

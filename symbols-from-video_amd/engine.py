@@ -368,15 +368,17 @@ class Engine:
         if n:
             L.call("rbvae_run_jobs", t, n, self._job_blocks)
 
-    def update_jobs(self, flat, gflat, m, v, hyper, betas, eps, gscale, extra_rows=None):
+    def update_jobs(self, flat, gflat, m, v, hyper, betas, eps, gscale, extra_rows=None, part=None):
         """Optimiser step + weight repack of a training step as ONE batched job launch: every parameter tensor is a job
         that applies torch.optim.Adam to its slice of the flat buffers (the arithmetic of rbvae_adam_step) and writes
         the tensor's packed copies from the new values while it holds them -- kind 3 (conv weights: the block updates
         the rows it packs), kind 6 (generic scatter to one or two copies), kind 7 (no packed copy: biases).
-        Returns (device table, n_jobs); cached per buffer set."""
+        part: None = every parameter; "tail" / "head" = the data-parallel trainer's gradient buckets (decoder CNN + both
+        LSTM stacks / encoder CNN, cut at decoder_cnn.fc.weight): the tail is updated while the head is still being
+        all-reduced.  Returns (device table, n_jobs); cached per buffer set."""
         import struct
         key = ("update", flat.data_ptr(), gflat.data_ptr(), m.data_ptr(), v.data_ptr(), hyper.data_ptr(), tuple(betas),
-               float(eps), float(gscale), tuple(map(tuple, extra_rows)) if extra_rows else None)
+               float(eps), float(gscale), tuple(map(tuple, extra_rows)) if extra_rows else None, part)
         tab = self._pack_tab.get(key)
         if tab is not None:
             return tab[0], tab[1]
@@ -391,10 +393,13 @@ class Engine:
         lay = self.layout
         rows: List[List[int]] = [list(r) for r in extra_rows] if extra_rows else []
         cp = ctx.data_ptr()
+        o_cut = lay.offsets["decoder_cnn.fc.weight"]
         for name in lay.names:
             src = lay.view(flat, name)
             n = src.numel()
             packs = by_src.pop(src.data_ptr(), [])
+            if part is not None and (lay.offsets[name] >= o_cut) != (part == "tail"):
+                continue
             if len(packs) == 1 and packs[0][0] == JOB_CONV_PACK:
                 r = list(packs[0])
                 r[14] = cp

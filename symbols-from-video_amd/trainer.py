@@ -221,16 +221,17 @@ class FusedTrainer:
         return [JOB_GATHER, table.data_ptr(), x.data_ptr(), plan.shape[1], plan.shape[0], table[0].numel() // 4,
                 plan.data_ptr(), self.step_dev.data_ptr(), table.shape[0], 1, 0, 0, 0, 0, 0, 0]
 
-    def _update(self):
+    def _update(self, part=None):
+        """part: None, or "tail" / "head" (fused update only): one gradient bucket's parameters."""
         if self.early_update:
             return                    # done group by group inside the backward pass
         if self.fused_update:
             extra = None
-            if self._data is not None and self._data_active:
+            if self._data is not None and self._data_active and part != "tail":
                 B, T = self._data[2], self._data[3]
                 extra = [self._gather_row(self._static[(B, T)]["x"])]      # the next step's batch (the counter has advanced)
             tab, n = self.eng.update_jobs(self.model._flat, self.gflat, self.m, self.vv, self.hyper, self.betas, self.eps,
-                                          1.0 / self.world, extra)
+                                          1.0 / self.world, extra, part)
             L.call("rbvae_run_jobs", tab, n, self.eng._job_blocks)
             return
         b1, b2 = self.betas
@@ -314,7 +315,18 @@ class FusedTrainer:
         else:
             g = graph
             g[0].replay()
-            if len(g) == 3:
+            if len(g) == 4:
+                # tail (decoder CNN + LSTM gradients) all-reduced on the collective's stream beside the encoder CNN's
+                # backward graph; the head's all-reduce beside the tail's optimiser update + repack
+                red = self._reducer()
+                wt = red.start_tail()
+                g[1].replay()
+                wh = red.start_head()
+                red.wait(wt)
+                g[2].replay()
+                red.wait(wh)
+                g[3].replay()
+            elif len(g) == 3:
                 # tail (decoder CNN + LSTM gradients) on the collective's stream beside the encoder CNN's backward graph
                 red = self._reducer()
                 w = red.start_tail()
@@ -487,7 +499,11 @@ class FusedTrainer:
         with torch.cuda.stream(s):
             for _ in range(2):
                 self._fwd_bwd(x, U, tau, B, T, cut=(lambda: None) if (self.world > 1 and self.ddp_overlap) else None)
-                self._update()
+                if self.world > 1 and self.ddp_overlap and self.fused_update:
+                    self._update("tail")          # (the warm-up also builds the job tables the capture replays)
+                    self._update("head")
+                else:
+                    self._update()
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
         g1, g2 = torch.cuda.CUDAGraph(), None
@@ -514,8 +530,18 @@ class FusedTrainer:
                 self._fwd_bwd(x, U, tau, B, T, cut=cut)
                 g2.capture_end()
                 g3.capture_begin(pool=pool)
-                self._update()
-                g3.capture_end()
+                g4 = None
+                if self.fused_update:
+                    # the update in the two gradient buckets: the tail's runs while the head is still being all-reduced
+                    self._update("tail")
+                    g3.capture_end()
+                    g4 = torch.cuda.CUDAGraph()
+                    g4.capture_begin(pool=pool)
+                    self._update("head")
+                    g4.capture_end()
+                else:
+                    self._update()
+                    g3.capture_end()
             torch.cuda.current_stream().wait_stream(cs)
             self.model._flat.copy_(flat0)
             self.m.copy_(m0)
@@ -523,7 +549,7 @@ class FusedTrainer:
             self.step_dev.copy_(s0)
             self.eng.pack(self.model._flat)
             torch.cuda.synchronize()
-            return g1, g2, g3
+            return (g1, g2, g3) if g4 is None else (g1, g2, g3, g4)
         else:
             g2 = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g1, pool=pool):

@@ -55,7 +55,10 @@ def _worker(rank, world, port, q):
     g_b, g_1 = gflat.clone(), gflat.clone()
     red = ddp.GradReducer(g_b, lay.offsets["decoder_cnn.fc.weight"])
     assert red.world == world and red.tail.numel() + red.head.numel() == lay.total
-    red.finish(red.start_tail())
+    wt = red.start_tail()
+    wh = red.start_head()
+    red.wait(wt)
+    red.wait(wh)
     ddp.GradReducer(g_1, lay.offsets["decoder_cnn.fc.weight"]).reduce_all()
     ddp.allreduce_mean_(gflat)
     assert torch.equal(g_b / world, gflat) and torch.equal(g_1 / world, gflat)

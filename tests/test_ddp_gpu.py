@@ -86,7 +86,7 @@ def _launch(world, overlap):
 def test_ddp_overlap_matches_single_allreduce():
     n_graphs_a, flat_a = _launch(2, 1)
     n_graphs_b, flat_b = _launch(2, 0)
-    assert n_graphs_a == 3 and n_graphs_b == 2
+    assert n_graphs_a == 4 and n_graphs_b == 2      # overlapped: fwd+bwd to the cut | rest of bwd | update(tail) | update(head)
     assert torch.equal(flat_a, flat_b)
     # sanity against one process on the global batch (per-rank losses are shard means, their average is the global mean);
     # Adam turns bf16 accumulation-order noise on near-zero gradients into +-lr steps, hence the loose bound -- the

@@ -42,3 +42,11 @@ for key, val in eng._pack_tab.items():
         time_tab("pack", *val)
 for sig, (tab, n, jl) in eng._bwd_tab.items():
     time_tab("bwd reduce", tab, n, jl)
+
+# the fused update launch (Adam + packed copies), whole and job by job
+tab, nj = eng.update_jobs(model._flat, tr.gflat, tr.m, tr.vv, tr.hyper, tr.betas, tr.eps, 1.0)
+rows = tab.cpu().tolist()
+names.update({5: "gather", 6: "adam+pack", 7: "adam"})
+class _JL: pass
+jl = _JL(); jl.rows = rows
+time_tab("fused update", tab, nj, jl)
