@@ -109,6 +109,10 @@ def dbg_call(name, *args):
                 fn.restype = restype
                 fn.argtypes = [t for t, _ in a]
         _dbg = l
-    rc = getattr(_dbg, name)(*[_ptr(a) for a in args], stream_ptr())
+    fn = getattr(_dbg, name, None)
+    if fn is None:                              # a stamp hook: lives in the stamped build of the main library (RBVAE_LIB)
+        fn = getattr(lib(), name)
+        fn.restype, fn.argtypes = parse_header(DBG_HEADER)[name][0], [t for t, _ in parse_header(DBG_HEADER)[name][1]]
+    rc = fn(*[_ptr(a) for a in args], stream_ptr())
     if rc != 0:
         raise RuntimeError(f"{name} failed ({rc}): {lib().rbvae_last_error().decode()}")

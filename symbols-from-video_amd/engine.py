@@ -256,6 +256,8 @@ class Engine:
         self.main_first = os.environ.get("RBVAE_MAIN_FIRST", "1") == "1"
         self._ks_force = int(os.environ.get("RBVAE_WG_KS", "0"))
         self._ks_small = int(os.environ.get("RBVAE_WG_KS_SMALL", "3"))
+        self._wg_nt4 = os.environ.get("RBVAE_WG_NT4", "0") == "1"
+        self._wg_nt4_slab = int(os.environ.get("RBVAE_WG_NT4_SLAB", "8"))     # cap on a weight's f32 slabs, M floats
         self._ks_narrow = int(os.environ.get("RBVAE_WG_KS_NARROW", "0"))
         self.book_with_dec = os.environ.get("RBVAE_BOOK_WITH_DEC", "1") == "1"
         self.wfc_side = os.environ.get("RBVAE_WFC_SIDE", "1") == "1"
@@ -562,14 +564,15 @@ class Engine:
 
     def _wgrad(self, Dy, In, idx, P, Co, Ci, ldy, ldi, taps, out, dims, strides, tag=None):
         """wgrad GEMM into K-slice slabs; their fixed-order reduction into the torch layout is a job."""
-        blocks = -(-Co // 128) * -(-Ci // (128 if Ci > 64 else 64)) * taps
+        nt4 = self._wg_nt4 and self.dt == BF16 and Ci % 256 == 0        # 128 x 256 tiles (wgrad_gemm.hip)
+        blocks = -(-Co // 128) * -(-Ci // (256 if nt4 else 128 if Ci > 64 else 64)) * taps
         # K-slices: one round of workgroups on the 256 CUs, each with >= 256 pixels, and at most ~16 MB of f32
         # slabs to reduce afterwards
         # (self._wg_cus: the CUs this launch can count on -- beside the LSTM backward kernels, which hold one CU per
         # sequence and whose registers leave no room for a second workgroup there, a 252-workgroup grid ran in two
         # rounds: 31 -> 43 us)
         ks = max(1, min(self._wg_cus // max(blocks, 1), P // 256 if P >= 256 else 1,
-                        max(1, (4 << 20) // (Co * taps * Ci))))
+                        max(1, ((self._wg_nt4_slab if nt4 else 4) << 20) // (Co * taps * Ci))))
         if self._ks_force and blocks >= 8:
             ks = self._ks_force                 # RBVAE_WG_KS: experiment switch (K-slices of the multi-tile weight gradients)
         if self._ks_small and blocks >= 8 and P <= 4096:
@@ -579,7 +582,7 @@ class Engine:
             ks = min(ks, self._ks_small)
         if self._ks_narrow and blocks < 8:
             ks = min(ks, self._ks_narrow)       # RBVAE_WG_KS_NARROW: the 64-column weight gradients (first conv, last deconv)
-        ks = max(ks, -(-P // 4096))            # the kernel keeps a K-slice's gather indices in LDS (<= 4096)
+        ks = max(ks, -(-P // (2048 if nt4 else 4096)))   # the kernel keeps a K-slice's gather indices in LDS
         slabs = self._buf(("slabs", tag), ks * Co * taps * Ci)
         L.call("rbvae_wgrad_gemm", self.dt, Dy, In, slabs, idx, self.zero, P, In.numel() // ldi, Co, Ci, ldy, ldi, taps, ks)
         if (taps > 1 and taps <= 16 and tuple(dims) == (Co, Ci, taps) and tuple(strides) == (taps * Ci, 1, Ci)

@@ -8,6 +8,6 @@ base=$(basename $src .hip)
 for spec in "$@"; do
   name=${spec%%:*}; flags=${spec#*:}
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -Wno-unused-function $flags -c $P/csrc/$src -o /tmp/${base}_$name.o
-  ls $P/build/*.o | grep -v "/$base.o" | xargs /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $P/librbvae_hip_$name.so /tmp/${base}_$name.o
+  ls $P/build/*.o | grep -v "\.dbg\.o$" | grep -v "/dbg.o$" | grep -v "/$base.o" | xargs /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $P/librbvae_hip_$name.so /tmp/${base}_$name.o
   echo built $P/librbvae_hip_$name.so
 done

@@ -44,5 +44,7 @@ def run(N, ih, oh, C=256, ks=7):
     print(f"   K loop per step: median {np.median(dur[:, 2]) / steps:.3f} us;  workgroup start median {np.median(rel[:, 0]):.1f} max {rel[:, 0].max():.1f} us; last end {rel[:, 5].max():.1f} us")
 
 
-run(256, 16, 8)          # conv2 / deconv1 weight gradient: P = 16384
-run(256, 8, 4)           # conv3 / deconv0: P = 4096
+ks_big = int(sys.argv[1]) if len(sys.argv) > 1 else 7
+ks_small = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+run(256, 16, 8, ks=ks_big)          # conv2 / deconv1 weight gradient: P = 16384
+run(256, 8, 4, ks=ks_small)         # conv3 / deconv0: P = 4096
