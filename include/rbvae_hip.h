@@ -329,6 +329,20 @@ int rbvae_lstm_bwd_bin(const float* wblk, const float* acts, const float* cs, co
                        const float* z, const float* g_hs, float tau, const float* tau_dev, float kl_weight, float kl_p, float kl_eps,
                        int kl_clamp, float* dG, float* dx, void* cast_out, int cast_dtype, int cast_ld, float* dx_colsum,
                        int S, int T, int L, int layers, void* stream);
+/* Both stacks' BPTT as ONE wavefront launch (autograd of percep_RBVAE_model.py:155-163 as run by
+ * percep_RBVAE_train.py:552): rbvae_lstm_bwd_ex(decoder stack) -> rbvae_binarize_kl_bwd -> rbvae_lstm_bwd_ex(encoder
+ * stack), T + 2*layers - 1 dependent steps instead of 2 * (T + layers - 1).  The decoder stack's input gradient (the
+ * gradient of the codes) never leaves the chip; dz (may be NULL) receives a copy, gz_extra (may be NULL) is a second
+ * gradient of the codes added to it before the binarise backward.  Everything else as in rbvae_lstm_bwd_ex /
+ * rbvae_lstm_bwd_bin.  rbvae_lstm_pair_bwd_ok tells whether the shape is covered (L <= 32,
+ * 2 * layers * roundup64(4L) <= 1024, saved gates of both stacks within 64 KB of LDS). */
+int rbvae_lstm_pair_bwd_ok(int T, int L, int layers);
+int rbvae_lstm_pair_bwd(const float* wblk_enc, const float* wblk_dec, const float* acts_enc, const float* cs_enc,
+                        const float* acts_dec, const float* cs_dec, const float* g_top_parts, int nparts, long part_stride,
+                        const float* gz_extra, const float* y_soft, const float* z, const float* g_hs, float tau,
+                        const float* tau_dev, float kl_weight, float kl_p, float kl_eps, int kl_clamp, float* dG_enc,
+                        float* dG_dec, float* dx, float* dz, void* cast_out, int cast_dtype, int cast_ld, float* dx_colsum,
+                        int S, int T, int L, int layers, void* stream);
 int rbvae_lstm_wgrad(const float* dG, const float* hs_all, const float* hprev, float* gblk, int S, int T, int L,
                      int layers, int accumulate, void* stream);
 /* the same for two stacks of equal shape (the encoder and decoder LSTMs) in one launch */

@@ -953,6 +953,212 @@ __global__ __launch_bounds__(1024) void lstm_bwd_wave_k(const float* __restrict_
     }
 }
 
+// Both stacks' BPTT as ONE launch: decoder stack -> binarise backward (+ fused KL) -> encoder stack, the 2 * layers
+// layers along one anti-diagonal wavefront (T + 2*layers - 1 dependent steps instead of 2 * (T + layers - 1), one launch
+// and one staging prologue fewer).  Virtual layer vl: 0 .. layers-1 = encoder, layers .. 2*layers-1 = decoder.  The seam
+// is the encoder's top layer: its dh is the decoder's input gradient (the partial sums of decoder layer 0, summed in
+// the order lstm_bwd_wave_k writes dx) through the binarise backward of struct BinBwd -- same expressions, same order.
+struct PairBwdArgs {
+    const float *wblk_e, *wblk_d, *acts_e, *cs_e, *acts_d, *cs_d;
+    const float* g_top; int nparts; long part_stride;       // decoder top: gradient of its output (K-split slabs summed in order)
+    float *dG_e, *dG_d, *dx, *dz;                           // dz: the decoder stack's input gradient (optional copy)
+    const float* gz_extra;                                  // optional second gradient of the codes
+    void* cast_out; int cast_bf16, cast_ld;
+    float* dx_colsum;
+    BinBwd bb;                                              // gz unused (it never leaves the chip)
+    int S, T, L, layers, G;
+};
+
+template <int LMAX, bool EXACT>
+__global__ __launch_bounds__(1024) void lstm_pair_bwd_k(const PairBwdArgs p) {
+    RBVAE_RAISE_PRIO();
+    const int L = EXACT ? LMAX : p.L;
+    const int T = p.T, S = p.S, layers = p.layers, G = p.G, VL = 2 * layers;
+    const BinBwd& bb = p.bb;
+    const float bin_tau = bb.tau_dev ? bb.tau_dev[0] : bb.tau;
+    extern __shared__ float sm[];
+    float* gtop = sm;                              // [T][L]            decoder top
+    float* sy = gtop + T * L;                      // [T][L]            seam: y, dKL/dz, g_hs, extra code gradient
+    float* sk = sy + T * L;
+    float* sh = sk + T * L;
+    float* sx = sh + T * L;
+    float* sacts = sx + T * L;                     // [VL][T][4L]
+    float* scs = sacts + VL * T * 4 * L;           // [VL][T][L]
+    float* dg = scs + VL * T * L;                  // [VL][4L]
+    float* part = dg + VL * 4 * L;                 // [VL][4][2][L]
+    const int vl = threadIdx.x / G, j = threadIdx.x - vl * G;
+    const bool dec = vl >= layers;
+    const int l = dec ? vl - layers : vl;
+    const int s = blockIdx.x;
+    const bool row = j < 4 * L;
+    const int kcol = j % L, prt = j / L;
+    {
+        // every global load of the prologue in flight before the first use (see lstm_bwd_wave_k)
+        constexpr int U = 12;
+        const int n0 = T * L, na = T * 4 * L, n1 = VL * na, ntot = n1 + VL * n0;
+        const int nth = blockDim.x;
+        float v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            int i = (int)threadIdx.x + u * nth;
+            i = i < ntot ? i : ntot - 1;
+            const bool in_acts = i < n1;
+            const int rel = in_acts ? i : i - n1;
+            const int per = in_acts ? na : n0;
+            const int vll = rel / per, r = rel - vll * per;
+            const bool d = vll >= layers;
+            const int ll = d ? vll - layers : vll;
+            const float* base = in_acts ? (d ? p.acts_d : p.acts_e) : (d ? p.cs_d : p.cs_e);
+            v[u] = base[(((long)ll * S + s) * T) * (in_acts ? 4 * L : L) + r];
+        }
+        for (int i0 = 0; i0 < n0; i0 += nth) {
+            const int i = i0 + (int)threadIdx.x;
+            const long e = ((long)s * T) * L + (i < n0 ? i : n0 - 1);
+            const float* gp = p.g_top + e;
+            float gt = gp[0];
+            int q = 1;
+            for (; q + 3 <= p.nparts; q += 3) {
+                const float a = gp[q * p.part_stride], b = gp[(q + 1) * p.part_stride], c = gp[(q + 2) * p.part_stride];
+                gt = ((gt + a) + b) + c;
+            }
+            for (; q < p.nparts; ++q) gt += gp[q * p.part_stride];
+            const float yv = bb.y[e], zv = bb.z[e];
+            const float hsv = bb.g_hs ? bb.g_hs[e] : 0.f;
+            const float xv = p.gz_extra ? p.gz_extra[e] : 0.f;
+            if (i < n0) {
+                gtop[i] = gt;
+                sy[i] = yv;
+                sk[i] = bb.klw != 0.f ? kl_elem_grad(zv, bb.lp, bb.l1p, bb.keps, bb.clamp) : 0.f;
+                sh[i] = hsv;
+                sx[i] = xv;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int i = (int)threadIdx.x + u * nth;
+            if (i < ntot) sacts[i] = v[u];
+        }
+        for (int i = (int)threadIdx.x + U * nth; i < ntot; i += nth) {
+            const bool in_acts = i < n1;
+            const int rel = in_acts ? i : i - n1;
+            const int per = in_acts ? na : n0;
+            const int vll = rel / per, r = rel - vll * per;
+            const bool d = vll >= layers;
+            const int ll = d ? vll - layers : vll;
+            const float* base = in_acts ? (d ? p.acts_d : p.acts_e) : (d ? p.cs_d : p.cs_e);
+            sacts[i] = base[(((long)ll * S + s) * T) * (in_acts ? 4 * L : L) + r];
+        }
+    }
+    if (p.cast_out) {
+        const int pw = p.cast_ld - L;
+        for (int i = threadIdx.x; i < T * pw; i += blockDim.x) {
+            const long o = ((long)s * T + i / pw) * p.cast_ld + L + i % pw;
+            if (p.cast_bf16) ((bf16_t*)p.cast_out)[o] = 0; else ((float*)p.cast_out)[o] = 0.f;
+        }
+    }
+    const float* wl = (dec ? p.wblk_d : p.wblk_e) + l * lstm_layer_floats(L);
+    float wic[LMAX], whc[LMAX];
+    if (row) {
+        const float* pi = wl + prt * L * L + kcol;
+        const float* ph = pi + 4 * L * L;
+#pragma unroll
+        for (int jj = 0; jj < LMAX; ++jj) {
+            const int o = (jj < L ? jj : L - 1) * L;
+            const float a = pi[o], b = ph[o];
+            wic[jj] = jj < L ? a : 0.f;
+            whc[jj] = jj < L ? b : 0.f;
+        }
+    }
+    float dc_next = 0.f;
+    float dx_sum = 0.f;
+    float* dG = dec ? p.dG_d : p.dG_e;
+    __syncthreads();
+    const int top = VL - 1;
+    const int ndiag = T + VL - 1;
+    for (int e = 0; e < ndiag; ++e) {
+        const int q = e - (top - vl);
+        const int t = T - 1 - q;
+        const bool active = q >= 0 && q < T;
+        if (j < L) {
+            // encoder layer 0: the input gradient of the step finished at the previous diagonal (time t+1)
+            if (vl == 0 && q >= 1 && q <= T) {
+                const float* p0 = part;
+                const float dv = p0[0 * L + j] + p0[2 * L + j] + p0[4 * L + j] + p0[6 * L + j];
+                p.dx[((long)s * T + t + 1) * L + j] = dv;
+                dx_sum += dv;
+                if (p.cast_out) {
+                    const long o = ((long)s * T + t + 1) * p.cast_ld + j;
+                    if (p.cast_bf16) ((bf16_t*)p.cast_out)[o] = f32_to_bf16(dv); else ((float*)p.cast_out)[o] = dv;
+                }
+            }
+            if (active) {
+                float dh;
+                if (vl == top) dh = gtop[t * L + j];
+                else {
+                    const float* pu = part + (vl + 1) * 8 * L;
+                    dh = pu[0 * L + j] + pu[2 * L + j] + pu[4 * L + j] + pu[6 * L + j];
+                    if (vl == layers - 1) {
+                        // the seam: dh so far is the decoder stack's input gradient = the gradient of the codes
+                        if (p.dz) p.dz[((long)s * T + t) * L + j] = dh;
+                        float gg = p.gz_extra ? dh + sx[t * L + j] : dh;
+                        if (bb.klw != 0.f) gg += bb.klw * sk[t * L + j];
+                        const float yv = sy[t * L + j];
+                        dh = sh[t * L + j] + gg * yv * (1.0f - yv) / bin_tau;
+                    }
+                }
+                if (q > 0) {
+                    const float* pm = part + vl * 8 * L;
+                    dh += pm[1 * L + j] + pm[3 * L + j] + pm[5 * L + j] + pm[7 * L + j];
+                }
+                const float* ap = sacts + (vl * T + t) * 4 * L;
+                const float ig = ap[j], fg = ap[L + j], gg = ap[2 * L + j], og = ap[3 * L + j];
+                const float c = scs[(vl * T + t) * L + j];
+                const float cprev = t > 0 ? scs[(vl * T + t - 1) * L + j] : 0.f;
+                const float tc = fast_tanh(c);
+                const float dc = dc_next + dh * og * (1.f - tc * tc);
+                const float d_o = dh * tc * og * (1.f - og);
+                const float d_i = dc * gg * ig * (1.f - ig);
+                const float d_f = dc * cprev * fg * (1.f - fg);
+                const float d_g = dc * ig * (1.f - gg * gg);
+                dc_next = dc * fg;
+                float* dl = dg + vl * 4 * L;
+                dl[j] = d_i; dl[L + j] = d_f; dl[2 * L + j] = d_g; dl[3 * L + j] = d_o;
+                float* gp = dG + (((long)l * S + s) * T + t) * 4 * L;
+                gp[j] = d_i; gp[L + j] = d_f; gp[2 * L + j] = d_g; gp[3 * L + j] = d_o;
+            }
+        }
+        lds_barrier();
+        if (active && row) {
+            float ax0 = 0.f, ax1 = 0.f, ah0 = 0.f, ah1 = 0.f;
+            const float* dgp = dg + vl * 4 * L + prt * L;
+#pragma unroll
+            for (int jj = 0; jj < LMAX; jj += 2) {
+                if (jj + 1 < L) {
+                    const float d0 = dgp[jj], d1 = dgp[jj + 1];
+                    ax0 = fmaf(wic[jj], d0, ax0); ax1 = fmaf(wic[jj + 1], d1, ax1);
+                    ah0 = fmaf(whc[jj], d0, ah0); ah1 = fmaf(whc[jj + 1], d1, ah1);
+                } else if (jj < L) {
+                    const float d0 = dgp[jj];
+                    ax0 = fmaf(wic[jj], d0, ax0); ah0 = fmaf(whc[jj], d0, ah0);
+                }
+            }
+            part[vl * 8 * L + (prt * 2 + 0) * L + kcol] = ax0 + ax1;
+            part[vl * 8 * L + (prt * 2 + 1) * L + kcol] = ah0 + ah1;
+        }
+        lds_barrier();
+    }
+    if (vl == 0 && j < L) {
+        const float dv = part[0 * L + j] + part[2 * L + j] + part[4 * L + j] + part[6 * L + j];
+        p.dx[((long)s * T) * L + j] = dv;
+        dx_sum += dv;
+        if (p.cast_out) {
+            const long o = ((long)s * T) * p.cast_ld + j;
+            if (p.cast_bf16) ((bf16_t*)p.cast_out)[o] = f32_to_bf16(dv); else ((float*)p.cast_out)[o] = dv;
+        }
+        if (p.dx_colsum) p.dx_colsum[(long)s * L + j] = dx_sum;
+    }
+}
+
 // Weight gradients, LDS-tiled: block = (8 gate rows, ih|hh, layer); thread (jj, kq) owns gate row jj and
 // the columns kq, kq+32, ... (column L = the bias).  Rows of dG / X stream through LDS 128 at a time.
 constexpr int LW_ROWS = 128;
@@ -1294,6 +1500,50 @@ int rbvae_lstm_bwd_bin(const float* wblk, const float* acts, const float* cs, co
     bb.keps = kl_eps; bb.clamp = kl_clamp; bb.on = 1;
     return lstm_bwd_impl(wblk, nullptr, acts, cs, g_z, dG, dx, S, T, L, layers, 1, 0, cast_out, cast_dtype, cast_ld, dx_colsum, bb,
                          stream);
+}
+
+static size_t pair_bwd_lds(int T, int L, int layers) {
+    return (size_t)(5 * T * L + 2 * layers * (T * 5 * L + 12 * L)) * sizeof(float);
+}
+
+int rbvae_lstm_pair_bwd_ok(int T, int L, int layers) {
+    const int threads = ((4 * L + 63) / 64) * 64;
+    return L <= 32 && 2 * layers * threads <= 1024 && pair_bwd_lds(T, L, layers) <= 64 * 1024;
+}
+
+int rbvae_lstm_pair_bwd(const float* wblk_enc, const float* wblk_dec, const float* acts_enc, const float* cs_enc,
+                        const float* acts_dec, const float* cs_dec, const float* g_top_parts, int nparts, long part_stride,
+                        const float* gz_extra, const float* y_soft, const float* z, const float* g_hs, float tau,
+                        const float* tau_dev, float kl_weight, float kl_p, float kl_eps, int kl_clamp, float* dG_enc,
+                        float* dG_dec, float* dx, float* dz, void* cast_out, int cast_dtype, int cast_ld, float* dx_colsum,
+                        int S, int T, int L, int layers, void* stream) {
+    RBVAE_CHECK_ARG(wblk_enc && wblk_dec && acts_enc && cs_enc && acts_dec && cs_dec && g_top_parts && y_soft && z &&
+                    dG_enc && dG_dec && dx && S > 0 && T > 0 && L > 0 && layers > 0, "lstm_pair_bwd: bad arguments");
+    RBVAE_CHECK_ARG(rbvae_lstm_pair_bwd_ok(T, L, layers), "lstm_pair_bwd: T=%d L=%d layers=%d outside the fused kernel's "
+                    "range (rbvae_lstm_pair_bwd_ok)", T, L, layers);
+    RBVAE_CHECK_ARG(nparts >= 1 && (nparts == 1 || part_stride >= (long)S * T * L), "lstm_pair_bwd: bad slabs");
+    RBVAE_CHECK_ARG(tau_dev || tau > 0.f, "lstm_pair_bwd: tau=%g", tau);
+    RBVAE_CHECK_ARG(kl_weight == 0.f || (kl_p > 0.f && kl_p < 1.f), "lstm_pair_bwd: kl_p=%g outside (0,1)", kl_p);
+    RBVAE_CHECK_ARG(!cast_out || ((cast_dtype == RBVAE_F32 || cast_dtype == RBVAE_BF16) && cast_ld >= L),
+                    "lstm_pair_bwd: cast output dtype %d ld %d", cast_dtype, cast_ld);
+    PairBwdArgs a;
+    a.wblk_e = wblk_enc; a.wblk_d = wblk_dec; a.acts_e = acts_enc; a.cs_e = cs_enc; a.acts_d = acts_dec; a.cs_d = cs_dec;
+    a.g_top = g_top_parts; a.nparts = nparts; a.part_stride = part_stride;
+    a.dG_e = dG_enc; a.dG_d = dG_dec; a.dx = dx; a.dz = dz; a.gz_extra = gz_extra;
+    a.cast_out = cast_out; a.cast_bf16 = cast_dtype == RBVAE_BF16; a.cast_ld = cast_ld; a.dx_colsum = dx_colsum;
+    a.bb.gz = nullptr; a.bb.y = y_soft; a.bb.z = z; a.bb.g_hs = g_hs; a.bb.tau = tau; a.bb.tau_dev = tau_dev;
+    a.bb.klw = kl_weight / (float)((long)S * T);
+    a.bb.lp = kl_weight != 0.f ? logf(kl_p) : 0.f; a.bb.l1p = kl_weight != 0.f ? logf(1.0f - kl_p) : 0.f;
+    a.bb.keps = kl_eps; a.bb.clamp = kl_clamp; a.bb.on = 1;
+    const int threads = ((4 * L + 63) / 64) * 64;
+    a.S = S; a.T = T; a.L = L; a.layers = layers; a.G = threads;
+    const size_t lds = pair_bwd_lds(T, L, layers);
+    if (L == 32)
+        hipLaunchKernelGGL((lstm_pair_bwd_k<32, true>), dim3(S), dim3(2 * layers * threads), lds, (hipStream_t)stream, a);
+    else
+        hipLaunchKernelGGL((lstm_pair_bwd_k<32, false>), dim3(S), dim3(2 * layers * threads), lds, (hipStream_t)stream, a);
+    RBVAE_CHECK_LAUNCH("lstm_pair_bwd");
+    return RBVAE_OK;
 }
 
 static int launch_lstm_wgrad(const float* dG, const float* hs_all, const float* hprev, float* gblk, const float* dG2,

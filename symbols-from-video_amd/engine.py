@@ -257,6 +257,8 @@ class Engine:
         self._ks_force = int(os.environ.get("RBVAE_WG_KS", "0"))
         self._ks_small = int(os.environ.get("RBVAE_WG_KS_SMALL", "3"))
         self._wg_nt4 = os.environ.get("RBVAE_WG_NT4", "0") == "1"
+        self.lstm_pair_bwd = os.environ.get("RBVAE_LSTM_PAIR_BWD", "1") == "1"   # both stacks' BPTT in one launch
+        self.keep_dz = os.environ.get("RBVAE_KEEP_DZ", "0") == "1"                # also store the codes' gradient
         self._wg_nt4_slab = int(os.environ.get("RBVAE_WG_NT4_SLAB", "8"))     # cap on a weight's f32 slabs, M floats
         self._ks_narrow = int(os.environ.get("RBVAE_WG_KS_NARROW", "0"))
         self.book_with_dec = os.environ.get("RBVAE_BOOK_WITH_DEC", "1") == "1"
@@ -1056,13 +1058,27 @@ class Engine:
         dG = tmp("dG_dec", nl, S, T, 4 * Ld, dtype=f32)
         dGe = tmp("dG_enc", nl, S, T, 4 * Ld, dtype=f32)
         d_in_dec = tmp("d_in_dec", N, Ld, dtype=f32)
-        if self.fc_split > 1:
+        de = tmp("de", N, Ld, dtype=f32)
+        pair_bwd = (self.lstm_pair_bwd and not v.simple_order and self.lstm_cast and self.bin_bwd_fused
+                    and L.query("rbvae_lstm_pair_bwd_ok", T, Ld, nl))
+        if pair_bwd:
+            # decoder stack -> binarise backward (+ fused KL) -> encoder stack: one wavefront launch
+            de_pad = tmp("de_pad", N, self.Lp)
+            de_sums = self._buf((N, "de_sums"), S * Ld)
+            nparts = self.fc_split if self.fc_split > 1 else 1
+            L.call("rbvae_lstm_pair_bwd", wenc, wdec, sv.acts_enc, sv.cs_enc, sv.acts_dec, sv.cs_dec, dds, nparts, N * Ld,
+                   None if g_z is None else g_z.reshape(N, Ld).contiguous(), sv.y, sv.z,
+                   None if g_hs is None else g_hs.reshape(N, Ld).contiguous(), float(sv.tau), sv.tau_dev, float(kl_weight),
+                   float(kl_p), 1e-8, 1, dGe, dG, de, d_in_dec if self.keep_dz else None, de_pad, self.dt, self.Lp, de_sums,
+                   S, T, Ld, nl)
+        elif self.fc_split > 1:
             L.call("rbvae_lstm_bwd_ex", wdec, sv.acts_dec, sv.cs_dec, dds, self.fc_split, N * Ld, dG, d_in_dec, None, 0, 0,
                    None, S, T, Ld, nl)
         else:
             L.call("rbvae_lstm_bwd", wdec, self.wT_dec, sv.acts_dec, sv.cs_dec, dds, dG, d_in_dec, S, T, Ld, nl)
-        de = tmp("de", N, Ld, dtype=f32)
-        if not v.simple_order:
+        if pair_bwd:
+            pass
+        elif not v.simple_order:
             # z -> binarise backward (+ fused KL) -> gradient of h_seq
             gz = d_in_dec
             if g_z is not None:

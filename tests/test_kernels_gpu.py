@@ -519,6 +519,58 @@ def test_lstm_pair_forward_equals_three_launches(sfv, L, layers, S, T, hard):
     assert not sfv._lib.query("rbvae_lstm_pair_fwd_ok", 8, 64, 2)
 
 
+@pytest.mark.parametrize("L,layers,S,T,nparts,klw,ghs,extra", [(32, 4, 5, 8, 4, 1.0, True, False), (32, 2, 3, 5, 1, 0.0, False, True),
+                                                              (25, 4, 3, 8, 3, 0.5, True, True), (7, 2, 2, 3, 1, 1.0, False, False),
+                                                              (30, 3, 2, 9, 2, 0.0, True, False)])
+def test_lstm_pair_backward_equals_two_launches(sfv, L, layers, S, T, nparts, klw, ghs, extra):
+    """rbvae_lstm_pair_bwd (decoder stack -> binarise backward -> encoder stack, one wavefront) against
+    rbvae_lstm_bwd_ex(decoder) + rbvae_lstm_bwd_bin(encoder): gate gradients of both stacks, the input gradient, its cast
+    copy and per-sequence sums, and the codes' gradient -- the same expressions in the same order, so bit for bit."""
+    lib = sfv._lib
+    assert lib.query("rbvae_lstm_pair_bwd_ok", T, L, layers)
+    g = torch.Generator().manual_seed(70 + L + layers)
+    N = S * T
+    per = layers * (8 * L * L + 8 * L)
+    we, wd = (torch.randn(per, generator=g) * 0.3).cuda(), (torch.randn(per, generator=g) * 0.3).cuda()
+
+    def saved():        # gates in (0, 1) / (-1, 1) like a forward pass leaves them, cell states of moderate size
+        a = torch.rand(layers, S, T, 4 * L, generator=g)
+        a[..., 2 * L:3 * L] = a[..., 2 * L:3 * L] * 2 - 1
+        return a.cuda(), torch.randn(layers, S, T, L, generator=g).cuda()
+    ae, ce = saved(); ad, cd = saved()
+    gparts = torch.randn(nparts, N, L, generator=g).cuda()
+    y = torch.rand(N, L, generator=g).clamp(1e-3, 1 - 1e-3).cuda()
+    z = torch.rand(N, L, generator=g).clamp(1e-3, 1 - 1e-3).cuda()
+    g_hs = torch.randn(N, L, generator=g).cuda() if ghs else None
+    gzx = torch.randn(N, L, generator=g).cuda() if extra else None
+    tau = torch.tensor([0.7], device="cuda")
+    Lp = 64
+    # two launches
+    dGd0, dz0 = torch.empty(layers, S, T, 4 * L, device="cuda"), torch.empty(N, L, device="cuda")
+    lib.call("rbvae_lstm_bwd_ex", wd, ad, cd, gparts, nparts, N * L, dGd0, dz0, None, 0, 0, None, S, T, L, layers)
+    gz = dz0 if gzx is None else dz0 + gzx
+    dGe0, dx0 = torch.empty(layers, S, T, 4 * L, device="cuda"), torch.empty(N, L, device="cuda")
+    pad0, sums0 = torch.full((N, Lp), 3.0, dtype=torch.bfloat16, device="cuda"), torch.empty(S, L, device="cuda")
+    lib.call("rbvae_lstm_bwd_bin", we, ae, ce, gz, y, z, g_hs, 9.0, tau, klw, 0.1, 1e-8, 1, dGe0, dx0, pad0, 1, Lp, sums0,
+             S, T, L, layers)
+    # one launch
+    dGd1, dz1 = torch.empty_like(dGd0), torch.empty_like(dz0)
+    dGe1, dx1 = torch.empty_like(dGe0), torch.empty_like(dx0)
+    pad1, sums1 = torch.full((N, Lp), 5.0, dtype=torch.bfloat16, device="cuda"), torch.empty(S, L, device="cuda")
+    lib.call("rbvae_lstm_pair_bwd", we, wd, ae, ce, ad, cd, gparts, nparts, N * L, gzx, y, z, g_hs, 9.0, tau, klw, 0.1, 1e-8, 1,
+             dGe1, dGd1, dx1, dz1, pad1, 1, Lp, sums1, S, T, L, layers)
+    torch.cuda.synchronize()
+    for nm, a, b in (("dG_dec", dGd0, dGd1), ("dz", dz0, dz1), ("dG_enc", dGe0, dGe1), ("dx", dx0, dx1), ("cast", pad0, pad1),
+                     ("sums", sums0, sums1)):
+        assert torch.equal(a, b), (nm, (a.float() - b.float()).abs().max().item())
+    # dz is optional
+    dx2 = torch.empty_like(dx0)
+    lib.call("rbvae_lstm_pair_bwd", we, wd, ae, ce, ad, cd, gparts, nparts, N * L, gzx, y, z, g_hs, 9.0, tau, klw, 0.1, 1e-8, 1,
+             torch.empty_like(dGe0), torch.empty_like(dGd0), dx2, None, None, 0, 0, None, S, T, L, layers)
+    assert torch.equal(dx2, dx0)
+    assert not lib.query("rbvae_lstm_pair_bwd_ok", 8, 64, 2) and not lib.query("rbvae_lstm_pair_bwd_ok", 64, 32, 4)
+
+
 @pytest.mark.parametrize("N,IH,IW,C1,Cout", [(3, 16, 16, 256, 4), (2, 11, 20, 256, 4), (2, 8, 8, 64, 3), (1, 5, 37, 128, 4)])
 def test_deconv_last_fused(sfv, N, IH, IW, C1, Cout):
     """rbvae_deconv_last_fused (per-tap products on the MFMA from an LDS-resident pixel block + gather + sigmoid +
