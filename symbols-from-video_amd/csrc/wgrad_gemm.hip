@@ -93,10 +93,9 @@ template <int N> __device__ __forceinline__ void wg_wait_barrier() {
 // WG_NS = LDS ring depth.  3: two K steps in flight behind the one being multiplied, one workgroup per CU;
 // 2: double buffer, two workgroups per CU (grids of more than 256 workgroups).
 //
-// Workgroup order: the grid is one-dimensional and the K-slice index is the fastest digit of the workgroup
-// id.  Workgroups are dealt to the 8 XCDs round-robin by id, so with ksplit a multiple of 8 every workgroup
-// of one XCD works on the same pixel slices: all taps and channel tiles of a slice re-read its Dy / In rows
-// from that XCD's own L2 instead of from the Infinity Cache.
+// Workgroup order: the grid is one-dimensional; with xcd_order (the default when ksplit > 1) every XCD's workgroups
+// work on one or two pixel slices, so all taps and channel tiles of a slice re-read its Dy / In rows from that XCD's
+// own L2 instead of from the Infinity Cache; otherwise the K-slice index is the fastest digit of the workgroup id.
 template <typename T, int NT, int WG_NS>
 __global__ __launch_bounds__(512, WG_NS == 2 ? 2 : 1) void wgrad_gemm_k(const WgArgs p) {
     constexpr int ES = sizeof(T);
@@ -125,10 +124,10 @@ __global__ __launch_bounds__(512, WG_NS == 2 ? 2 : 1) void wgrad_gemm_k(const Wg
     const int gx = (p.Co + BM - 1) / BM, gy = (p.Ci + BN - 1) / BN;
     int ks, wg;
     if (p.xcd_order) {
-        // Experiment (RBVAE_WG_XCD=1): workgroups are dealt to the 8 XCDs round-robin by id; XCD x takes the x-th
-        // eighth of the (K-slice, tile) items in slice-major order, so its workgroups share one or two pixel slices
-        // of Dy / In (with the K-slice as the fastest digit every XCD walks every slice).  It did not pay: see the
-        // launch code.
+        // Workgroups are dealt to the 8 XCDs round-robin by id; XCD x takes the x-th eighth of the (K-slice, tile)
+        // items in slice-major order, so its workgroups share one or two pixel slices of Dy / In and re-read them from
+        // that XCD's L2 (with the K-slice as the fastest digit every XCD walks every slice).  Placement is a speed
+        // matter only: every item is computed whichever XCD takes it.
         const int ntiles = gx * gy * p.taps, total = ntiles * p.ksplit, per = (total + 7) >> 3;
         const int x = blockIdx.x & 7, q = blockIdx.x >> 3;
         const int item = x * per + q;
@@ -623,8 +622,10 @@ int rbvae_wgrad_gemm(int dtype, const void* Dy, const void* In, float* dW_slabs,
     a.P = P; a.Co = Co; a.Ci = Ci; a.ldy = ldy; a.ldi = ldi; a.taps = taps; a.ksplit = ksplit;
     a.Pper = ((cdiv(P, ksplit) + 63) / 64) * 64;
     a.stamps = g_wg_stamps;
-    // measured on the bench step, same GPU, 3 runs each: 0.529 ms (off) vs 0.540 ms (on): off
-    static const int xcd = getenv("RBVAE_WG_XCD") ? atoi(getenv("RBVAE_WG_XCD")) : 0;
+    // XCD-ordered workgroups: the same step time (0.4454 on vs 0.4456 ms off, same GPU, 4 runs each -- the K step is bound
+    // by the CU's intake, not by where the rows come from) but a third less traffic behind the L2s: 66.9 vs 103.1 MB
+    // fetched by the 252-workgroup launch, 68.4 vs 86.3 (216), 21.1 vs 25.9 (108) (FETCH_SIZE, tools/pmc_traffic_env.sh)
+    static const int xcd = getenv("RBVAE_WG_XCD") ? atoi(getenv("RBVAE_WG_XCD")) : 1;
     a.xcd_order = xcd && ksplit > 1;
     RBVAE_CHECK_ARG(a.Pper <= WG_MAXP, "wgrad_gemm: %d pixels per K-slice exceed %d: raise ksplit (>= %d)", a.Pper,
                     WG_MAXP, cdiv(P, WG_MAXP));
