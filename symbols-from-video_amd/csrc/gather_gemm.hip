@@ -60,6 +60,7 @@ struct GgArgs {
     float* colsum_ws;          // optional [nclass * m-tiles][Nout]: per-tile column sums of the stored values
     int nclass;
     int dephase;               // 8-wave kernels: the two waves of a SIMD stage at different points of the step
+    int xcd_order;             // 1: the N tiles and tap classes of one M tile run back to back on ONE XCD (see the kernel)
     int sh_thw, sh_tw;         // log2(TH*TW), log2(TW) when those are powers of two, else -1 (row index -> (n, a, b) by shifts)
     unsigned long long* stamps; // debug (rbvae_dbg_gg_stamps): [workgroup][8] phase time stamps (100 MHz), or null
     TapClass cls[4];
@@ -182,9 +183,23 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void gather_gemm_k(const GgArgs p)
     if (gridDim.x * gridDim.y * gridDim.z <= 64) __builtin_amdgcn_s_setprio(2);
 #endif
     GG_STAMP(0);
-    const TapClass& tc = p.cls[blockIdx.z];
+    // Tile of this workgroup.  xcd_order (RBVAE_GG_XCD=1, off): the gridDim.y * gridDim.z workgroups that read the SAME
+    // gathered rows (the N tiles and tap classes of one M tile) take consecutive ids of one XCD.  Measured on the bench
+    // step, same GPU, 4 runs each: 0.452 ms (off) vs 0.462 ms (on), and FETCH_SIZE of the parity-class launches
+    // unchanged (40.5 vs 39.8 MB: their reads are the input once per launch plus the 33.5 MB ReLU gate of the
+    // backward one, not re-fetches) -- the plain order spreads the 1/2/2/4-tap classes over the CUs more evenly.
+    unsigned bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    if (p.xcd_order) {
+        const unsigned lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+        const unsigned nsub = gridDim.y * gridDim.z, r = lin >> 3;
+        const unsigned g = r / nsub, sub = r - g * nsub;
+        bx = g * 8 + (lin & 7);
+        by = sub % gridDim.y;
+        bz = sub / gridDim.y;
+    }
+    const TapClass& tc = p.cls[bz];
     const int Mc = p.Nimg * p.TH * p.TW;
-    const int m0 = blockIdx.x * GG_BM, n0 = blockIdx.y * BN;
+    const int m0 = bx * GG_BM, n0 = by * BN;
     const int ntaps = tc.ntaps;
 
     // output row of every tile row (for the store phase) and the class's tap table
@@ -544,7 +559,7 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void gather_gemm_k(const GgArgs p)
             float t = 0.f;
 #pragma unroll
             for (int k = 0; k < RL; ++k) t += red[k * BN + tid];
-            p.colsum_ws[((size_t)blockIdx.z * gridDim.x + blockIdx.x) * p.Nout + n0 + tid] = t;
+            p.colsum_ws[((size_t)bz * gridDim.x + bx) * p.Nout + n0 + tid] = t;
         }
     }
 #if GG_STAMPS
@@ -651,6 +666,8 @@ extern "C" int rbvae_gather_gemm(int dtype, const void* A, const void* W, void* 
     a.nclass = nclass;
     static const int dephase = getenv("RBVAE_GG_DEPHASE") ? atoi(getenv("RBVAE_GG_DEPHASE")) : 1;
     a.dephase = dephase;
+    static const int xcd = getenv("RBVAE_GG_XCD") ? atoi(getenv("RBVAE_GG_XCD")) : 0;
+    a.xcd_order = xcd && cdiv(Nimg * TH * TW, GG_BM) % 8 == 0 && (nclass > 1 || cdiv(Nout, Nout > 64 ? 128 : 64) > 1);
     a.stamps = g_gg_stamps;
     auto log2_or_neg = [](int v) { int s = 0; while ((1 << s) < v) ++s; return (1 << s) == v ? s : -1; };
     a.sh_thw = log2_or_neg(TH * TW);
