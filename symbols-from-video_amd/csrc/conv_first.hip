@@ -16,7 +16,7 @@
 #include "common.h"
 #include <stdlib.h>
 
-#ifndef CF_DBG      // timing experiments only: 1 no output stores, 2 no col stores, 3 stop after the staging, 4 no patch loads
+#ifndef CF_DBG      // timing experiments only: 1 no output stores, 2 no col stores, 3 stop after the staging, 4 no patch loads, 5 no gate reads
 #define CF_DBG 0
 #endif
 
@@ -241,8 +241,12 @@ template <int CIN, int MODE> __global__ __launch_bounds__(512, 4) void conv_firs
         const size_t orow = (size_t)(n * p.OH + oh) * p.OW + ow;
         u32x4_t g4[2];
         if constexpr (MODE == 1) {
+#if CF_DBG == 5
+            g4[0] = u32x4_t{0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u}; g4[1] = g4[0];   // timing: no gate reads
+#else
             g4[0] = *(const u32x4_t*)(p.gate + (orow * p.ldo + col) * 2);
             g4[1] = second ? *(const u32x4_t*)(p.gate + (orow * p.ldo + col + 8) * 2) : u32x4_t{0u, 0u, 0u, 0u};
+#endif
         }
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
