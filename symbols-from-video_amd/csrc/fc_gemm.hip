@@ -1,0 +1,134 @@
+// The two K = 64 products around the latent bottleneck, bf16 storage:
+//
+//   Out[m][n] = sum_{k < 64} A[m][k] * W[n][k] (+ bias[n]),   M = a few hundred frames, N = thousands of features
+//
+// = the decoder's fc forward (Linear(latent -> C3*h3*w3), percep_RBVAE_model.py:74 on the zero-padded codes) and the
+// input gradient of the encoder's fc (autograd of :61).  They are 0.13 GFLOP and 2.5 MB each -- latency, not work:
+// through the tiled gather GEMM (64 workgroups, index tables, an LDS ring for ONE K step, an LDS round trip for the
+// stores) a launch took 10-11 us on the step's critical chain.  Here a workgroup owns 16 output columns of 256 rows:
+// every operand goes from global memory straight into the MFMA operand layout (a row of A or W is one 128-byte
+// line; lane (i, g) takes bytes 16 g .. 16 g + 15 of row i of each half), 8 MFMAs per wave, and the results leave
+// from the accumulators.  No LDS, no barrier (column sums apart), N/16 workgroups.
+//
+// Arithmetic is that of gather_gemm_k element for element (two 32-deep MFMAs in k order, + bias, round to bf16);
+// the optional column sums of the STORED values (the bias gradient of the layer below the encoder's fc) come out
+// per 128-row tile in gather_gemm_k's layout [tile][N], summed in a different (fixed) order.
+#include "common.h"
+
+namespace rbvae {
+
+typedef __attribute__((ext_vector_type(8))) short bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
+
+struct FcArgs {
+    const unsigned char* A;      // [M][lda] bf16, 64 used columns
+    const unsigned char* W;      // [N][64] bf16
+    unsigned char* Out;          // [M][ldo] bf16
+    const float* bias;           // [N] or null
+    float* colsum_ws;            // [ceil(M/128)][N] or null
+    int M, N, lda, ldo;
+};
+
+template <int CTRL> __device__ __forceinline__ float fc_dpp(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, false));
+}
+// sum over the 16 lanes of a DPP row (lane & 15), every lane gets the total
+__device__ __forceinline__ float fc_row_sum(float v) {
+    v += fc_dpp<0x128>(v);     // row_ror:8
+    v += fc_dpp<0x124>(v);     // row_ror:4
+    v += fc_dpp<0x4E>(v);      // quad_perm [2,3,0,1]
+    v += fc_dpp<0xB1>(v);      // quad_perm [1,0,3,2]
+    return v;
+}
+
+// grid (N / 16, ceil(M / 256)), 256 threads: wave w owns rows 64 w .. 64 w + 63 of the workgroup's 256
+__global__ __launch_bounds__(256) void fc_gemm_k(const FcArgs p) {
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int fi = lane & 15, fg = lane >> 4;
+    const int n0 = blockIdx.x * 16;
+    const int r0 = blockIdx.y * 256 + 64 * w;
+    // every load of the kernel is issued before the first use
+    u32x4_t wf[2], af[4][2];
+    const unsigned char* wp = p.W + ((size_t)(n0 + fi) * 64 + 8 * fg) * 2;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) wf[h] = *(const u32x4_t*)(wp + 64 * h);
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+        const int row = min(r0 + 16 * mt + fi, p.M - 1);               // clamped: rows past M are computed, not stored
+        const unsigned char* ap = p.A + ((size_t)row * p.lda + 8 * fg) * 2;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) af[mt][h] = *(const u32x4_t*)(ap + 64 * h);
+    }
+    f32x4_t bz = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    if (p.bias) bz = *(const f32x4_t*)(p.bias + n0 + 4 * fg);
+    f32x4_t acc[4];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) acc[mt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+            acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8_t*)&wf[h], *(const bf16x8_t*)&af[mt][h], acc[mt], 0, 0, 0);
+    // lane = row fi of tile mt, columns n0 + 4 fg .. + 3
+    float cs[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+        const int row = r0 + 16 * mt + fi;
+        unsigned short e[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) e[r] = f32_to_bf16(acc[mt][r] + bz[r]);
+        if (row < p.M) {
+            uint2 pk;
+            pk.x = (unsigned)e[0] | ((unsigned)e[1] << 16);
+            pk.y = (unsigned)e[2] | ((unsigned)e[3] << 16);
+            *(uint2*)(p.Out + ((size_t)row * p.ldo + n0 + 4 * fg) * 2) = pk;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) cs[r] += __uint_as_float((unsigned)e[r] << 16);
+        }
+    }
+    if (p.colsum_ws) {
+        __shared__ float red[4][16];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) cs[r] = fc_row_sum(cs[r]);
+        if (fi == 0) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) red[w][4 * fg + r] = cs[r];
+        }
+        __syncthreads();
+        if (tid < 32) {
+            const int t = tid >> 4, c = tid & 15;                       // 128-row tile t of this workgroup: waves 2t, 2t+1
+            if (blockIdx.y * 256 + 128 * t < p.M)
+                p.colsum_ws[((size_t)blockIdx.y * 2 + t) * p.N + n0 + c] = red[2 * t][c] + red[2 * t + 1][c];
+        }
+    }
+}
+
+}  // namespace rbvae
+
+using namespace rbvae;
+
+extern "C" {
+
+/* 1 when rbvae_fc_gemm covers the product (bf16, K = 64, N a multiple of 16) */
+int rbvae_fc_gemm_ok(int dtype, int M, int K, int N, int lda, int ldo) {
+    return dtype == RBVAE_BF16 && M >= 1 && K == 64 && N >= 16 && N % 16 == 0 && lda >= 64 && lda % 8 == 0 && ldo >= N &&
+           ldo % 4 == 0 && (long)cdiv(M, 256) < 65536;
+}
+
+int rbvae_fc_gemm(int dtype, const void* A, const void* W, void* Out, const float* bias, float* colsum_ws, int M, int K,
+                  int N, int lda, int ldo, void* stream) {
+    RBVAE_CHECK_ARG(A && W && Out, "fc_gemm: null pointer");
+    RBVAE_CHECK_ARG(rbvae_fc_gemm_ok(dtype, M, K, N, lda, ldo), "fc_gemm: shape outside the kernel (bf16, K = 64, N %% 16 == 0): "
+                    "dtype=%d M=%d K=%d N=%d lda=%d ldo=%d", dtype, M, K, N, lda, ldo);
+    RBVAE_CHECK_ARG(((uintptr_t)A | (uintptr_t)W) % 16 == 0 && (uintptr_t)Out % 8 == 0 && (!bias || (uintptr_t)bias % 16 == 0),
+                    "fc_gemm: A / W / bias must be 16-byte aligned, Out 8-byte aligned");
+    FcArgs a;
+    a.A = (const unsigned char*)A; a.W = (const unsigned char*)W; a.Out = (unsigned char*)Out; a.bias = bias;
+    a.colsum_ws = colsum_ws; a.M = M; a.N = N; a.lda = lda; a.ldo = ldo;
+    hipLaunchKernelGGL(fc_gemm_k, dim3(N / 16, cdiv(M, 256)), dim3(256), 0, (hipStream_t)stream, a);
+    RBVAE_CHECK_LAUNCH("fc_gemm");
+    return RBVAE_OK;
+}
+
+}  // extern "C"

@@ -257,6 +257,7 @@ class Engine:
         self._ks_force = int(os.environ.get("RBVAE_WG_KS", "0"))
         self._ks_small = int(os.environ.get("RBVAE_WG_KS_SMALL", "3"))
         self._wg_nt4 = os.environ.get("RBVAE_WG_NT4", "0") == "1"
+        self.fc_gemm = os.environ.get("RBVAE_FC_GEMM", "1") == "1"               # dedicated kernel for the K = 64 fc products
         self.lstm_pair_bwd = os.environ.get("RBVAE_LSTM_PAIR_BWD", "1") == "1"   # both stacks' BPTT in one launch
         self.keep_dz = os.environ.get("RBVAE_KEEP_DZ", "0") == "1"                # also store the codes' gradient
         self._wg_nt4_slab = int(os.environ.get("RBVAE_WG_NT4_SLAB", "8"))     # cap on a weight's f32 slabs, M floats
@@ -522,6 +523,12 @@ class Engine:
                 self._jobs.add(JOB_ROWS, ws, bias_grad, (1, 1, nout), (0, 0, 1), nslab=nb, slab=nout)
             L.call("rbvae_stream_gemm", A, W, out, bias, gate, nimg, nout, ldo, relu, drop_mode, float(drop_p),
                    float(scale), int(seed), seed_dev, ws)
+            return
+        if (self.fc_gemm and cls_key == "one" and gate is None and mask is None and drop_mode == 0 and not relu
+                and scale == 1.0 and bias_grad is None and nimg <= 4096 and nout >= 1024
+                and ih * iw * th * tw * oh * ow == 1 and L.query("rbvae_fc_gemm_ok", self.dt, nimg, kc, nout, lda, ldo)):
+            # the two fc products at the latent bottleneck: 0.13 GFLOP each, latency-bound (csrc/fc_gemm.hip)
+            L.call("rbvae_fc_gemm", self.dt, A, W, out, bias, colsum_ws, nimg, kc, nout, lda, ldo)
             return
         if cls_key == "one":
             desc, ncls = self._desc("one", ONE_TAP), 1
