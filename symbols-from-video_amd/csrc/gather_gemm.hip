@@ -150,26 +150,29 @@ template <int N> __device__ __forceinline__ void wait_vmcnt_barrier() {
 // problems: the 3/4-channel ends of the CNNs, the fc products) live on having four workgroups per CU in flight;
 // the 128 x 128 one takes 230 registers unconstrained (2 per CU: a 1024-workgroup grid runs as two rounds) and
 // spills accumulators when held to 128, the 128 x 64 one fits 128 registers without spilling.
-template <typename T, int NT, int WAVES, int GG_NS, int OCC = 1>
+// BM = tile rows (128; 64 for the 4-wave 64 x 64 tile of deep-K problems with few rows: at the same number of
+// workgroups a square tile takes in the fewest operand bytes per K step, and the CU's intake is what bounds the loop).
+template <typename T, int NT, int WAVES, int GG_NS, int OCC = 1, int BM = GG_BM>
 __global__ __launch_bounds__(WAVES * 64, OCC) void gather_gemm_k(const GgArgs p) {
     constexpr int THREADS = WAVES * 64;
+    static_assert(BM % 32 == 0 && BM + 16 <= THREADS, "tile rows");
     constexpr int BN = NT * 32;
     constexpr int ES = sizeof(T);
     constexpr int KE = 128 / ES;                 // k elements per staged row slice
     constexpr int EC = 16 / ES;                  // elements per 16-B chunk
-    constexpr int A_BYTES = GG_BM * 128, B_BYTES = BN * 128;
+    constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128;
     constexpr int STAGE = A_BYTES + B_BYTES;
     constexpr int PITCH = BN * ES + 16;          // epilogue tile row pitch
     // wave grid WR x WC over the 128 x BN tile; a wave owns MT x NTW MFMA tiles (16 x 16 each)
     constexpr int WR = 2, WC = WAVES / 2;
-    constexpr int MT = 8 / WR, NTW = (2 * NT) / WC;
-    constexpr int A_INSTR = 16 / WAVES, B_INSTR = (BN / 8) / WAVES;   // LDS-DMA instructions per wave per slice
+    constexpr int MT = (BM / 16) / WR, NTW = (2 * NT) / WC;
+    constexpr int A_INSTR = (BM / 8) / WAVES, B_INSTR = (BN / 8) / WAVES;   // LDS-DMA instructions per wave per slice
     constexpr int LOADS = A_INSTR + B_INSTR;
-    static_assert(NTW >= 1 && B_INSTR >= 1, "tile too narrow for this many waves");
-    constexpr int RING = GG_NS * STAGE > GG_BM * PITCH ? GG_NS * STAGE : GG_BM * PITCH;
+    static_assert(NTW >= 1 && B_INSTR >= 1 && A_INSTR >= 1 && MT >= 1, "tile too small for this many waves");
+    constexpr int RING = GG_NS * STAGE > BM * PITCH ? GG_NS * STAGE : BM * PITCH;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     int* s_orow = (int*)(smem + RING);           // [128]
-    int* s_tap = s_orow + GG_BM;                 // [16][4]: widx, dh, dw of this class
+    int* s_tap = s_orow + BM;                 // [16][4]: widx, dh, dw of this class
     float* s_bias = (float*)(s_tap + 64);        // [BN]: this tile's bias (0 without one), loaded while the tables are built
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -199,14 +202,14 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void gather_gemm_k(const GgArgs p)
     }
     const TapClass& tc = p.cls[bz];
     const int Mc = p.Nimg * p.TH * p.TW;
-    const int m0 = bx * GG_BM, n0 = by * BN;
+    const int m0 = bx * BM, n0 = by * BN;
     const int ntaps = tc.ntaps;
 
     // output row of every tile row (for the store phase) and the class's tap table
 #if GG_BIAS_LDS
     for (int i = tid; i < BN; i += THREADS) s_bias[i] = (p.bias && n0 + i < p.Nout) ? p.bias[n0 + i] : 0.f;
 #endif
-    if (tid < GG_BM) {
+    if (tid < BM) {
         const int m = m0 + tid;
         int o = -1;
         if (m < Mc) {
@@ -216,8 +219,8 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void gather_gemm_k(const GgArgs p)
             if (oh < p.OH && ow < p.OW) o = (n * p.OH + oh) * p.OW + ow;
         }
         s_orow[tid] = o;
-    } else if (tid < GG_BM + 16) {
-        const int j = tid - GG_BM;
+    } else if (tid < BM + 16) {
+        const int j = tid - BM;
         s_tap[j * 4 + 0] = tc.widx[j];
         s_tap[j * 4 + 1] = tc.dh[j];
         s_tap[j * 4 + 2] = tc.dw[j];
@@ -334,19 +337,23 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void gather_gemm_k(const GgArgs p)
     // wait until at most YOUNGER LDS reads are outstanding (in-order return): the guarded fragments landed
     auto landed = [&](auto younger_tag, u32x4_t (&fa)[MT], u32x4_t (&fb)[NTW]) {
         constexpr int YOUNGER = decltype(younger_tag)::value;
-        static_assert(MT == 4 && (NTW == 1 || NTW == 2 || NTW == 4), "operand list below");
-        if constexpr (NTW == 1)
+        static_assert((MT == 4 && (NTW == 1 || NTW == 2 || NTW == 4)) || (MT == 2 && NTW == 2), "operand list below");
+        if constexpr (MT == 2)
+            asm volatile("s_waitcnt lgkmcnt(%4)"
+                         : "+v"(fa[0]), "+v"(fa[MT - 1]), "+v"(fb[0]), "+v"(fb[NTW - 1])
+                         : "n"(YOUNGER));
+        else if constexpr (NTW == 1)
             asm volatile("s_waitcnt lgkmcnt(%5)"
-                         : "+v"(fa[0]), "+v"(fa[1]), "+v"(fa[2]), "+v"(fa[3]), "+v"(fb[0])
+                         : "+v"(fa[0]), "+v"(fa[1]), "+v"(fa[2 % MT]), "+v"(fa[3 % MT]), "+v"(fb[0])
                          : "n"(YOUNGER));
         else if constexpr (NTW == 2)
             asm volatile("s_waitcnt lgkmcnt(%6)"
-                         : "+v"(fa[0]), "+v"(fa[1]), "+v"(fa[2]), "+v"(fa[3]), "+v"(fb[0]), "+v"(fb[1])
+                         : "+v"(fa[0]), "+v"(fa[1]), "+v"(fa[2 % MT]), "+v"(fa[3 % MT]), "+v"(fb[0]), "+v"(fb[1 % NTW])
                          : "n"(YOUNGER));
         else
             asm volatile("s_waitcnt lgkmcnt(%8)"
-                         : "+v"(fa[0]), "+v"(fa[1]), "+v"(fa[2]), "+v"(fa[3]), "+v"(fb[0]), "+v"(fb[1]),
-                           "+v"(fb[2]), "+v"(fb[NTW - 1])
+                         : "+v"(fa[0]), "+v"(fa[1]), "+v"(fa[2 % MT]), "+v"(fa[3 % MT]), "+v"(fb[0]), "+v"(fb[1 % NTW]),
+                           "+v"(fb[2 % NTW]), "+v"(fb[NTW - 1])
                          : "n"(YOUNGER));
     };
     auto mma_half = [&](const u32x4_t (&fa)[MT], const u32x4_t (&fb)[NTW]) {
@@ -431,7 +438,7 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void gather_gemm_k(const GgArgs p)
     // so their latency runs under the register phase and the LDS round trip instead of once per store pass
     constexpr int CPR = BN / EC;                 // 16-B chunks per tile row
     constexpr int RL = THREADS / CPR;            // row lanes of the store phase
-    constexpr int ITERS = GG_BM / RL;            // store passes: pass `it` handles tile row it * RL + rl
+    constexpr int ITERS = BM / RL;            // store passes: pass `it` handles tile row it * RL + rl
     constexpr bool PREFETCH = GG_PREFETCH && ITERS <= 8;
     constexpr bool PF_LATE = GG_PREFETCH == 2;   // gate chunks fetched after the register phase (accumulators dead)
     const int sch = tid % CPR, rl = tid / CPR;
@@ -570,22 +577,22 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void gather_gemm_k(const GgArgs p)
 #endif
 }
 
-template <typename T, int NT, int WAVES, int NS, int OCC = 1>
+template <typename T, int NT, int WAVES, int NS, int OCC = 1, int BM = GG_BM>
 static int launch_gg(const GgArgs& a, hipStream_t st) {
     constexpr int BN = NT * 32;
     constexpr int ES = sizeof(T);
     const int Mc = a.Nimg * a.TH * a.TW;
-    const size_t ring = (size_t)NS * (GG_BM * 128 + BN * 128);
-    const size_t tile = (size_t)GG_BM * (BN * ES + 16);
-    const size_t lds = (ring > tile ? ring : tile) + GG_BM * sizeof(int) + 64 * sizeof(int) + BN * sizeof(float);
+    const size_t ring = (size_t)NS * (BM * 128 + BN * 128);
+    const size_t tile = (size_t)BM * (BN * ES + 16);
+    const size_t lds = (ring > tile ? ring : tile) + BM * sizeof(int) + 64 * sizeof(int) + BN * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute((const void*)gather_gemm_k<T, NT, WAVES, NS, OCC>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        hipFuncSetAttribute((const void*)gather_gemm_k<T, NT, WAVES, NS, OCC, BM>, hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)lds);
         attr_set = true;
     }
-    dim3 grid(cdiv(Mc, GG_BM), cdiv(a.Nout, BN), a.nclass);
-    hipLaunchKernelGGL((gather_gemm_k<T, NT, WAVES, NS, OCC>), grid, dim3(WAVES * 64), lds, st, a);
+    dim3 grid(cdiv(Mc, BM), cdiv(a.Nout, BN), a.nclass);
+    hipLaunchKernelGGL((gather_gemm_k<T, NT, WAVES, NS, OCC, BM>), grid, dim3(WAVES * 64), lds, st, a);
     RBVAE_CHECK_LAUNCH("gather_gemm");
     return RBVAE_OK;
 }
@@ -601,6 +608,12 @@ static int dispatch_gg(const GgArgs& a, hipStream_t st, int max_steps) {
     // deep-K problems with too few 128x128 tiles for the 256 CUs: narrower tiles (more workgroups, shorter steps)
     static const int small = getenv("RBVAE_GG_SMALL") ? atoi(getenv("RBVAE_GG_SMALL")) : 2;
     if (ns == 3 && !force && !dbg && small) {
+        // 64 x 64 tiles for the 64-block problems (conv3 forward, first deconv's input gradient at 256 frames): the same
+        // 256 workgroups as 128 x 32 tiles at 16 KB instead of 20 KB of operands per K step.  The fused column sums keep
+        // the 128-row tiles (their partial-sum rows are counted in 128-row tiles by the callers); xcd_order too.
+        static const int sq = getenv("RBVAE_GG_SQUARE") ? atoi(getenv("RBVAE_GG_SQUARE")) : 1;
+        if (sq && small >= 2 && blocks <= 64 && !a.colsum_ws && !a.xcd_order && sizeof(T) == 2)
+            return launch_gg<T, 2, 4, 3, 1, 64>(a, st);
         if (small >= 2 && blocks <= 64) return launch_gg<T, 1, 4, 3>(a, st);
         if (blocks <= 128) return launch_gg<T, 2, 4, 3>(a, st);
     }
