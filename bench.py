@@ -98,6 +98,7 @@ def roofline_leg(trainer, steps, tname, overlap):
     ~20 ms device-side sleep while the host enqueues the whole step, so an event pair brackets the kernel and not the
     host's launch latency, and the cost of an empty event pair is measured the same way and subtracted.
 
+      gather_gemm_k<T,2,4,3,64-row tile>  64x64 tiles, deep K, 4096 rows: conv3 forward, first deconv's input gradient
       gather_gemm_k<T,4,8,3>  128x128 row-gather GEMM, deep K, 129..256 workgroups: conv2 forward, first deconv
                               forward (4 parity classes) and their two input-gradient twins
       wgrad_gemm_k<T,2,3>     128x128 weight-gradient GEMM with K split over workgroups: the five 256-channel ones
@@ -116,10 +117,17 @@ def roofline_leg(trainer, steps, tname, overlap):
         max_taps = {"one": 1, "conv": taps, "dgrad": 4 if taps == 9 else max(1, taps // 4)}[cls_key]
         blocks = -(-(nimg * th * tw) // 128) * -(-nout // 128) * ncls
         deep = nout > 64 and max_taps * (kc // ke) > 2            # same rules as dispatch_gg()
-        if not deep:
+        fc = (getattr(eng, "fc_gemm", False) and cls_key == "one" and kc == 64 and nout >= 1024 and nimg <= 4096
+              and gate is None and mask is None and tname == "unsigned short" and not kw.get("relu") and not kw.get("drop_mode")
+              and kw.get("scale", 1.0) == 1.0 and kw.get("bias_grad") is None)
+        if fc:
+            name = "fc_gemm_k"                      # the two K = 64 fc products (csrc/fc_gemm.hip)
+        elif not deep:
             name = "gather_gemm_k<%s, single/double buffer>" % tname
         elif blocks > 256:
             name = "gather_gemm_k<%s, 4, 8, 2>" % tname
+        elif blocks <= 64 and tname == "unsigned short" and kw.get("bias_grad") is None and kw.get("colsum_ws") is None:
+            name = "gather_gemm_k<%s, 2, 4, 3, 64-row tile>" % tname
         elif blocks <= 64:
             name = "gather_gemm_k<%s, 1, 4, 3>" % tname
         elif blocks <= 128:

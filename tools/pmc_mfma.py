@@ -30,6 +30,8 @@ def inst_key(name):
     if m.group(1) == "gather_gemm_k":
         if a[3] == "1" or (a[1] == "2" and a[3] == "2"):
             return "gather_gemm_k<%s, single/double buffer>" % a[0]
+        if len(a) > 5 and a[5] == "64":
+            return "gather_gemm_k<%s, %s, %s, %s, 64-row tile>" % (a[0], a[1], a[2], a[3])
         return "gather_gemm_k<%s, %s, %s, %s>" % (a[0], a[1], a[2], a[3])
     return "wgrad_gemm_k<%s, %s, K-split>" % (a[0], a[1])
 

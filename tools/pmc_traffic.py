@@ -33,6 +33,8 @@ for name, grid, n, rd, wr in rows:
     a = [x.strip() for x in m.group(2).split(",")]
     if m.group(1) == "gather_gemm_k":
         key = "gather_gemm_k<%s, %s, %s, %s>" % (a[0], a[1], a[2], a[3])
+        if len(a) > 5 and a[5] == "64":
+            key = "gather_gemm_k<%s, %s, %s, %s, 64-row tile>" % (a[0], a[1], a[2], a[3])
         if a[3] == "1" or (a[1] == "2" and a[3] == "2"):
             key = "gather_gemm_k<%s, single/double buffer>" % a[0]
     else:
