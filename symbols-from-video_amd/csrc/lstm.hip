@@ -26,6 +26,8 @@
 
 namespace rbvae {
 
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+
 __device__ __forceinline__ long lstm_layer_floats(int L) { return 8l * L * L + 8l * L; }
 
 // hs_all : [layers+1][S][T][L]  slot 0 = stack input, slot l+1 = output of layer l
@@ -705,19 +707,21 @@ __global__ __launch_bounds__(1024) void lstm_pair_fwd_k(const PairArgs p) {
             const float* xt = hb + (l * T + t) * LS;
             const float* hp = hb + ((l + 1) * T + (t > 0 ? t - 1 : 0)) * LS;
             const float hscale = t > 0 ? 1.f : 0.f;
-            float a0 = bsum, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-            float b0 = 0.f, b1 = 0.f, b2 = 0.f, b3 = 0.f;
+            // four accumulator chains per dot product, kept as two float2 pairs: the fused multiply-adds of a pair issue
+            // as ONE packed instruction (v_pk_fma_f32, two FMAs per lane at the issue cost of one); every chain sees
+            // the same operands in the same order as the scalar form, so the sums are bit for bit the same
+            f32x2_t a01 = f32x2_t{bsum, 0.f}, a23 = f32x2_t{0.f, 0.f}, b01 = f32x2_t{0.f, 0.f}, b23 = f32x2_t{0.f, 0.f};
 #pragma unroll
             for (int k = 0; k < LMAX; k += 4) {
                 if (LC ? k < LC : k < L) {
                     const float4 xv = *(const float4*)(xt + k), hv = *(const float4*)(hp + k);
-                    a0 = fmaf(wih[k], xv.x, a0); a1 = fmaf(wih[k + 1], xv.y, a1);
-                    a2 = fmaf(wih[k + 2], xv.z, a2); a3 = fmaf(wih[k + 3], xv.w, a3);
-                    b0 = fmaf(whh[k], hv.x, b0); b1 = fmaf(whh[k + 1], hv.y, b1);
-                    b2 = fmaf(whh[k + 2], hv.z, b2); b3 = fmaf(whh[k + 3], hv.w, b3);
+                    a01 = __builtin_elementwise_fma(f32x2_t{wih[k], wih[k + 1]}, f32x2_t{xv.x, xv.y}, a01);
+                    a23 = __builtin_elementwise_fma(f32x2_t{wih[k + 2], wih[k + 3]}, f32x2_t{xv.z, xv.w}, a23);
+                    b01 = __builtin_elementwise_fma(f32x2_t{whh[k], whh[k + 1]}, f32x2_t{hv.x, hv.y}, b01);
+                    b23 = __builtin_elementwise_fma(f32x2_t{whh[k + 2], whh[k + 3]}, f32x2_t{hv.z, hv.w}, b23);
                 }
             }
-            const float pre = ((a0 + a1) + (a2 + a3)) + hscale * ((b0 + b1) + (b2 + b3));
+            const float pre = ((a01[0] + a01[1]) + (a23[0] + a23[1])) + hscale * ((b01[0] + b01[1]) + (b23[0] + b23[1]));
             const float av = is_g ? fast_tanh(pre) : fast_sigmoid(pre);
             gates[q * 4 * L + j] = av;
             if (acts) acts[(((long)l * S + s) * T + t) * 4 * L + j] = av;
