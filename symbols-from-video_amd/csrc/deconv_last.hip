@@ -40,6 +40,10 @@ struct DlArgs {
     int N, IH, IW, C1, NYP, Cout;
 };
 
+#ifndef DL_PIPE
+#define DL_PIPE 1        // 1: double buffer over single slices (slice s+1 in flight under slice s's MFMAs); 0: two slices staged
+                         // together, then multiplied
+#endif
 #ifndef DL_SL
 #define DL_SL 2          // 128-byte channel slices resident at a time (build switch: 1 -> three workgroups per CU)
 #endif
@@ -100,6 +104,77 @@ __global__ __launch_bounds__(256, (DL_SL == 1 ? 3 : 2)) void deconv_last_fused_k
     for (int a = 0; a < 3; ++a)
 #pragma unroll
         for (int b = 0; b < 3; ++b) acc[a][b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#if DL_PIPE
+    // Double buffer over single 128-byte channel slices (the same LDS as two resident slices): slice s+1 is in flight
+    // while slice s is multiplied, so the memory system is never idle between the staging rounds.
+    static_assert(SL == 2, "the two slice buffers of the pipelined form");
+    constexpr int PIX_I = DL_MROWS / 8, WTS_I = DL_WROWS / 8;         // LDS-DMA instructions of one slice
+    auto stage = [&](int s, int buf) __attribute__((always_inline)) {
+        for (int q = w; q < PIX_I + WTS_I; q += 4) {
+            const bool is_w = q >= PIX_I;
+            const int r = (is_w ? q - PIX_I : q) * 8 + srow;
+            const int sw = (schunk ^ ((r >> 1) & 7)) * 16;
+            const unsigned char* src = p.zero;
+            if (is_w) {
+                if (r < p.NYP) src = p.V + ((size_t)r * p.C1) * 2 + s * 128 + sw;
+            } else if (r < DL_PIX) {
+                const int la = r / DL_HB, lb = r - la * DL_HB;
+                const int a = a0 + la, b = b0 + lb;
+                if (a < p.IH && b < p.IW) src = p.D2 + ((size_t)((n * p.IH + a) * p.IW + b) * p.C1) * 2 + s * 128 + sw;
+            }
+            unsigned char* dst = (is_w ? s_wts + (size_t)buf * DL_WROWS * 128 : s_pix + (size_t)buf * DL_MROWS * 128) +
+                                 (size_t)(r - srow) * 128;
+            dl_glds16(src, dst);
+        }
+    };
+    // this wave's LDS-DMA count per slice: q = w, w + 4, ... < 26
+    constexpr int PER0 = (PIX_I + WTS_I + 3) / 4, PER1 = (PIX_I + WTS_I) / 4;
+    static_assert((PIX_I + WTS_I) % 4 == 2, "waves 0, 1 issue PER0 pieces, waves 2, 3 PER1");
+    // The fragment reads are inline asm behind explicit waits: a C++ LDS read (or __syncthreads) after a
+    // global_load_lds makes the compiler drain EVERY LDS-DMA first (s_waitcnt vmcnt(0)), slice s+1 included.
+    const unsigned lds_pix = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)s_pix;
+    const unsigned lds_wts = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)s_wts;
+    stage(0, 0);
+    for (int s = 0; s < KS; ++s) {
+        const int buf = s & 1;
+        if (s + 1 < KS) {
+            stage(s + 1, buf ^ 1);
+            // slice s landed for this wave (its PER pieces of slice s+1 stay in flight), then the workgroup barrier
+            if (w < 2) asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::"n"(PER0) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::"n"(PER1) : "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        }
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const int ch = ((4 * kk + fg) ^ fsw) * 16;
+            u32x4_t wf[3], pf[3];
+#pragma unroll
+            for (int rt = 0; rt < 3; ++rt) {
+                const unsigned ad = lds_wts + (unsigned)((buf * DL_WROWS + rt * 16 + fi) * 128 + ch);
+                asm volatile("ds_read_b128 %0, %1" : "=v"(wf[rt]) : "v"(ad));
+            }
+#pragma unroll
+            for (int pi = 0; pi < 3; ++pi) {
+                const int pt = min(w + 4 * pi, DL_MROWS / 16 - 1);           // waves 2, 3 have no third tile: read, not used
+                const unsigned ad = lds_pix + (unsigned)((buf * DL_MROWS + pt * 16 + fi) * 128 + ch);
+                asm volatile("ds_read_b128 %0, %1" : "=v"(pf[pi]) : "v"(ad));
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(wf[0]), "+v"(wf[1]), "+v"(wf[2]), "+v"(pf[0]), "+v"(pf[1]), "+v"(pf[2]));
+#pragma unroll
+            for (int pi = 0; pi < 3; ++pi) {
+                if (w + 4 * pi < DL_MROWS / 16) {
+#pragma unroll
+                    for (int rt = 0; rt < 3; ++rt)
+                        acc[pi][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8_t*)&wf[rt],
+                                                                              *(const bf16x8_t*)&pf[pi], acc[pi][rt], 0, 0, 0);
+                }
+            }
+        }
+        // everyone is done reading this buffer (every read above was waited for): slice s+2 may land in it
+        if (s + 2 < KS) asm volatile("s_barrier" ::: "memory");
+    }
+#else
     for (int s0 = 0; s0 < KS; s0 += SL) {
         const int ns = min(SL, KS - s0);
         if (s0) __syncthreads();                                     // everyone is done reading the previous slices
@@ -149,6 +224,7 @@ __global__ __launch_bounds__(256, (DL_SL == 1 ? 3 : 2)) void deconv_last_fused_k
             }
         }
     }
+#endif
     // the prefetched epilogue operands landed long ago; saying so here keeps the compiler from waiting for them (and with
     // them for the x_recon stores) in the middle of the epilogue
 #pragma unroll
