@@ -55,9 +55,12 @@ class GradReducer:
     Bucket order = reverse layer order, as SURVEY.md 8e asks; the cut sits where the side stream's work is done
     when the main chain arrives (engine.backward(cut=...)), so it costs no idle time."""
 
-    def __init__(self, gflat: torch.Tensor, cut: int, group=None):
+    def __init__(self, gflat: torch.Tensor, cut: int, group=None, force: bool = False):
+        """force: issue the collectives even in a one-rank group (rehearsals of the multi-rank schedule on one GPU)."""
         self.gflat, self.cut, self.group = gflat, int(cut), group
         self.world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
+        if force and dist.is_available() and dist.is_initialized():
+            self.world = max(self.world, 2)
         if not 0 < self.cut < gflat.numel() or self.cut % 4:
             raise ValueError(f"bucket cut {cut} outside the buffer or not 16-byte aligned")
 
@@ -72,6 +75,16 @@ class GradReducer:
     def reduce_all(self):
         if self.world > 1:
             dist.all_reduce(self.gflat, op=dist.ReduceOp.SUM, group=self.group)
+
+    def reduce_tail(self):
+        """Tail bucket, synchronous form: on return the CURRENT stream is ordered behind the collective (what an
+        in-graph schedule captures on its communication stream)."""
+        if self.world > 1:
+            dist.all_reduce(self.tail, op=dist.ReduceOp.SUM, group=self.group)
+
+    def reduce_head(self):
+        if self.world > 1:
+            dist.all_reduce(self.head, op=dist.ReduceOp.SUM, group=self.group)
 
     def start_tail(self):
         if self.world > 1:

@@ -387,6 +387,9 @@ class Engine:
         tab = self._pack_tab.get(key)
         if tab is not None:
             return tab[0], tab[1]
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("update job table missing during graph capture: run one eager update with the same buffers, "
+                               f"hyper-parameters and part ({part!r}) first (FusedTrainer's warm-up steps do)")
         f2 = lambda a, b: struct.unpack("<q", struct.pack("<ff", float(a), float(b)))[0]
         b1, b2 = betas
         ctx = torch.tensor([flat.data_ptr(), gflat.data_ptr(), m.data_ptr(), v.data_ptr(), hyper.data_ptr(),

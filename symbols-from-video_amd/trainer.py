@@ -98,6 +98,14 @@ class FusedTrainer:
         # collective's own stream beside the encoder CNN's backward graph, the head after it.  RBVAE_DDP_OVERLAP=0:
         # one all-reduce of the whole buffer between the backward graph and the Adam graph.
         self.ddp_overlap = os.environ.get("RBVAE_DDP_OVERLAP", "1") == "1"
+        # with the overlap schedule: update the tail bucket's parameters while the head's all-reduce is in flight.  Off: the
+        # one-rank RCCL rehearsal (tools/rccl_single.py) prices the fourth graph at +17 us per step (0.505 -> 0.522 ms),
+        # more than the 14 us of update it can hide; in the in-graph schedule it costs 9 us
+        self.ddp_split_update = os.environ.get("RBVAE_DDP_SPLIT_UPDATE", "0") == "1"
+        # RBVAE_DDP_INGRAPH=1 (opt-in; rehearsed with a one-rank RCCL group only, tools/rccl_single.py): the two all-reduces
+        # are captured INTO the step's single graph on a communication stream -- no graph boundary at the cut, no
+        # host-side choreography between replays
+        self.ddp_ingraph = os.environ.get("RBVAE_DDP_INGRAPH", "0") == "1"
         self.fused_pair = os.environ.get("RBVAE_FUSED_PAIR", "1") == "1"
         # RBVAE_EARLY_UPDATE=1 (single GPU, experiment, off): the optimiser update and the weight repack run per parameter
         # group as soon as the group's gradients are final, on the side stream beside the rest of the backward pass
@@ -499,7 +507,7 @@ class FusedTrainer:
         with torch.cuda.stream(s):
             for _ in range(2):
                 self._fwd_bwd(x, U, tau, B, T, cut=(lambda: None) if (self.world > 1 and self.ddp_overlap) else None)
-                if self.world > 1 and self.ddp_overlap and self.fused_update:
+                if self.world > 1 and self.ddp_overlap and self.fused_update and self.ddp_split_update:
                     self._update("tail")          # (the warm-up also builds the job tables the capture replays)
                     self._update("head")
                 else:
@@ -515,6 +523,40 @@ class FusedTrainer:
             with torch.cuda.graph(g1, pool=pool):
                 self._fwd_bwd(x, U, tau, B, T)
                 self._update()
+        elif self.world > 1 and self.ddp_overlap and self.ddp_ingraph:
+            # ONE graph with the collectives inside: the tail bucket's all-reduce forks onto a communication stream at the
+            # cut and runs beside the encoder CNN's backward pass, the head's follows it there behind the last reduction,
+            # the update(s) wait for their bucket
+            red = self._reducer()
+            red.reduce_all()                                   # communicator up before the capture (gflat is scratch here)
+            torch.cuda.synchronize()
+            cs, comm = torch.cuda.Stream(), torch.cuda.Stream()
+            cs.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(cs):
+                g1.capture_begin(pool=pool)
+                ev_tail = torch.cuda.Event()
+
+                def cut():
+                    comm.wait_stream(torch.cuda.current_stream())
+                    with torch.cuda.stream(comm):
+                        red.reduce_tail()
+                        ev_tail.record(comm)
+
+                self._fwd_bwd(x, U, tau, B, T, cut=cut)
+                comm.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(comm):
+                    red.reduce_head()
+                if self.fused_update and self.ddp_split_update:
+                    torch.cuda.current_stream().wait_event(ev_tail)
+                    self._update("tail")
+                    torch.cuda.current_stream().wait_stream(comm)
+                    self._update("head")
+                else:
+                    torch.cuda.current_stream().wait_stream(comm)
+                    self._update()
+                g1.capture_end()
+            torch.cuda.current_stream().wait_stream(cs)
+            g2 = None
         elif self.world > 1 and self.ddp_overlap:
             # three graphs: forward + backward up to the cut | the encoder CNN's backward | Adam
             g2, g3 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
@@ -531,7 +573,7 @@ class FusedTrainer:
                 g2.capture_end()
                 g3.capture_begin(pool=pool)
                 g4 = None
-                if self.fused_update:
+                if self.fused_update and self.ddp_split_update:
                     # the update in the two gradient buckets: the tail's runs while the head is still being all-reduced
                     self._update("tail")
                     g3.capture_end()

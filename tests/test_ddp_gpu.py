@@ -21,10 +21,10 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _run(rank, world, port, overlap, q):
+def _run(rank, world, port, overlap, q, split=0):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
-                      LOCAL_RANK="0", RBVAE_DDP_OVERLAP=str(overlap))
+                      LOCAL_RANK="0", RBVAE_DDP_OVERLAP=str(overlap), RBVAE_DDP_SPLIT_UPDATE=str(split))
     from importlib import import_module
     import sfv_amd as sfv
     ddp = import_module("symbols-from-video_amd.ddp")
@@ -57,11 +57,11 @@ def _run(rank, world, port, overlap, q):
         torch.distributed.destroy_process_group()
 
 
-def _launch(world, overlap):
+def _launch(world, overlap, split=0):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_run, args=(r, world, port, overlap, q)) for r in range(world)]
+    procs = [ctx.Process(target=_run, args=(r, world, port, overlap, q, split)) for r in range(world)]
     for p in procs:
         p.start()
     import queue
@@ -86,8 +86,10 @@ def _launch(world, overlap):
 def test_ddp_overlap_matches_single_allreduce():
     n_graphs_a, flat_a = _launch(2, 1)
     n_graphs_b, flat_b = _launch(2, 0)
-    assert n_graphs_a == 4 and n_graphs_b == 2      # overlapped: fwd+bwd to the cut | rest of bwd | update(tail) | update(head)
-    assert torch.equal(flat_a, flat_b)
+    n_graphs_c, flat_c = _launch(2, 1, split=1)
+    # overlapped: fwd+bwd to the cut | rest of bwd | update; with RBVAE_DDP_SPLIT_UPDATE=1: update(tail) | update(head)
+    assert n_graphs_a == 3 and n_graphs_b == 2 and n_graphs_c == 4
+    assert torch.equal(flat_a, flat_b) and torch.equal(flat_c, flat_b)
     # sanity against one process on the global batch (per-rank losses are shard means, their average is the global mean);
     # Adam turns bf16 accumulation-order noise on near-zero gradients into +-lr steps, hence the loose bound -- the
     # reduction semantics themselves are pinned by tests/test_ddp_cpu.py
@@ -115,3 +117,19 @@ def test_bench_gpus2_self_launches():
     assert line["config"]["graphs_captured"] == 1
     assert 0 < line["roofline"]["e2e"]["frac_hbm"] < 1
     assert all(abs(v) < 1e4 for v in line["config"]["last_losses"].values())
+
+
+@pytest.mark.timeout(600)
+def test_in_graph_collectives_with_one_rank_rccl():
+    """RBVAE_DDP_INGRAPH=1: the two all-reduces captured INTO the step's single HIP graph on a communication stream.
+    Rehearsed the only way one GPU allows: a one-rank "nccl" (RCCL) group whose collectives are really issued
+    (GradReducer(force=True)); every schedule -- 2 / 3 / 4 graphs, and one graph with the collectives inside, with and
+    without the split update -- must leave bit-identical parameters (tools/rccl_single.py)."""
+    import subprocess
+    env = dict(os.environ, RCCL_SINGLE_STEPS="20", MASTER_PORT=str(_free_port()))
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "rccl_single.py")], env=env, capture_output=True, text=True,
+                       timeout=500)
+    out = r.stdout + r.stderr
+    assert r.returncode == 0, out[-3000:]
+    assert "parameters after 5 steps identical: True" in out, out[-3000:]
+    assert out.count("1 graphs + RCCL") == 2 and "4 graphs + RCCL" in out and "3 graphs + RCCL" in out, out[-3000:]
