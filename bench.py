@@ -117,7 +117,7 @@ def roofline_leg(trainer, steps, tname, overlap):
         max_taps = {"one": 1, "conv": taps, "dgrad": 4 if taps == 9 else max(1, taps // 4)}[cls_key]
         blocks = -(-(nimg * th * tw) // 128) * -(-nout // 128) * ncls
         deep = nout > 64 and max_taps * (kc // ke) > 2            # same rules as dispatch_gg()
-        fc = (getattr(eng, "fc_gemm", False) and cls_key == "one" and kc == 64 and nout >= 1024 and nimg <= 4096
+        fc = (getattr(eng, "fc_gemm", False) and cls_key == "one" and kc in (64, 128) and nout >= 1024 and nimg <= 4096
               and gate is None and mask is None and tname == "unsigned short" and not kw.get("relu") and not kw.get("drop_mode")
               and kw.get("scale", 1.0) == 1.0 and kw.get("bias_grad") is None)
         if fc:

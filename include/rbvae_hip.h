@@ -148,14 +148,14 @@ int rbvae_gather_gemm(int dtype, const void* A, const void* W, void* Out, const 
                       unsigned long long seed, const unsigned long long* seed_dev, float* colsum_ws,
                       void* stream);
 
-/* ---- the K = 64 products around the latent bottleneck (bf16) -------------------------------------
- * Out[M][ldo] = A[M][lda] (64 used columns) * W[N][64]^T (+ bias[N]) for a few hundred rows and thousands of columns:
+/* ---- the K = 64 / 128 products around the latent bottleneck (bf16) -------------------------------
+ * Out[M][ldo] = A[M][lda] (K used columns) * W[N][K]^T (+ bias[N]) for a few hundred rows and thousands of columns:
  * the decoder's fc forward (Linear(latent_dim -> C3*h3*w3), percep_RBVAE_model.py:74, on the zero-padded codes) and
  * the input gradient of the encoder's fc (autograd of :61).  The arithmetic of rbvae_gather_gemm with one tap,
  * element for element; operands go from global memory straight into the MFMA layout (no tables, no LDS ring).
  * colsum_ws (may be NULL): [ceil(M/128)][N] column sums of the stored values per 128-row tile (rbvae_gather_gemm's
- * layout; the bias gradient of the layer below).  rbvae_fc_gemm_ok: 1 when the shape is covered (bf16, K == 64,
- * N % 16 == 0). */
+ * layout; the bias gradient of the layer below).  rbvae_fc_gemm_ok: 1 when the shape is covered (bf16, K == 64 or
+ * 128 = latent_dim padded to the GEMMs' 64-column slices, N % 16 == 0). */
 int rbvae_fc_gemm_ok(int dtype, int M, int K, int N, int lda, int ldo);
 int rbvae_fc_gemm(int dtype, const void* A, const void* W, void* Out, const float* bias, float* colsum_ws, int M, int K,
                   int N, int lda, int ldo, void* stream);

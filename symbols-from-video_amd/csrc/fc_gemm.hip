@@ -1,6 +1,6 @@
-// The two K = 64 products around the latent bottleneck, bf16 storage:
+// The two K = 64 (or 128) products around the latent bottleneck, bf16 storage:
 //
-//   Out[m][n] = sum_{k < 64} A[m][k] * W[n][k] (+ bias[n]),   M = a few hundred frames, N = thousands of features
+//   Out[m][n] = sum_{k < K} A[m][k] * W[n][k] (+ bias[n]),   M = a few hundred frames, N = thousands of features
 //
 // = the decoder's fc forward (Linear(latent -> C3*h3*w3), percep_RBVAE_model.py:74 on the zero-padded codes) and the
 // input gradient of the encoder's fc (autograd of :61).  They are 0.13 GFLOP and 2.5 MB each -- latency, not work:
@@ -22,8 +22,8 @@ typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
 
 struct FcArgs {
-    const unsigned char* A;      // [M][lda] bf16, 64 used columns
-    const unsigned char* W;      // [N][64] bf16
+    const unsigned char* A;      // [M][lda] bf16, K used columns
+    const unsigned char* W;      // [N][K] bf16
     unsigned char* Out;          // [M][ldo] bf16
     const float* bias;           // [N] or null
     float* colsum_ws;            // [ceil(M/128)][N] or null
@@ -42,23 +42,26 @@ __device__ __forceinline__ float fc_row_sum(float v) {
     return v;
 }
 
-// grid (N / 16, ceil(M / 256)), 256 threads: wave w owns rows 64 w .. 64 w + 63 of the workgroup's 256
+// grid (N / 16, ceil(M / 256)), 256 threads: wave w owns rows 64 w .. 64 w + 63 of the workgroup's 256.
+// KH = 32-deep MFMA steps: K = 64 (latent_dim <= 64) or 128 (latent_dim 65 .. 128).
+template <int KH>
 __global__ __launch_bounds__(256) void fc_gemm_k(const FcArgs p) {
+    constexpr int K = 32 * KH;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int fi = lane & 15, fg = lane >> 4;
     const int n0 = blockIdx.x * 16;
     const int r0 = blockIdx.y * 256 + 64 * w;
     // every load of the kernel is issued before the first use
-    u32x4_t wf[2], af[4][2];
-    const unsigned char* wp = p.W + ((size_t)(n0 + fi) * 64 + 8 * fg) * 2;
+    u32x4_t wf[KH], af[4][KH];
+    const unsigned char* wp = p.W + ((size_t)(n0 + fi) * K + 8 * fg) * 2;
 #pragma unroll
-    for (int h = 0; h < 2; ++h) wf[h] = *(const u32x4_t*)(wp + 64 * h);
+    for (int h = 0; h < KH; ++h) wf[h] = *(const u32x4_t*)(wp + 64 * h);
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) {
         const int row = min(r0 + 16 * mt + fi, p.M - 1);               // clamped: rows past M are computed, not stored
         const unsigned char* ap = p.A + ((size_t)row * p.lda + 8 * fg) * 2;
 #pragma unroll
-        for (int h = 0; h < 2; ++h) af[mt][h] = *(const u32x4_t*)(ap + 64 * h);
+        for (int h = 0; h < KH; ++h) af[mt][h] = *(const u32x4_t*)(ap + 64 * h);
     }
     f32x4_t bz = f32x4_t{0.f, 0.f, 0.f, 0.f};
     if (p.bias) bz = *(const f32x4_t*)(p.bias + n0 + 4 * fg);
@@ -66,7 +69,7 @@ __global__ __launch_bounds__(256) void fc_gemm_k(const FcArgs p) {
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) acc[mt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int h = 0; h < 2; ++h)
+    for (int h = 0; h < KH; ++h)
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt)
             acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8_t*)&wf[h], *(const bf16x8_t*)&af[mt][h], acc[mt], 0, 0, 0);
@@ -110,23 +113,24 @@ using namespace rbvae;
 
 extern "C" {
 
-/* 1 when rbvae_fc_gemm covers the product (bf16, K = 64, N a multiple of 16) */
+/* 1 when rbvae_fc_gemm covers the product (bf16, K = 64 or 128, N a multiple of 16) */
 int rbvae_fc_gemm_ok(int dtype, int M, int K, int N, int lda, int ldo) {
-    return dtype == RBVAE_BF16 && M >= 1 && K == 64 && N >= 16 && N % 16 == 0 && lda >= 64 && lda % 8 == 0 && ldo >= N &&
+    return dtype == RBVAE_BF16 && M >= 1 && (K == 64 || K == 128) && N >= 16 && N % 16 == 0 && lda >= K && lda % 8 == 0 && ldo >= N &&
            ldo % 4 == 0 && (long)cdiv(M, 256) < 65536;
 }
 
 int rbvae_fc_gemm(int dtype, const void* A, const void* W, void* Out, const float* bias, float* colsum_ws, int M, int K,
                   int N, int lda, int ldo, void* stream) {
     RBVAE_CHECK_ARG(A && W && Out, "fc_gemm: null pointer");
-    RBVAE_CHECK_ARG(rbvae_fc_gemm_ok(dtype, M, K, N, lda, ldo), "fc_gemm: shape outside the kernel (bf16, K = 64, N %% 16 == 0): "
+    RBVAE_CHECK_ARG(rbvae_fc_gemm_ok(dtype, M, K, N, lda, ldo), "fc_gemm: shape outside the kernel (bf16, K = 64 or 128, N %% 16 == 0): "
                     "dtype=%d M=%d K=%d N=%d lda=%d ldo=%d", dtype, M, K, N, lda, ldo);
     RBVAE_CHECK_ARG(((uintptr_t)A | (uintptr_t)W) % 16 == 0 && (uintptr_t)Out % 8 == 0 && (!bias || (uintptr_t)bias % 16 == 0),
                     "fc_gemm: A / W / bias must be 16-byte aligned, Out 8-byte aligned");
     FcArgs a;
     a.A = (const unsigned char*)A; a.W = (const unsigned char*)W; a.Out = (unsigned char*)Out; a.bias = bias;
     a.colsum_ws = colsum_ws; a.M = M; a.N = N; a.lda = lda; a.ldo = ldo;
-    hipLaunchKernelGGL(fc_gemm_k, dim3(N / 16, cdiv(M, 256)), dim3(256), 0, (hipStream_t)stream, a);
+    if (K == 64) hipLaunchKernelGGL(fc_gemm_k<2>, dim3(N / 16, cdiv(M, 256)), dim3(256), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(fc_gemm_k<4>, dim3(N / 16, cdiv(M, 256)), dim3(256), 0, (hipStream_t)stream, a);
     RBVAE_CHECK_LAUNCH("fc_gemm");
     return RBVAE_OK;
 }

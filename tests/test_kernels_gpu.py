@@ -41,39 +41,40 @@ def gemm(sfv, dt, A, Wp, out, bias, gate, mask, geom, kc, nout, taps, desc, ncls
                   out.shape[1], taps, ncls, ctypes.addressof(d), relu, drop_mode, drop_p, scale, seed, None, colsum_ws)
 
 
-@pytest.mark.parametrize("M,N,lda,with_bias", [(256, 4096, 64, True), (256, 4096, 64, False), (37, 1024, 72, True),
-                                                (300, 2064, 64, False), (1, 16, 64, True)])
-def test_fc_gemm_equals_one_tap_gather_gemm(sfv, M, N, lda, with_bias):
+@pytest.mark.parametrize("M,N,lda,with_bias,K", [(256, 4096, 64, True, 64), (256, 4096, 64, False, 64), (37, 1024, 72, True, 64),
+                                                  (300, 2064, 64, False, 64), (1, 16, 64, True, 64), (256, 4096, 128, True, 128),
+                                                  (70, 1040, 136, False, 128)])
+def test_fc_gemm_equals_one_tap_gather_gemm(sfv, M, N, lda, with_bias, K):
     """rbvae_fc_gemm (the K = 64 fc products, operands straight into the MFMA layout) against rbvae_gather_gemm with one
     tap: outputs bit for bit (same MFMAs in the same k order, same rounding), the per-128-row column sums to f32
     rounding of their different summation order, and against the f32 product of the bf16 operands."""
     lib = sfv._lib
-    assert lib.query("rbvae_fc_gemm_ok", 1, M, 64, N, lda, N)
+    assert lib.query("rbvae_fc_gemm_ok", 1, M, K, N, lda, N)
     g = torch.Generator().manual_seed(90 + M)
     A = torch.zeros(M, lda, dtype=torch.bfloat16)
-    A[:, :64] = torch.randn(M, 64, generator=g).bfloat16()
+    A[:, :K] = torch.randn(M, K, generator=g).bfloat16()
     A = A.cuda()
-    W = (torch.randn(N, 64, generator=g) / 8).bfloat16().cuda()
+    W = (torch.randn(N, K, generator=g) / 8).bfloat16().cuda()
     b = torch.randn(N, generator=g).cuda() if with_bias else None
     mt = -(-M // 128)
     out0, ws0 = torch.empty(M, N, dtype=torch.bfloat16, device="cuda"), torch.zeros(mt, N, device="cuda")
-    gemm(sfv, 1, A, W, out0, b, None, None, (M, 1, 1, 1, 1, 1, 1, 1, 1), 64, N, 1, (1, 0, 0, 0, 0, 0), 1, colsum_ws=ws0)
+    gemm(sfv, 1, A, W, out0, b, None, None, (M, 1, 1, 1, 1, 1, 1, 1, 1), K, N, 1, (1, 0, 0, 0, 0, 0), 1, colsum_ws=ws0)
     out1, ws1 = torch.full((M, N), 7.0, dtype=torch.bfloat16, device="cuda"), torch.full((mt, N), 7.0, device="cuda")
-    lib.call("rbvae_fc_gemm", 1, A, W, out1, b, ws1, M, 64, N, lda, N)
+    lib.call("rbvae_fc_gemm", 1, A, W, out1, b, ws1, M, K, N, lda, N)
     torch.cuda.synchronize()
     assert torch.equal(out0, out1)
-    ref = A[:, :64].float() @ W.float().t() + (b if with_bias else 0)
+    ref = A[:, :K].float() @ W.float().t() + (b if with_bias else 0)
     assert rel(out1.float().cpu(), ref.cpu()) < 4e-3
     np.testing.assert_allclose(ws1.cpu().numpy(), ws0.cpu().numpy(), rtol=1e-5, atol=1e-4)
     sums = torch.stack([out1[128 * t:128 * (t + 1)].float().sum(0) for t in range(mt)])
     np.testing.assert_allclose(ws1.cpu().numpy(), sums.cpu().numpy(), rtol=1e-5, atol=1e-4)
     # without column sums, and shapes it does not cover
     out2 = torch.empty_like(out1)
-    lib.call("rbvae_fc_gemm", 1, A, W, out2, b, None, M, 64, N, lda, N)
+    lib.call("rbvae_fc_gemm", 1, A, W, out2, b, None, M, K, N, lda, N)
     assert torch.equal(out2, out0)
-    assert not lib.query("rbvae_fc_gemm_ok", 0, M, 64, N, lda, N) and not lib.query("rbvae_fc_gemm_ok", 1, M, 128, N, 128, N)
+    assert not lib.query("rbvae_fc_gemm_ok", 0, M, K, N, lda, N) and not lib.query("rbvae_fc_gemm_ok", 1, M, 192, N, 192, N)
     with pytest.raises(ValueError):
-        lib.call("rbvae_fc_gemm", 1, A, W, out2, b, None, M, 64, N + 8, lda, N + 8)
+        lib.call("rbvae_fc_gemm", 1, A, W, out2, b, None, M, K, N + 8, lda, N + 8)
 
 
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
