@@ -266,7 +266,9 @@ constexpr int BIG_W = 128;       // weights per lane
 // chunks are in flight together.
 template <int NCH>
 __device__ __forceinline__ float big_dot(const float (&w)[BIG_W], const float* __restrict__ vec) {
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    // four accumulator chains as two float2 pairs: a pair's fused multiply-adds issue as one packed instruction
+    // (v_pk_fma_f32); each chain sees the operands of the scalar form in the same order (bit-identical sums)
+    f32x2_t a01 = f32x2_t{0.f, 0.f}, a23 = f32x2_t{0.f, 0.f};
     constexpr int CH = NCH > 28 ? 4 : 8;           // reads in flight (the full 128-weight rows leave fewer registers)
 #pragma unroll
     for (int i0 = 0; i0 < NCH; i0 += CH) {
@@ -277,12 +279,12 @@ __device__ __forceinline__ float big_dot(const float (&w)[BIG_W], const float* _
 #pragma unroll
         for (int i = 0; i < CH; ++i)
             if (i0 + i < NCH) {
-                a0 = fmaf(w[4 * (i0 + i)], v[i].x, a0); a1 = fmaf(w[4 * (i0 + i) + 1], v[i].y, a1);
-                a2 = fmaf(w[4 * (i0 + i) + 2], v[i].z, a2); a3 = fmaf(w[4 * (i0 + i) + 3], v[i].w, a3);
+                a01 = __builtin_elementwise_fma(f32x2_t{w[4 * (i0 + i)], w[4 * (i0 + i) + 1]}, f32x2_t{v[i].x, v[i].y}, a01);
+                a23 = __builtin_elementwise_fma(f32x2_t{w[4 * (i0 + i) + 2], w[4 * (i0 + i) + 3]}, f32x2_t{v[i].z, v[i].w}, a23);
             }
         __builtin_amdgcn_sched_barrier(0);
     }
-    return (a0 + a1) + (a2 + a3);
+    return (a01[0] + a01[1]) + (a23[0] + a23[1]);
 }
 
 // w[i] = base[i * step] for i < n (else 0): unconditional loads on clamped (always valid) indices, eight in flight,
