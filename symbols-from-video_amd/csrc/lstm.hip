@@ -381,6 +381,9 @@ __global__ __launch_bounds__(512) void lstm_fwd_big_k(const float* __restrict__ 
 // one batch per layer.  dG rows sit in LDS in four 132-float segments (one per lane of a group: conflict-free 16-byte
 // reads).
 constexpr int BIG_SEG = 132;
+template <int CTRL> __device__ __forceinline__ float big_quad(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, false));
+}
 template <int NCH>
 __global__ __launch_bounds__(512) void lstm_bwd_big_k(const float* __restrict__ wblk, const float* __restrict__ wT,
                                                       const float* __restrict__ acts, const float* __restrict__ cs,
@@ -456,8 +459,8 @@ __global__ __launch_bounds__(512) void lstm_bwd_big_k(const float* __restrict__ 
             }
             lds_barrier();
             float a = big_dot<NCH>(w, dgall + t * DS + p * BIG_SEG);
-            a += __shfl_xor(a, 1, 64);
-            a += __shfl_xor(a, 2, 64);
+            a += big_quad<0xB1>(a);          // + lane ^ 1   (DPP quad_perm [1,0,3,2]; a + b == b + a: the sums of __shfl_xor)
+            a += big_quad<0x4E>(a);          // + lane ^ 2   (quad_perm [2,3,0,1])
             if (p == 0 && col) dhrec[k] = a;
             lds_barrier();
         }
@@ -465,8 +468,8 @@ __global__ __launch_bounds__(512) void lstm_bwd_big_k(const float* __restrict__ 
 #pragma unroll 1
         for (int t = 0; t < T; ++t) {
             float a = big_dot<NCH>(w, dgall + t * DS + p * BIG_SEG);
-            a += __shfl_xor(a, 1, 64);
-            a += __shfl_xor(a, 2, 64);
+            a += big_quad<0xB1>(a);          // + lane ^ 1   (DPP quad_perm [1,0,3,2]; a + b == b + a: the sums of __shfl_xor)
+            a += big_quad<0x4E>(a);          // + lane ^ 2   (quad_perm [2,3,0,1])
             if (p == 0 && col) dxin[t * BIG_VS + k] = a;
         }
         __syncthreads();
