@@ -295,16 +295,18 @@ __device__ __forceinline__ void big_load_w(float (&w)[BIG_W], const float* __res
     // opaque to the optimiser: otherwise the 128 clamped 64-bit addresses are computed once outside the layer loop and
     // live (spilled) across the time loops
     asm volatile("" : "+v"(n1));
+    // every load goes straight into its weight register and nothing is used before the last one is issued: the whole
+    // row is in flight at once (with a select inside each batch of eight the batches were 13 dependent round trips per
+    // reload, two reloads per layer).  The scheduling barriers keep the address arithmetic to eight loads at a time.
 #pragma unroll
     for (int i0 = 0; i0 < 4 * NCH; i0 += 8) {
-        float v[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) v[i] = base[min(i0 + i, n1) * step];
 #pragma unroll
         for (int i = 0; i < 8; ++i)
-            if (i0 + i < 4 * NCH) w[i0 + i] = (on && i0 + i < n) ? v[i] : 0.f;
+            if (i0 + i < 4 * NCH) w[i0 + i] = base[min(i0 + i, n1) * step];
         __builtin_amdgcn_sched_barrier(0);
     }
+#pragma unroll
+    for (int i = 0; i < 4 * NCH; ++i) w[i] = (on && i < n) ? w[i] : 0.f;
 }
 
 template <int NCH>
