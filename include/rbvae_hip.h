@@ -413,6 +413,10 @@ size_t rbvae_groupnorm_ws_floats(int dtype, int N, int HW, int C, int groups);
 int rbvae_groupnorm_swish_ws(int dtype, const void* x, void* y, const float* gamma, const float* beta, float* stats_ws,
                              size_t ws_floats, int N, int HW, int C, int ldx, int ldy, int groups, float eps, int swish,
                              void* stream);
+/* the statistics alone (no normalised copy): mean = stats_ws[0 : N*groups], rstd = stats_ws[N*groups : 2*N*groups];
+ * rbvae_gn_affine turns them into the scale / shift rbvae_conv3x3_halo applies while it stages its input. */
+int rbvae_groupnorm_stats(int dtype, const void* x, float* stats_ws, size_t ws_floats, int N, int HW, int C, int ldx,
+                          int groups, float eps, void* stream);
 int rbvae_softmax_rows(int dtype, const void* x, void* y, long rows, int n, int ld, void* stream);
 /* AttnBlock.forward's q k^T * C^-0.5 -> softmax -> . v (ldm/modules/diffusionmodules/model.py:186-198) for N images
  * of hw tokens x C channels as ONE batched, tiled, online-softmax kernel: the hw x hw scores are never materialised.
@@ -425,6 +429,35 @@ int rbvae_attention(int dtype, const void* Q, const void* K, const void* V, void
 int rbvae_transpose2d(int dtype, const void* in, void* out, int R, int C, int ldi, int ldo, void* stream);
 int rbvae_posterior_sample(int dtype, const void* moments, int ld, const float* eps, float* latent, int N, int Z,
                            int HW, float scale, void* stream);
+
+/* ---- halo-resident 3x3 convolution, stride 1 (csrc/conv_halo.hip) ---------------------------------
+ * The ResnetBlock / conv_out convolutions of the LDM encoder (ldm/modules/diffusionmodules/model.py:82-141, 368-459:
+ * torch.nn.Conv2d(cin, cout, 3, 1, 1)) with the 18 x 18 input patch of a 16 x 16 pixel tile staged in LDS once per
+ * 128-byte channel slice and shared by all nine taps (rbvae_gather_gemm re-gathers it per tap).
+ *   Out[n][oh][ow][co] = bias[co] + addend + sum_{kh,kw,ci} f(A[n][oh+kh-pad_h][ow+kw-pad_w][ci]) * W[co][kh*3+kw][ci]
+ * A / Out / addend NHWC rows of the storage type, W packed [Nout][9][Kc] (rbvae_pack3), zero_page >= 128 zero bytes.
+ * f = identity, or with gn_scale / gn_shift ([Nimg][Kc] f32, from rbvae_gn_finish_tiles / rbvae_gn_affine) the
+ * producer's GroupNorm (+ swish when gn_swish) applied while the patch is staged: model.py:38-39 + :33-35 as called at
+ * :121-131 -- x -> swish(x * scale + shift); padding pixels stay zero (the reference pads AFTER the normalisation).
+ * stats_part (may be NULL; rbvae_conv3x3_halo_stats_floats floats): per pixel tile and group of stats_cg output channels
+ * the (mean, sum of squared deviations) of the STORED values (after bias / addend), which rbvae_gn_finish_tiles merges
+ * into the next GroupNorm's statistics -- the consumer's normalisation costs no pass over the activation.
+ * rbvae_conv3x3_halo_ok: 1 when the shape is covered (OW >= 16, OH >= 8, Kc % 64 (bf16) / 32 (f32) == 0, Nout % 128 == 0);
+ * other shapes run on rbvae_gather_gemm. */
+int rbvae_conv3x3_halo_ok(int dtype, int IH, int IW, int OH, int OW, int Kc, int Nout);
+int rbvae_conv3x3_halo(int dtype, const void* A, const void* W, void* Out, const float* bias, const void* addend,
+                       const void* zero_page, const float* gn_scale, const float* gn_shift, int gn_swish,
+                       float* stats_part, int stats_cg, int Nimg, int IH, int IW, int OH, int OW, int pad_h, int pad_w,
+                       int Kc, int Nout, int lda, int ldo, void* stream);
+size_t rbvae_conv3x3_halo_stats_floats(int Nimg, int OH, int OW, int Nout, int cg);
+/* GroupNorm(groups, eps, affine) statistics -> the per-(image, channel) scale / shift rbvae_conv3x3_halo applies
+ * (model.py:38-39): from the producing convolution's per-tile partials (gn_finish_tiles; mean_out / rstd_out [Nimg*groups]
+ * optional), or from the mean / rstd of rbvae_groupnorm_swish_ws's statistics kernels (gn_affine). */
+int rbvae_gn_finish_tiles(const float* stats_part, const float* gamma, const float* beta, float* scale, float* shift,
+                          float* mean_out, float* rstd_out, int Nimg, int OH, int OW, int C, int groups, float eps,
+                          void* stream);
+int rbvae_gn_affine(const float* mean, const float* rstd, const float* gamma, const float* beta, float* scale,
+                    float* shift, int N, int C, int groups, void* stream);
 
 #ifdef __cplusplus
 }

@@ -52,6 +52,7 @@ def _compile(src, extra=(), suffix=""):
 ISA_CHECKED = {
     "wgrad_gemm.hip": ("_ZN5rbvae12wgrad_gemm_k", ("ds_read_b64_tr_b16",)),
     "gather_gemm.hip": ("_ZN5rbvae13gather_gemm_k", ("ds_read_b128",)),
+    "conv_halo.hip": ("_ZN5rbvae11conv_halo_k", ("ds_read_b128",)),
 }
 
 

@@ -1,0 +1,622 @@
+// Halo-resident 3x3 convolution on the gfx950 matrix cores (stride 1): the LDM / Stable-Diffusion VAE encoder's
+// ResnetBlock convolutions (src/stable-diffusion/ldm/modules/diffusionmodules/model.py:82-141, conv_in/conv_out
+// :368-459) and any other NHWC 3x3 stride-1 convolution of the path.
+//
+//   Out[n][oh][ow][co] = epi( sum_{kh,kw,ci} f(A[n][oh+kh+dh0][ow+kw+dw0][ci]) * W[co][kh*3+kw][ci] )
+//
+// rbvae_gather_gemm re-gathers one pixel row per tap and K slice: a stride-1 tile takes its input in nine times
+// through the CU's L2 -> LDS path, which is what bounds that kernel.  Here a workgroup owns a 16 x 16 patch of output
+// pixels x 128 output channels; per 128-byte channel slice (64 bf16 / 32 f32 channels) the 18 x 18 input patch
+// (tile + halo) is staged into LDS ONCE and all nine taps read it, so per slice the workgroup takes in 41 KB of
+// input + 9 x 16 KB of weights for 256 x 128 x 576 MACs (200 FLOP per byte against 64 of the 128 x 128 gather tile).
+//
+// LDS images
+//   * input patch, chunk-major: [8 chunks of 16 B][336 slots], slot = patch_row * 18 + patch_col.  A tap (kh, kw)
+//     shifts every lane's slot by the same kh*18+kw, so a fragment read is base + tap offset: no per-lane gather, and
+//     16 consecutive slots of one chunk are 256 contiguous bytes = conflict-free ds_read_b128 at every shift (planes
+//     are multiples of 256 B; the (chunk>>1)*32 stagger keeps the transposing ds_write_b128 at a 2-way conflict).
+//     Filled through registers (coalesced 128-B pixel rows in, transposed on the way to LDS), double buffered; the
+//     register pass is also where the producer's GroupNorm + swish is applied (gn_scale / gn_shift: model.py:38-39,
+//     121-131), so a normalised copy of the activation never exists in HBM.
+//   * weight tap tiles [128 co][128 B], XOR-swizzled 16-B chunks, LDS-DMA ring (as gather_gemm.hip).
+// 8 waves as 4 (pixel rows) x 2 (channel halves), 64 x 64 per wave on v_mfma_f32_16x16x32_bf16 / 16x16x4_f32, weights
+// as the MFMA row operand so a lane owns 4 consecutive output channels of one pixel; the tile leaves through LDS as
+// whole 16-B chunks of NHWC rows (bias, residual addend), optionally with the tile's GroupNorm partial statistics
+// (per image and group: mean and sum of squared deviations) for the NEXT GroupNorm.
+#include "common.h"
+#include <stdlib.h>
+#include <type_traits>
+
+namespace rbvae {
+
+typedef __attribute__((ext_vector_type(8))) short bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
+
+struct ChArgs {
+    const unsigned char* A;        // [Nimg*IH*IW][lda] T
+    const unsigned char* W;        // [Nout][9][Kc] T
+    unsigned char* Out;            // [Nimg*OH*OW][ldo] T
+    const float* bias;             // [Nout] or null
+    const unsigned char* addend;   // [Nimg*OH*OW][ldo] T or null (residual)
+    const unsigned char* zero;     // >= 128 zero bytes
+    const float* gn_scale;         // [Nimg][Kc] or null: input -> swish?(x * scale + shift) while staging
+    const float* gn_shift;
+    float* stats;                  // null or [m tiles][Nout / cg] float2 (mean, M2) of the stored tile per group
+    int gn_swish, stats_cg;        // channels per group of the output statistics
+    int Nimg, IH, IW, OH, OW, dh0, dw0;
+    int Kc, Nout, lda, ldo;
+    int tiles_r, tiles_c, ntn, total;
+};
+
+__device__ __forceinline__ void ch_glds16(const void* g, void* lds) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                     (__attribute__((address_space(3))) void*)lds, 16, 0, 0);
+}
+
+template <typename T> struct ChMma;
+template <> struct ChMma<bf16_t> {
+    static __device__ __forceinline__ void run(f32x4_t& acc, const u32x4_t& rowop, const u32x4_t& colop) {
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8_t*)&rowop, *(const bf16x8_t*)&colop, acc, 0, 0, 0);
+    }
+};
+template <> struct ChMma<float> {
+    static __device__ __forceinline__ void run(f32x4_t& acc, const u32x4_t& rowop, const u32x4_t& colop) {
+        const f32x4_t r = *(const f32x4_t*)&rowop, c = *(const f32x4_t*)&colop;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(r[q], c[q], acc, 0, 0, 0);
+    }
+};
+
+constexpr int CH_BM = 256, CH_BN = 128, CH_T = 16;          // tile: 16 x 16 pixels x 128 channels
+constexpr int CH_PW = CH_T + 2, CH_NSLOT = CH_PW * CH_PW;    // 18 x 18 patch
+constexpr int CH_NSLOT_PAD = 336;                             // multiple of 16
+constexpr int CH_PLANE = CH_NSLOT_PAD * 16;                   // bytes per chunk plane
+constexpr int CH_KKOFF = 4 * CH_PLANE + 64;                   // chunk 4kk+fg = kk * KKOFF + fg part
+constexpr int CH_ABUF = 8 * CH_PLANE + 128;                   // 43136: one patch image (planes + staggers)
+constexpr int CH_BBYTES = CH_BN * 128;
+constexpr int CH_NA = 6;                                      // register-staged 16-B pieces per thread and slice
+
+__device__ __forceinline__ unsigned ch_plane_off(int chunk) { return (unsigned)(chunk * CH_PLANE + (chunk >> 1) * 32); }
+
+// bytes of the staging buffers / epilogue tile + statistics scratch (the tables follow)
+template <typename T, int RING> constexpr int ch_lds_main() {
+    constexpr int ES = sizeof(T);
+    constexpr int ring = 2 * CH_ABUF + RING * CH_BBYTES;
+    constexpr int epi = CH_BM * (CH_BN * ES + 16) + (512 / (CH_BN / (16 / ES))) * CH_BN * 4 + 512;
+    return ring > epi ? ring : epi;
+}
+
+// build-time ablation switches for timing-only builds (tools/ab_variants.sh; results are wrong with any bit set):
+// 1 no weight LDS-DMA in the loop, 2 no workgroup barrier in the loop, 4 no fragment reads in the loop, 8 no patch staging
+#ifndef CH_ABL
+#define CH_ABL 0
+#endif
+
+template <int N> __device__ __forceinline__ void ch_wait_barrier() {
+#if CH_ABL & 2
+    asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)" ::"n"(N) : "memory");
+#else
+    asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::"n"(N) : "memory");
+#endif
+}
+
+template <typename T, int RING>
+__global__ __launch_bounds__(512) void conv_halo_k(const ChArgs p) {
+    constexpr int ES = sizeof(T);
+    constexpr int KE = 128 / ES, EC = 16 / ES;
+    constexpr int MT = 4, NTW = 4;
+    constexpr int LOADS = 2;                                  // weight LDS-DMA instructions per wave and step
+    constexpr int PITCH = CH_BN * ES + 16;
+    constexpr int A_BYTES = 2 * CH_ABUF;
+    constexpr int CPR = CH_BN / EC;              // 16-B chunks per tile row
+    constexpr int RL = 512 / CPR;                // row lanes of the store phase
+    constexpr int ITERS = CH_BM / RL;
+    constexpr int RED_BYTES = RL * CH_BN * 4 + 512;      // statistics scratch behind the epilogue tile
+    constexpr int RINGB = ch_lds_main<T, RING>();
+    static_assert(CH_BM * PITCH + RED_BYTES <= RINGB && A_BYTES + RING * CH_BBYTES <= RINGB, "LDS carve");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    int* s_orow = (int*)(smem + RINGB);            // [256]
+    int* s_pix = s_orow + CH_BM;                   // [336]
+    float* s_gsc = (float*)(s_pix + CH_NSLOT_PAD); // [Kc] scale, then [Kc] shift (only with gn_scale)
+    float* s_gsh = s_gsc + p.Kc;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    // work item: the N tiles of one pixel tile run back to back on ONE XCD (they re-read the same patch from its L2), and
+    // an XCD walks a contiguous range of pixel tiles (neighbours share halo rows).  Bijective for any total.
+    int item;
+    {
+        const int lin = blockIdx.x, xcd = lin & 7, q = p.total >> 3, r = p.total & 7;
+        item = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (lin >> 3);
+    }
+    const int mtile = item / p.ntn, ntile = item - mtile * p.ntn;
+    const int per_img = p.tiles_r * p.tiles_c;
+    const int n = mtile / per_img, trc = mtile - n * per_img;
+    const int tr = trc / p.tiles_c, tc = trc - tr * p.tiles_c;
+    const int r0 = tr * CH_T, c0 = tc * CH_T, n0 = ntile * CH_BN;
+
+    // ---- tables
+    if (tid < CH_BM) {
+        const int oh = r0 + (tid >> 4), ow = c0 + (tid & 15);
+        s_orow[tid] = (oh < p.OH && ow < p.OW) ? (n * p.OH + oh) * p.OW + ow : -1;
+    }
+    if (tid < CH_NSLOT_PAD) {
+        int v = -1;
+        if (tid < CH_NSLOT) {
+            const int pr = tid / CH_PW, pc = tid - pr * CH_PW;
+            const int ih = r0 + pr + p.dh0, iw = c0 + pc + p.dw0;
+            if (ih >= 0 && ih < p.IH && iw >= 0 && iw < p.IW) v = (n * p.IH + ih) * p.IW + iw;
+        }
+        s_pix[tid] = v;
+    }
+    if (p.gn_scale) {
+        for (int i = tid; i < p.Kc; i += 512) {
+            s_gsc[i] = p.gn_scale[(size_t)n * p.Kc + i];
+            s_gsh[i] = p.gn_shift[(size_t)n * p.Kc + i];
+        }
+    }
+    __syncthreads();
+
+    // ---- input staging roles: piece i of this thread = (slot (tid>>3) + 64 i, chunk tid&7): 8 lanes read one pixel's
+    // 128-byte slice (coalesced), and write it to 8 chunk planes
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
+    const int chunk = tid & 7;
+    int pix[CH_NA];
+    unsigned adst[CH_NA];
+#pragma unroll
+    for (int i = 0; i < CH_NA; ++i) {
+        const int slot = (tid >> 3) + 64 * i;
+        pix[i] = slot < CH_NSLOT_PAD ? s_pix[slot] : -2;     // -1: zero (padding), -2: no such slot
+        adst[i] = ch_plane_off(chunk) + (unsigned)slot * 16;
+    }
+    const unsigned char* zsrc = p.zero + chunk * 16;
+    u32x4_t areg[CH_NA];
+    auto a_load = [&](int kc) {
+#pragma unroll
+        for (int i = 0; i < CH_NA; ++i) {
+            const unsigned char* src = pix[i] >= 0 ? p.A + ((size_t)pix[i] * p.lda) * ES + (size_t)kc * 128 + chunk * 16 : zsrc;
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(areg[i]) : "v"(src) : "memory");
+        }
+    };
+    // wait until at most YOUNGER vector-memory operations are outstanding: the six staged pieces have landed
+    auto a_landed = [](auto younger_tag, u32x4_t (&ar)[CH_NA]) {
+        constexpr int YOUNGER = decltype(younger_tag)::value;
+        asm volatile("s_waitcnt vmcnt(%6)"
+                     : "+v"(ar[0]), "+v"(ar[1]), "+v"(ar[2]), "+v"(ar[3]), "+v"(ar[4]), "+v"(ar[5])
+                     : "n"(YOUNGER));
+    };
+    auto a_write = [&](int kc, int buf) {
+        if (p.gn_scale) {
+            float sc[EC], sh[EC];
+            const int cb = kc * KE + chunk * EC;
+#pragma unroll
+            for (int e = 0; e < EC; ++e) { sc[e] = s_gsc[cb + e]; sh[e] = s_gsh[cb + e]; }
+#pragma unroll
+            for (int i = 0; i < CH_NA; ++i) {
+                if (pix[i] >= 0) {
+                    T* ev = (T*)&areg[i];
+#pragma unroll
+                    for (int e = 0; e < EC; ++e) {
+                        float v = fmaf(Elem<T>::load(ev + e), sc[e], sh[e]);
+                        if (p.gn_swish) {
+                            if constexpr (ES == 2) v = v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504f * v));
+                            else v = v * sigmoidf_(v);
+                        }
+                        Elem<T>::store(ev + e, v);
+                    }
+                }
+            }
+        }
+        // (asm: a compiler-issued LDS store would first drain the weight tiles' LDS-DMA -- it cannot tell them apart)
+        const unsigned lbase = lds0 + (unsigned)buf * CH_ABUF;
+#pragma unroll
+        for (int i = 0; i < CH_NA; ++i)
+            if (pix[i] >= -1) asm volatile("ds_write_b128 %0, %1" ::"v"(lbase + adst[i]), "v"(areg[i]) : "memory");
+    };
+
+    // ---- weight staging roles (LDS-DMA): instruction i of wave w moves rows (w*2+i)*8 .. +7 of the tap tile
+    const int srow = lane >> 3, schunk = lane & 7;
+    const unsigned char* bptr[LOADS];
+#pragma unroll
+    for (int i = 0; i < LOADS; ++i) {
+        const int r = (w * LOADS + i) * 8 + srow;
+        bptr[i] = p.W + ((size_t)(n0 + r) * 9 * p.Kc) * ES + (schunk ^ ((r >> 1) & 7)) * 16;
+    }
+    const int nkc = p.Kc / KE;
+    const int nsteps = nkc * 9;
+    int pstep = 0, pkc = 0, pj = 0, pbuf = 0;          // producer: next (slice, tap) to stage
+    auto b_issue = [&]() {
+        const size_t off = ((size_t)pj * p.Kc) * ES + (size_t)pkc * 128;
+        unsigned char* lb = smem + A_BYTES + pbuf * CH_BBYTES + (w * LOADS) * 1024;
+#pragma unroll
+        for (int i = 0; i < LOADS; ++i) ch_glds16(bptr[i] + off, lb + i * 1024);
+        ++pstep;
+        if (++pj == 9) { pj = 0; ++pkc; }
+        pbuf = (pbuf + 1 == RING) ? 0 : pbuf + 1;
+    };
+
+    // ---- fragment addresses
+    const int fi = lane & 15, fg = lane >> 4;
+    const int wr = w >> 1, wc = w & 1;
+    unsigned abase[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+        abase[mt] = lds0 + (unsigned)fg * CH_PLANE + (unsigned)(fg >> 1) * 32 + (unsigned)((wr * MT + mt) * CH_PW + fi) * 16;
+    const int fsw = (fi >> 1) & 7;
+    unsigned offB[2];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) offB[kk] = lds0 + A_BYTES + (unsigned)(wc * NTW * 16 + fi) * 128 + (unsigned)(((4 * kk + fg) ^ fsw) * 16);
+
+    f32x4_t acc[MT][NTW];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt) acc[mt][nt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    // One 32-k half of a step: MT + NTW fragment reads (inline asm, counted waits: see gather_gemm.hip) and MT x NTW MFMAs
+    unsigned ta[MT];                         // this step's patch read addresses (buffer + tap shift folded in)
+    bool first_reads = true;
+    auto read_half = [&](unsigned bslot, auto kk_tag, u32x4_t (&fa)[MT], u32x4_t (&fb)[NTW]) {
+        constexpr int kk = decltype(kk_tag)::value;
+#if CH_ABL & 4
+        if (!first_reads) return;
+#endif
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fa[mt]) : "v"(ta[mt]), "n"(kk * CH_KKOFF));
+        const unsigned ab_ = offB[kk] + bslot;
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt)
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fb[nt]) : "v"(ab_), "n"(nt * 2048));
+    };
+    auto landed = [&](auto younger_tag, u32x4_t (&fa)[MT], u32x4_t (&fb)[NTW]) {
+        constexpr int YOUNGER = decltype(younger_tag)::value;
+        asm volatile("s_waitcnt lgkmcnt(%8)"
+                     : "+v"(fa[0]), "+v"(fa[1]), "+v"(fa[2]), "+v"(fa[3]), "+v"(fb[0]), "+v"(fb[1]), "+v"(fb[2]), "+v"(fb[3])
+                     : "n"(YOUNGER));
+    };
+    auto mma_half = [&](const u32x4_t (&fa)[MT], const u32x4_t (&fb)[NTW]) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NTW; ++nt) ChMma<T>::run(acc[mt][nt], fb[nt], fa[mt]);
+    };
+    using K0 = std::integral_constant<int, 0>;
+    using K1 = std::integral_constant<int, 1>;
+    using Younger = std::integral_constant<int, MT + NTW>;
+    using None = std::integral_constant<int, 0>;
+    // consumer state: step s = (slice ckc, tap cj); ring slot cslot
+    int ckc = 0, cj = 0, cslot = 0;
+    auto set_tap = [&]() {
+        const unsigned sh = (unsigned)((ckc & 1) * CH_ABUF) + (unsigned)((cj / 3) * CH_PW + (cj % 3)) * 16;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) ta[mt] = abase[mt] + sh;
+    };
+    // after the barrier of step (ckc, cj): stage the weights RING-1 steps ahead; the next slice's patch goes to registers
+    // at tap 0 and into the other patch buffer at tap 8 (its last reader finished a slice ago; the barrier of the next
+    // step publishes it)
+    auto post_barrier = [&]() {
+#if CH_ABL & 1
+        if (pstep < nsteps) { ++pstep; if (++pj == 9) { pj = 0; ++pkc; } pbuf = (pbuf + 1 == RING) ? 0 : pbuf + 1; }
+#else
+        if (pstep < nsteps) b_issue();
+#endif
+#if CH_ABL & 8
+        return;
+#endif
+        if (cj == 0 && ckc + 1 < nkc) a_load(ckc + 1);
+        if (cj == 8 && ckc + 1 < nkc) {
+            a_landed(std::integral_constant<int, 8 * LOADS>{}, areg);
+            __builtin_amdgcn_sched_barrier(0);
+            a_write(ckc + 1, (ckc + 1) & 1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    // before the barrier of the step after (ckc, cj) = step s+1: its weight tile has landed.  Younger operations that may
+    // stay in flight: the RING-2 tiles behind it, and the patch loads when they were issued after it (taps 1..RING-1)
+    auto pre_barrier = [&](int s_next) {
+        const bool tail = nsteps - s_next - 1 < RING - 2;            // fewer tiles behind it than the ring holds
+        const int nj = cj + 1 == 9 ? 0 : cj + 1;
+        const bool patch = nj >= 1 && nj <= RING - 1 && ckc + 1 < nkc;
+        if (tail) ch_wait_barrier<0>();
+        else if (patch) ch_wait_barrier<(RING - 2) * LOADS + CH_NA>();
+        else ch_wait_barrier<(RING - 2) * LOADS>();
+    };
+
+    // ---- prologue: patch of slice 0, the first RING-1 weight tiles
+    a_load(0);
+#pragma unroll
+    for (int i = 0; i < RING - 1; ++i)
+        if (pstep < nsteps) b_issue();
+    a_landed(std::integral_constant<int, 0>{}, areg);
+    a_write(0, 0);
+    ch_wait_barrier<0>();
+    post_barrier();                    // stages step RING-1; loads the patch of slice 1
+    u32x4_t fa0[MT], fb0[NTW], fa1[MT], fb1[NTW];
+    set_tap();
+    read_half(0u, K0{}, fa0, fb0);
+    for (int s = 0; s + 1 < nsteps; ++s) {
+        const unsigned bcur = (unsigned)cslot * CH_BBYTES;
+        read_half(bcur, K1{}, fa1, fb1);
+        first_reads = false;
+        landed(Younger{}, fa0, fb0);
+        __builtin_amdgcn_sched_barrier(0);
+        mma_half(fa0, fb0);
+        __builtin_amdgcn_sched_barrier(0);
+        landed(None{}, fa1, fb1);
+        pre_barrier(s + 1);
+        if (++cj == 9) { cj = 0; ++ckc; }
+        cslot = (cslot + 1 == RING) ? 0 : cslot + 1;
+        post_barrier();
+        set_tap();
+        read_half((unsigned)cslot * CH_BBYTES, K0{}, fa0, fb0);
+        __builtin_amdgcn_sched_barrier(0);
+        mma_half(fa1, fb1);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    {
+        read_half((unsigned)cslot * CH_BBYTES, K1{}, fa1, fb1);
+        landed(Younger{}, fa0, fb0);
+        __builtin_amdgcn_sched_barrier(0);
+        mma_half(fa0, fb0);
+        __builtin_amdgcn_sched_barrier(0);
+        landed(None{}, fa1, fb1);
+        __builtin_amdgcn_sched_barrier(0);
+        mma_half(fa1, fb1);
+    }
+    __syncthreads();
+
+    // ---- epilogue, register phase: bias; lane owns pixel fi, channels 4*fg..+3 of each 16 x 16 tile
+    unsigned char* tile = smem;
+#pragma unroll
+    for (int nt = 0; nt < NTW; ++nt) {
+        const int cb = (wc * NTW + nt) * 16 + 4 * fg;
+        float bz[4] = {0.f, 0.f, 0.f, 0.f};
+        if (p.bias) {
+            const float4 b4 = *(const float4*)(p.bias + n0 + cb);
+            bz[0] = b4.x; bz[1] = b4.y; bz[2] = b4.z; bz[3] = b4.w;
+        }
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int row = (wr * MT + mt) * 16 + fi;
+            unsigned char* dst = tile + row * PITCH + cb * ES;
+            if constexpr (ES == 4) {
+                *(float4*)dst = make_float4(acc[mt][nt][0] + bz[0], acc[mt][nt][1] + bz[1], acc[mt][nt][2] + bz[2],
+                                            acc[mt][nt][3] + bz[3]);
+            } else {
+                uint2 pk;
+                pk.x = (unsigned)f32_to_bf16(acc[mt][nt][0] + bz[0]) | ((unsigned)f32_to_bf16(acc[mt][nt][1] + bz[1]) << 16);
+                pk.y = (unsigned)f32_to_bf16(acc[mt][nt][2] + bz[2]) | ((unsigned)f32_to_bf16(acc[mt][nt][3] + bz[3]) << 16);
+                *(uint2*)dst = pk;
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- store phase: whole 16-B chunks of NHWC rows (+ residual); the stored values stay in the LDS tile for the statistics
+    const int sch = tid % CPR, rl = tid / CPR;
+    const int scol = n0 + sch * EC;
+    float csum[EC];
+#pragma unroll
+    for (int e = 0; e < EC; ++e) csum[e] = 0.f;
+#pragma unroll
+    for (int it = 0; it < ITERS; ++it) {
+        const int row = it * RL + rl;
+        const int orow = s_orow[row];
+        if (orow >= 0) {
+            u32x4_t val = *(const u32x4_t*)(tile + row * PITCH + sch * 16);
+            T* ev = (T*)&val;
+            if (p.addend) {
+                const u32x4_t a4 = *(const u32x4_t*)(p.addend + ((size_t)orow * p.ldo + scol) * ES);
+                const T* ae = (const T*)&a4;
+#pragma unroll
+                for (int e = 0; e < EC; ++e) Elem<T>::store(ev + e, Elem<T>::load(ev + e) + Elem<T>::load(ae + e));
+                if (p.stats) *(u32x4_t*)(tile + row * PITCH + sch * 16) = val;
+            }
+            *(u32x4_t*)(p.Out + ((size_t)orow * p.ldo + scol) * ES) = val;
+            if (p.stats) {
+#pragma unroll
+                for (int e = 0; e < EC; ++e) csum[e] += Elem<T>::load(ev + e);
+            }
+        }
+    }
+    if (p.stats) {
+        // GroupNorm partial statistics of the stored tile: per group (cg consecutive channels) the tile's mean and the
+        // sum of squared deviations from it (two passes over the LDS tile: as stable as torch's), merged across tiles
+        // by gn_finish_tiles_k with the parallel-variance formula.  Pass 1: channel sums -> group means.
+        __syncthreads();
+        float* red = (float*)(smem + CH_BM * PITCH);      // [RL][BN] channel sums, then [BN / cg] group means
+        const int cg = p.stats_cg, ng = CH_BN / cg;
+#pragma unroll
+        for (int e = 0; e < EC; ++e) red[rl * CH_BN + sch * EC + e] = csum[e];
+        // number of valid pixels of the tile (the same for every channel)
+        const int vr = min(CH_T, p.OH - r0), vc = min(CH_T, p.OW - c0);
+        const float cnt = (float)(vr * vc) * (float)cg;
+        __syncthreads();
+        float* gmean = red + RL * CH_BN;
+        if (tid < CH_BN) {
+            float t = 0.f;
+            for (int k = 0; k < RL; ++k) t += red[k * CH_BN + tid];
+            red[tid] = t;                                  // row 0 := channel totals (each thread its own column)
+        }
+        __syncthreads();
+        if (tid < ng) {
+            float t = 0.f;
+            for (int c = 0; c < cg; ++c) t += red[tid * cg + c];
+            gmean[tid] = t / cnt;
+        }
+        __syncthreads();
+        // pass 2: squared deviations from the group mean
+#pragma unroll
+        for (int e = 0; e < EC; ++e) csum[e] = 0.f;
+        float gm[EC];
+#pragma unroll
+        for (int e = 0; e < EC; ++e) gm[e] = gmean[(sch * EC + e) / cg];
+#pragma unroll
+        for (int it = 0; it < ITERS; ++it) {
+            const int row = it * RL + rl;
+            if (s_orow[row] >= 0) {
+                const u32x4_t val = *(const u32x4_t*)(tile + row * PITCH + sch * 16);
+                const T* ev = (const T*)&val;
+#pragma unroll
+                for (int e = 0; e < EC; ++e) { const float d = Elem<T>::load(ev + e) - gm[e]; csum[e] += d * d; }
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < EC; ++e) red[rl * CH_BN + sch * EC + e] = csum[e];
+        __syncthreads();
+        if (tid < CH_BN) {
+            float t = 0.f;
+            for (int k = 0; k < RL; ++k) t += red[k * CH_BN + tid];
+            red[tid] = t;                                  // its own column only
+        }
+        __syncthreads();
+        if (tid < ng) {
+            float t = 0.f;
+            for (int c = 0; c < cg; ++c) t += red[tid * cg + c];
+            const int G = p.Nout / cg;
+            ((float2*)p.stats)[(size_t)mtile * G + n0 / cg + tid] = make_float2(gmean[tid], t);
+        }
+    }
+}
+
+// Merge the per-tile (mean, M2) of rbvae_conv3x3_halo into per-(image, group) mean / rstd, and expand them with the
+// affine parameters into the per-(image, channel) scale / shift the consuming convolution applies while it stages its
+// input: y = x * scale + shift = (x - mean) * rstd * gamma + beta  (model.py:38-39).
+__global__ __launch_bounds__(64) void gn_finish_tiles_k(const float2* __restrict__ part, int tiles_r, int tiles_c, int OH,
+                                                        int OW, int cg, int G, float eps, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, float* __restrict__ scale,
+                                                        float* __restrict__ shift, float* __restrict__ mean_out,
+                                                        float* __restrict__ rstd_out) {
+    const int n = blockIdx.x / G, g = blockIdx.x - n * G;
+    const int nb = tiles_r * tiles_c;
+    const float2* pp = part + (size_t)n * nb * G + g;
+    auto count = [&](int b) {
+        const int tr = b / tiles_c, tc = b - tr * tiles_c;
+        return (float)(min(CH_T, OH - tr * CH_T) * min(CH_T, OW - tc * CH_T) * cg);
+    };
+    const float total = (float)OH * (float)OW * (float)cg;
+    float a = 0.f;
+    for (int b = threadIdx.x; b < nb; b += 64) a += count(b) * pp[(size_t)b * G].x;
+    const float m = wave_sum(a) / total;
+    float q = 0.f;
+    for (int b = threadIdx.x; b < nb; b += 64) {
+        const float2 pb = pp[(size_t)b * G];
+        const float d = pb.x - m;
+        q += pb.y + count(b) * d * d;
+    }
+    const float var = wave_sum(q) / total;
+    const float rs = rsqrtf(var + eps);
+    if (threadIdx.x == 0 && mean_out) { mean_out[blockIdx.x] = m; rstd_out[blockIdx.x] = rs; }
+    if ((int)threadIdx.x < cg) {
+        const int c = g * cg + threadIdx.x, C = G * cg;
+        const float sc = rs * gamma[c];
+        scale[(size_t)n * C + c] = sc;
+        shift[(size_t)n * C + c] = beta[c] - m * sc;
+    }
+}
+
+// scale / shift from existing mean / rstd (statistics from rbvae_groupnorm_swish_ws's kernels)
+__global__ void gn_affine_k(const float* __restrict__ mean, const float* __restrict__ rstd, const float* __restrict__ gamma,
+                            const float* __restrict__ beta, float* __restrict__ scale, float* __restrict__ shift, int N,
+                            int C, int groups) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N * C) return;
+    const int n = i / C, c = i - n * C, sg = n * groups + c / (C / groups);
+    const float sc = rstd[sg] * gamma[c];
+    scale[i] = sc;
+    shift[i] = beta[c] - mean[sg] * sc;
+}
+
+template <typename T, int RING>
+static int launch_ch(const ChArgs& a, hipStream_t st) {
+    constexpr int ES = sizeof(T);
+    const size_t lds = (size_t)ch_lds_main<T, RING>() + CH_BM * 4 + CH_NSLOT_PAD * 4 + (a.gn_scale ? (size_t)2 * a.Kc * 4 : 0) + 16;
+    if (lds > 160 * 1024) return fail(RBVAE_E_UNSUPPORTED, "conv3x3_halo: %zu bytes of LDS", lds);
+    (void)ES;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute((const void*)conv_halo_k<T, RING>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((conv_halo_k<T, RING>), dim3(a.total), dim3(512), lds, st, a);
+    RBVAE_CHECK_LAUNCH("conv3x3_halo");
+    return RBVAE_OK;
+}
+
+}  // namespace rbvae
+
+using namespace rbvae;
+
+extern "C" int rbvae_conv3x3_halo_ok(int dtype, int IH, int IW, int OH, int OW, int Kc, int Nout) {
+    const int KE = dtype == RBVAE_F32 ? 32 : 64;
+    if (dtype != RBVAE_F32 && dtype != RBVAE_BF16) return 0;
+    if (Kc <= 0 || Kc % KE || Nout <= 0 || Nout % CH_BN) return 0;
+    if (Kc > 1024) return 0;                         // scale / shift table in LDS
+    if (OH < 8 || OW < CH_T || IH < 1 || IW < 1) return 0;   // narrower images: rbvae_gather_gemm
+    return 1;
+}
+
+extern "C" int rbvae_conv3x3_halo(int dtype, const void* A, const void* W, void* Out, const float* bias, const void* addend,
+                                  const void* zero_page, const float* gn_scale, const float* gn_shift, int gn_swish,
+                                  float* stats_part, int stats_cg, int Nimg, int IH, int IW, int OH, int OW, int pad_h,
+                                  int pad_w, int Kc, int Nout, int lda, int ldo, void* stream) {
+    RBVAE_CHECK_ARG(A && W && Out && zero_page, "conv3x3_halo: null pointer");
+    RBVAE_CHECK_ARG(rbvae_conv3x3_halo_ok(dtype, IH, IW, OH, OW, Kc, Nout),
+                    "conv3x3_halo: shape not covered (dtype %d, %dx%d -> %dx%d, Kc %d, Nout %d)", dtype, IH, IW, OH, OW, Kc, Nout);
+    const int ES = dtype == RBVAE_F32 ? 4 : 2;
+    RBVAE_CHECK_ARG(lda >= Kc && (lda * ES) % 16 == 0 && ldo >= Nout && (ldo * ES) % 16 == 0,
+                    "conv3x3_halo: leading dimensions lda=%d ldo=%d", lda, ldo);
+    RBVAE_CHECK_ARG(Nimg > 0 && (long)Nimg * IH * IW < (1l << 30) && (long)Nimg * OH * OW < (1l << 30),
+                    "conv3x3_halo: more than 2^30 pixel rows");
+    RBVAE_CHECK_ARG(((uintptr_t)A | (uintptr_t)W | (uintptr_t)Out | (uintptr_t)zero_page | (uintptr_t)addend | (uintptr_t)bias) % 16 == 0,
+                    "conv3x3_halo: pointers must be 16-byte aligned");
+    RBVAE_CHECK_ARG((gn_scale == nullptr) == (gn_shift == nullptr), "conv3x3_halo: gn_scale and gn_shift go together");
+    RBVAE_CHECK_ARG(!stats_part || (stats_cg > 0 && CH_BN % stats_cg == 0 && Nout % stats_cg == 0),
+                    "conv3x3_halo: stats_cg=%d must divide %d", stats_cg, CH_BN);
+    RBVAE_CHECK_ARG(pad_h >= 0 && pad_h <= 2 && pad_w >= 0 && pad_w <= 2, "conv3x3_halo: pad %d %d", pad_h, pad_w);
+    ChArgs a;
+    a.A = (const unsigned char*)A; a.W = (const unsigned char*)W; a.Out = (unsigned char*)Out; a.bias = bias;
+    a.addend = (const unsigned char*)addend; a.zero = (const unsigned char*)zero_page;
+    a.gn_scale = gn_scale; a.gn_shift = gn_shift; a.gn_swish = gn_swish; a.stats = stats_part; a.stats_cg = stats_cg;
+    a.Nimg = Nimg; a.IH = IH; a.IW = IW; a.OH = OH; a.OW = OW; a.dh0 = -pad_h; a.dw0 = -pad_w;
+    a.Kc = Kc; a.Nout = Nout; a.lda = lda; a.ldo = ldo;
+    a.tiles_r = cdiv(OH, CH_T); a.tiles_c = cdiv(OW, CH_T); a.ntn = Nout / CH_BN;
+    const long total = (long)Nimg * a.tiles_r * a.tiles_c * a.ntn;
+    RBVAE_CHECK_ARG(total < (1l << 30), "conv3x3_halo: too many tiles");
+    a.total = (int)total;
+    hipStream_t st = (hipStream_t)stream;
+    static const int ring = getenv("RBVAE_CH_RING") ? atoi(getenv("RBVAE_CH_RING")) : 3;
+    if (dtype == RBVAE_F32) return launch_ch<float, 3>(a, st);
+    return ring == 4 ? launch_ch<bf16_t, 4>(a, st) : launch_ch<bf16_t, 3>(a, st);
+}
+
+extern "C" size_t rbvae_conv3x3_halo_stats_floats(int Nimg, int OH, int OW, int Nout, int cg) {
+    return (size_t)2 * Nimg * cdiv(OH, CH_T) * cdiv(OW, CH_T) * (Nout / cg);
+}
+
+extern "C" int rbvae_gn_finish_tiles(const float* stats_part, const float* gamma, const float* beta, float* scale,
+                                     float* shift, float* mean_out, float* rstd_out, int Nimg, int OH, int OW, int C,
+                                     int groups, float eps, void* stream) {
+    RBVAE_CHECK_ARG(stats_part && gamma && beta && scale && shift, "gn_finish_tiles: null pointer");
+    RBVAE_CHECK_ARG(groups > 0 && C % groups == 0 && C / groups <= 64, "gn_finish_tiles: C=%d groups=%d", C, groups);
+    RBVAE_CHECK_ARG((mean_out == nullptr) == (rstd_out == nullptr), "gn_finish_tiles: mean_out and rstd_out go together");
+    hipLaunchKernelGGL(gn_finish_tiles_k, dim3(Nimg * groups), dim3(64), 0, (hipStream_t)stream, (const float2*)stats_part,
+                       cdiv(OH, CH_T), cdiv(OW, CH_T), OH, OW, C / groups, groups, eps, gamma, beta, scale, shift, mean_out,
+                       rstd_out);
+    RBVAE_CHECK_LAUNCH("gn_finish_tiles");
+    return RBVAE_OK;
+}
+
+extern "C" int rbvae_gn_affine(const float* mean, const float* rstd, const float* gamma, const float* beta, float* scale,
+                               float* shift, int N, int C, int groups, void* stream) {
+    RBVAE_CHECK_ARG(mean && rstd && gamma && beta && scale && shift && N > 0 && C > 0 && groups > 0 && C % groups == 0,
+                    "gn_affine: bad arguments");
+    hipLaunchKernelGGL(gn_affine_k, dim3(cdiv((long)N * C, 256)), dim3(256), 0, (hipStream_t)stream, mean, rstd, gamma, beta,
+                       scale, shift, N, C, groups);
+    RBVAE_CHECK_LAUNCH("gn_affine");
+    return RBVAE_OK;
+}

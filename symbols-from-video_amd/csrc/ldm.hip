@@ -358,6 +358,40 @@ int rbvae_groupnorm_swish_ws(int dtype, const void* x, void* y, const float* gam
     return RBVAE_OK;
 }
 
+/* statistics only: mean = stats_ws[0 : N*groups], rstd = stats_ws[N*groups : 2*N*groups] (for rbvae_gn_affine) */
+int rbvae_groupnorm_stats(int dtype, const void* x, float* stats_ws, size_t ws_floats, int N, int HW, int C, int ldx,
+                          int groups, float eps, void* stream) {
+    RBVAE_CHECK_ARG(x && stats_ws && N > 0 && HW > 0 && C > 0, "groupnorm_stats: bad arguments");
+    RBVAE_CHECK_ARG(groups > 0 && C % groups == 0 && ldx >= C, "groupnorm_stats: C=%d groups=%d", C, groups);
+    RBVAE_CHECK_ARG(ws_floats >= (size_t)2 * N * groups, "groupnorm_stats: workspace of %zu floats < %zu", ws_floats,
+                    (size_t)2 * N * groups);
+    hipStream_t st = (hipStream_t)stream;
+    float* mean = stats_ws;
+    float* rstd = stats_ws + (size_t)N * groups;
+    const bool tiled = gn_tiled_ok(dtype, C, ldx, ldx, groups) && ws_floats >= rbvae_groupnorm_ws_floats(dtype, N, HW, C, groups) &&
+                       (uintptr_t)x % 16 == 0;
+    if (tiled) {
+        const int rb = gn_rows_per_block(dtype, C), nb = cdiv(HW, rb);
+        float* pbase = stats_ws + (size_t)2 * N * groups;
+        float2* part = (float2*)(pbase + (((uintptr_t)pbase % 8) ? 1 : 0));
+        const dim3 pgrid(nb, N);
+        DISPATCH_T(dtype,
+                   hipLaunchKernelGGL(gn_partial_k<float>, pgrid, dim3(256), 0, st, (const float*)x, HW, C, ldx, groups, part),
+                   hipLaunchKernelGGL(gn_partial_k<bf16_t>, pgrid, dim3(256), 0, st, (const bf16_t*)x, HW, C, ldx, groups, part),
+                   "groupnorm_stats")
+        hipLaunchKernelGGL(gn_finish_k, dim3(N * groups), dim3(64), 0, st, part, nb, rb, HW, C / groups, groups, eps, mean, rstd);
+    } else {
+        DISPATCH_T(dtype,
+                   hipLaunchKernelGGL(gn_stats_k<float>, dim3(N * groups), dim3(256), 0, st, (const float*)x, HW, C, ldx,
+                                      groups, eps, mean, rstd),
+                   hipLaunchKernelGGL(gn_stats_k<bf16_t>, dim3(N * groups), dim3(256), 0, st, (const bf16_t*)x, HW, C, ldx,
+                                      groups, eps, mean, rstd),
+                   "groupnorm_stats")
+    }
+    RBVAE_CHECK_LAUNCH("groupnorm_stats");
+    return RBVAE_OK;
+}
+
 int rbvae_softmax_rows(int dtype, const void* x, void* y, long rows, int n, int ld, void* stream) {
     RBVAE_CHECK_ARG(x && y && rows > 0 && n > 0 && ld >= n, "softmax_rows: bad arguments");
     hipStream_t st = (hipStream_t)stream;

@@ -8,9 +8,13 @@ cfg 5 runs on the fly:
   AutoencoderKL.encode       src/stable-diffusion/ldm/models/autoencoder.py:324-328
   posterior sample x 0.18215 ldm/modules/distributions/distributions.py:24-37, ldm/models/diffusion/ddpm.py:542-549
 
-Every 3x3 / 1x1 convolution and both attention products run on rbvae_gather_gemm (stride-1 and
-asymmetric-pad stride-2 tap tables; skip connections through the epilogue's `addend`); GroupNorm+swish,
-the attention softmax and the posterior sample are the kernels of csrc/ldm.hip.  state_dict keys are
+The ResnetBlock convolutions (3x3, stride 1) run on rbvae_conv3x3_halo (csrc/conv_halo.hip): the input patch of a
+16 x 16 pixel tile is staged in LDS once per channel slice and shared by the nine taps, the producer's GroupNorm + swish
+is applied while the patch is staged, and the statistics of the NEXT GroupNorm come out of the epilogue -- the
+GN -> swish -> conv chain of model.py:121-131 is two launches per block plus a 2 KB statistics merge, and no normalised
+copy of an activation is written.  The 1x1 / stride-2 / 3- and 8-channel convolutions and the images narrower than a
+tile run on rbvae_gather_gemm (stride-1 and asymmetric-pad stride-2 tap tables; skip connections through the
+epilogue's `addend`) with the GroupNorm kernels of csrc/ldm.hip; attention is csrc/attn.hip.  state_dict keys are
 the reference's (`encoder.*`, `quant_conv.*`), so a Stable-Diffusion `first_stage_model.*` checkpoint
 loads as is; without one the weights are torch's default initialisation (the pretrained weights are not
 available offline).
@@ -63,10 +67,13 @@ def _conv_desc(k, off):
 
 
 class LDMEncoder(nn.Module):
-    def __init__(self, compute_dtype: str = "bf16", cfg: Optional[dict] = None):
+    def __init__(self, compute_dtype: str = "bf16", cfg: Optional[dict] = None, conv_impl: str = "halo"):
         super().__init__()
         if compute_dtype not in ("f32", "bf16"):
             raise ValueError("compute_dtype must be 'f32' or 'bf16'")
+        if conv_impl not in ("halo", "gather"):
+            raise ValueError("conv_impl must be 'halo' (halo-resident 3x3 kernel + fused GroupNorm) or 'gather'")
+        self.conv_impl = conv_impl
         self.cfg = dict(DDCONFIG if cfg is None else cfg)
         self.compute_dtype = compute_dtype
         self.plan = _plan(self.cfg)
@@ -197,12 +204,55 @@ class LDMEncoder(nn.Module):
                x.shape[1], y.shape[1], 32, 1e-6, int(swish))
         return y
 
-    def _res(self, prefix, x, N, H, W, cin, cout):
+    def _scale_shift(self, name, x, xst, N, H, W, C):
+        """GroupNorm `name` of x as per-(image, channel) scale / shift (model.py:38-39): statistics from the producing
+        convolution's per-tile partials xst when there are any, else from the statistics kernels."""
+        dev = x.device
+        gamma, beta = self._p(f"{name}.weight"), self._p(f"{name}.bias")
+        sc = torch.empty(N, C, dtype=torch.float32, device=dev)
+        sh = torch.empty(N, C, dtype=torch.float32, device=dev)
+        if xst is not None:
+            L.call("rbvae_gn_finish_tiles", xst, gamma, beta, sc, sh, None, None, N, H, W, C, 32, 1e-6)
+        else:
+            dt = self._packed[1]
+            nws = L.query("rbvae_groupnorm_ws_floats", dt, N, H * W, C, 32)
+            ws = torch.empty(nws, dtype=torch.float32, device=dev)
+            L.call("rbvae_groupnorm_stats", dt, x, ws, nws, N, H * W, C, x.shape[1], 32, 1e-6)
+            L.call("rbvae_gn_affine", ws, ws[N * 32:], gamma, beta, sc, sh, N, C, 32)
+        return sc, sh
+
+    def _conv3_halo(self, name, x, N, H, W, cin, cout, sc, sh, addend=None):
+        """conv(swish(x * sc + sh)) + bias (+ addend) and the per-tile GroupNorm(32) partial statistics of the result"""
+        dt, tdt, pk = self._packed[1], self._packed[2], self._packed[4]
+        out = torch.empty(N * H * W, cout, dtype=tdt, device=x.device)
+        st = torch.empty(L.query("rbvae_conv3x3_halo_stats_floats", N, H, W, cout, cout // 32), dtype=torch.float32,
+                         device=x.device)
+        L.call("rbvae_conv3x3_halo", dt, x, pk[f"{name}.weight"], out, self._p(f"{name}.bias"), addend, self._zero, sc, sh, 1,
+               st, cout // 32, N, H, W, H, W, 1, 1, cin, cout, x.shape[1], cout)
+        return out, st
+
+    def _halo_ok(self, N, H, W, cin, cout):
+        dt = self._packed[1]
+        # a launch needs enough 256 x 128 tiles to fill the chip; smaller problems keep the 128-row gather tiles
+        tiles = N * ((H + 15) // 16) * ((W + 15) // 16) * (cout // 128)
+        return (self.conv_impl == "halo" and cout % 32 == 0 and tiles >= self._halo_min_tiles and
+                bool(L.query("rbvae_conv3x3_halo_ok", dt, H, W, H, W, cin, cout)))
+
+    _halo_min_tiles = 1
+
+    def _res(self, prefix, x, xst, N, H, W, cin, cout):
+        """ResnetBlock (model.py:82-141) -> (output rows, its GroupNorm partial statistics or None)"""
+        if self._halo_ok(N, H, W, cin, cout) and self._halo_ok(N, H, W, cout, cout):
+            sc, sh = self._scale_shift(f"{prefix}.norm1", x, xst, N, H, W, cin)
+            h, hst = self._conv3_halo(f"{prefix}.conv1", x, N, H, W, cin, cout, sc, sh)
+            sc, sh = self._scale_shift(f"{prefix}.norm2", h, hst, N, H, W, cout)
+            skip = x if cin == cout else self._conv1(f"{prefix}.nin_shortcut", x, N * H * W, cin, cout)
+            return self._conv3_halo(f"{prefix}.conv2", h, N, H, W, cout, cout, sc, sh, addend=skip)
         h = self._gn(f"{prefix}.norm1", x, N, H * W, cin)
         h = self._conv3(f"{prefix}.conv1", h, N, H, W, cin, cout)
         h = self._gn(f"{prefix}.norm2", h, N, H * W, cout)
         skip = x if cin == cout else self._conv1(f"{prefix}.nin_shortcut", x, N * H * W, cin, cout)
-        return self._conv3(f"{prefix}.conv2", h, N, H, W, cout, cout, addend=skip)
+        return self._conv3(f"{prefix}.conv2", h, N, H, W, cout, cout, addend=skip), None
 
     def _attn(self, prefix, x, N, H, W, C):
         dt, tdt, ke = self._packed[1], self._packed[2], self._packed[3]
@@ -251,7 +301,7 @@ class LDMEncoder(nn.Module):
             self._pack(x.device)
         dev, dt, tdt, ke, pk = self._packed
         x = x.float().contiguous()
-        h = None
+        h, hst = None, None          # activation rows and (when a halo convolution produced them) their GroupNorm partials
         for prefix, kind, cin, cout in self.plan:
             if kind == "conv_in":
                 K = pk[f"{prefix}.weight"].shape[1]
@@ -260,8 +310,10 @@ class LDMEncoder(nn.Module):
                 h = torch.empty(N * H * W, cout, dtype=tdt, device=dev)
                 self._gemm(col, pk[f"{prefix}.weight"], h, self._p(f"{prefix}.bias"), None, N * H * W, 1, 1, 1, 1, 1,
                            1, 1, K, cout, K, cout, 1, self._d_one)
+                hst = None
             elif kind == "res":
-                h = self._res(prefix, h, N, H, W, cin, cout)
+                h, hst = self._res(prefix, h, hst, N, H, W, cin, cout)
+                continue
             elif kind == "down":
                 out = torch.empty(N * (H // 2) * (W // 2), cout, dtype=tdt, device=dev)
                 self._gemm(h, pk[f"{prefix}.weight"], out, self._p(f"{prefix}.bias"), None, N, H, W, H // 2, W // 2, 2,
@@ -283,6 +335,7 @@ class LDMEncoder(nn.Module):
                 self._gemm(h, pk[f"{prefix}.weight"], out, self._p(f"{prefix}.bias"), None, N * H * W, 1, 1, 1, 1, 1, 1,
                            1, K, cout, K, cout, 1, self._d_one)
                 h = out
+            hst = None                # every kind but "res" leaves its statistics to the GroupNorm kernels
         return h
 
     @torch.no_grad()

@@ -104,3 +104,21 @@ def test_attention_online_softmax_matches_torch(N, hw, C):
     assert float((got - ref).abs().max()) < 4e-2 * float(ref.abs().max())
     with pytest.raises(ValueError):
         L.call("rbvae_attention", 1, dq, dq, dq, o, N, hw + 1, C, 3 * C, 3 * C, 3 * C, C, 1.0)
+
+
+@pytest.mark.parametrize("dtype,tol", [("f32", 2e-4), ("bf16", 4e-2)])
+def test_halo_resnet_path_equals_gather_path(dtype, tol):
+    """The halo-resident 3x3 kernel with GroupNorm folded into its staging / epilogue (conv_impl="halo", the default)
+    against the gather-GEMM + standalone GroupNorm kernels (conv_impl="gather") on 128x128 frames: every ResnetBlock
+    level of the encoder (128, 64, 32 and 16 pixel images; model.py:82-141, 368-459) takes the halo path."""
+    import sfv_amd as sfv
+    torch.manual_seed(5)
+    a = sfv.LDMEncoder(compute_dtype=dtype, conv_impl="halo").cuda()
+    b = sfv.LDMEncoder(compute_dtype=dtype, conv_impl="gather").cuda()
+    b.load_state_dict(a.state_dict())
+    x = (torch.rand(2, 3, 128, 128, generator=torch.Generator().manual_seed(6)) * 2 - 1).cuda()
+    ma, mb = a.moments(x).float().cpu()[:, :8], b.moments(x).float().cpu()[:, :8]
+    assert torch.isfinite(ma).all()
+    assert float((ma - mb).norm() / mb.norm()) < tol
+    with pytest.raises(ValueError):
+        sfv.LDMEncoder(conv_impl="cudnn")
