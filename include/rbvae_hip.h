@@ -417,6 +417,10 @@ int rbvae_groupnorm_swish_ws(int dtype, const void* x, void* y, const float* gam
  * rbvae_gn_affine turns them into the scale / shift rbvae_conv3x3_halo applies while it stages its input. */
 int rbvae_groupnorm_stats(int dtype, const void* x, float* stats_ws, size_t ws_floats, int N, int HW, int C, int ldx,
                           int groups, float eps, void* stream);
+/* the apply pass alone from given statistics (e.g. rbvae_gn_finish_tiles' mean_out / rstd_out): for convolutions with
+ * four or more 128-channel output tiles one standalone pass costs less than re-normalising the patch in every tile. */
+int rbvae_groupnorm_apply(int dtype, const void* x, void* y, const float* mean, const float* rstd, const float* gamma,
+                          const float* beta, int N, int HW, int C, int ldx, int ldy, int groups, int swish, void* stream);
 int rbvae_softmax_rows(int dtype, const void* x, void* y, long rows, int n, int ld, void* stream);
 /* AttnBlock.forward's q k^T * C^-0.5 -> softmax -> . v (ldm/modules/diffusionmodules/model.py:186-198) for N images
  * of hw tokens x C channels as ONE batched, tiled, online-softmax kernel: the hw x hw scores are never materialised.

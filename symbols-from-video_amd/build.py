@@ -56,6 +56,10 @@ ISA_CHECKED = {
 }
 
 
+# kernels with register-destination loads issued as inline asm (counted vmcnt waits): the load opcode
+ASM_VMEM_LOADS = {"conv_halo.hip": "global_load_dwordx4"}
+
+
 def _check_asm_reads(src):
     """The GEMM kernels hide their LDS fragment reads from the compiler (inline asm); prove on the ISA that no
     fragment register is touched before the wait that covers it (isa_check.py)."""
@@ -70,6 +74,8 @@ def _check_asm_reads(src):
         raise RuntimeError(f"hipcc -S failed on {src}:\n{r.stderr}")
     prefix, ops = ISA_CHECKED[src]
     bad = mod.tr_asm_hazards(open(asm).read(), prefix, ops)
+    if src in ASM_VMEM_LOADS:
+        bad += mod.asm_vmem_load_hazards(open(asm).read(), prefix, ASM_VMEM_LOADS[src])
     if bad:
         raise RuntimeError(src + " ISA check failed (fragment register touched before its wait):\n" + "\n".join(bad[:20]))
 

@@ -93,6 +93,13 @@ template <typename T, int RING> constexpr int ch_lds_main() {
 #define CH_ABL 0
 #endif
 
+template <int I, int N, typename F> __device__ __forceinline__ void ch_static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        ch_static_for<I + 1, N>(f);
+    }
+}
+
 template <int N> __device__ __forceinline__ void ch_wait_barrier() {
 #if CH_ABL & 2
     asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)" ::"n"(N) : "memory");
@@ -101,7 +108,7 @@ template <int N> __device__ __forceinline__ void ch_wait_barrier() {
 #endif
 }
 
-template <typename T, int RING>
+template <typename T, int RING, bool GN>
 __global__ __launch_bounds__(512) void conv_halo_k(const ChArgs p) {
     constexpr int ES = sizeof(T);
     constexpr int KE = 128 / ES, EC = 16 / ES;
@@ -163,20 +170,41 @@ __global__ __launch_bounds__(512) void conv_halo_k(const ChArgs p) {
     // 128-byte slice (coalesced), and write it to 8 chunk planes
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
     const int chunk = tid & 7;
-    int pix[CH_NA];
-    unsigned adst[CH_NA];
+    const unsigned char* zsrc = p.zero + chunk * 16;
+    // source pixel row of this thread's six pieces: -1 zero (padding), -2 no such slot.  Kept in registers: a
+    // compiler-issued LDS read inside the loop waits lgkmcnt(0), i.e. for the fragment reads in flight around it
+    int pixr[CH_NA];
 #pragma unroll
     for (int i = 0; i < CH_NA; ++i) {
         const int slot = (tid >> 3) + 64 * i;
-        pix[i] = slot < CH_NSLOT_PAD ? s_pix[slot] : -2;     // -1: zero (padding), -2: no such slot
-        adst[i] = ch_plane_off(chunk) + (unsigned)slot * 16;
+        pixr[i] = slot < CH_NSLOT_PAD ? s_pix[slot] : -2;
     }
-    const unsigned char* zsrc = p.zero + chunk * 16;
+    // (a runtime-indexed pick of pixr[i] becomes a scratch array: the staged steps rotate the six registers instead --
+    // one full turn per slice, so every a_load sees them in order)
+    // GroupNorm scale / shift of this thread's chunk for the slice being staged (loaded right behind a barrier)
+    float gsc[EC], gsh[EC];
+#pragma unroll
+    for (int e = 0; e < EC; ++e) { gsc[e] = 1.f; gsh[e] = 0.f; }
+    auto gn_coeffs = [&](int kc) {
+        if constexpr (GN) {
+            const int cb = kc * KE + chunk * EC;
+#pragma unroll
+            for (int e = 0; e < EC; ++e) { gsc[e] = s_gsc[cb + e]; gsh[e] = s_gsh[cb + e]; }
+#pragma unroll
+            for (int e = 0; e < EC; ++e) asm volatile("" : "+v"(gsc[e]), "+v"(gsh[e]));   // landed HERE
+        }
+    };
+    // The six staged pieces of a slice: asm loads (the compiler would drain the weight tiles' LDS-DMA in front of a load
+    // of its own), destinations tied to the counted wait that covers them.  Loads, wait and uses all sit inside ONE
+    // unrolled slice body (taps 1, 3 and 3..8): a value that stayed in flight across the loop's back edge got copied by
+    // the compiler's phi moves right behind the load instruction, before its data had landed.  The build's ISA check
+    // proves that nothing touches a destination between its load and the wait.
     u32x4_t areg[CH_NA];
     auto a_load = [&](int kc) {
 #pragma unroll
         for (int i = 0; i < CH_NA; ++i) {
-            const unsigned char* src = pix[i] >= 0 ? p.A + ((size_t)pix[i] * p.lda) * ES + (size_t)kc * 128 + chunk * 16 : zsrc;
+            const int pv = pixr[i];
+            const unsigned char* src = pv >= 0 ? p.A + ((size_t)pv * p.lda) * ES + (size_t)kc * 128 + chunk * 16 : zsrc;
             asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(areg[i]) : "v"(src) : "memory");
         }
     };
@@ -187,54 +215,57 @@ __global__ __launch_bounds__(512) void conv_halo_k(const ChArgs p) {
                      : "+v"(ar[0]), "+v"(ar[1]), "+v"(ar[2]), "+v"(ar[3]), "+v"(ar[4]), "+v"(ar[5])
                      : "n"(YOUNGER));
     };
-    auto a_write = [&](int kc, int buf) {
-        if (p.gn_scale) {
-            float sc[EC], sh[EC];
-            const int cb = kc * KE + chunk * EC;
+    // the producer's GroupNorm (+ swish) on one staged 16-byte piece of slice kc (padding pixels stay zero)
+    auto gn_piece = [&](u32x4_t v, int kc, int pv) -> u32x4_t {
+        if constexpr (!GN) return v;
+        u32x4_t t = v;
+        T* ev = (T*)&t;
 #pragma unroll
-            for (int e = 0; e < EC; ++e) { sc[e] = s_gsc[cb + e]; sh[e] = s_gsh[cb + e]; }
-#pragma unroll
-            for (int i = 0; i < CH_NA; ++i) {
-                if (pix[i] >= 0) {
-                    T* ev = (T*)&areg[i];
-#pragma unroll
-                    for (int e = 0; e < EC; ++e) {
-                        float v = fmaf(Elem<T>::load(ev + e), sc[e], sh[e]);
-                        if (p.gn_swish) {
-                            if constexpr (ES == 2) v = v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504f * v));
-                            else v = v * sigmoidf_(v);
-                        }
-                        Elem<T>::store(ev + e, v);
-                    }
-                }
+        for (int e = 0; e < EC; ++e) {
+            float x = fmaf(Elem<T>::load(ev + e), gsc[e], gsh[e]);
+            if (p.gn_swish) {
+                if constexpr (ES == 2) x = x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504f * x));
+                else x = x * sigmoidf_(x);
             }
+            Elem<T>::store(ev + e, x);
         }
-        // (asm: a compiler-issued LDS store would first drain the weight tiles' LDS-DMA -- it cannot tell them apart)
-        const unsigned lbase = lds0 + (unsigned)buf * CH_ABUF;
 #pragma unroll
-        for (int i = 0; i < CH_NA; ++i)
-            if (pix[i] >= -1) asm volatile("ds_write_b128 %0, %1" ::"v"(lbase + adst[i]), "v"(areg[i]) : "memory");
+        for (int q = 0; q < 4; ++q) t[q] = pv >= 0 ? t[q] : v[q];
+        return t;
+    };
+    // (asm store: a compiler-issued LDS store would first drain the weight tiles' LDS-DMA -- it cannot tell them apart)
+    auto piece_write = [&](const u32x4_t& v, int buf, int i, int pv) {
+        const unsigned dst = lds0 + (unsigned)buf * CH_ABUF + ch_plane_off(chunk) + (unsigned)((tid >> 3) + 64 * i) * 16;
+        if (pv >= -1) asm volatile("ds_write_b128 %0, %1" ::"v"(dst), "v"(v) : "memory");
+    };
+    auto a_write = [&](int kc, int buf) {                  // all six pieces at once (prologue)
+        gn_coeffs(kc);
+#pragma unroll
+        for (int i = 0; i < CH_NA; ++i) piece_write(gn_piece(areg[i], kc, pixr[i]), buf, i, pixr[i]);
     };
 
     // ---- weight staging roles (LDS-DMA): instruction i of wave w moves rows (w*2+i)*8 .. +7 of the tap tile
+    static_assert(RING == 3, "the unrolled slice body relies on 9 taps % RING == 0 (static ring slots)");
     const int srow = lane >> 3, schunk = lane & 7;
-    const unsigned char* bptr[LOADS];
+    // source = uniform base (tile, tap, slice: scalar registers) + a 32-bit per-lane offset (row, swizzled chunk): with
+    // per-tap 64-bit lane pointers the unrolled slice body kept 18 of them live and spilled
+    unsigned blane[LOADS];
 #pragma unroll
     for (int i = 0; i < LOADS; ++i) {
         const int r = (w * LOADS + i) * 8 + srow;
-        bptr[i] = p.W + ((size_t)(n0 + r) * 9 * p.Kc) * ES + (schunk ^ ((r >> 1) & 7)) * 16;
+        blane[i] = (unsigned)(r * 9 * p.Kc) * ES + (unsigned)((schunk ^ ((r >> 1) & 7)) * 16);
     }
+    const unsigned char* wtile = p.W + ((size_t)n0 * 9 * p.Kc) * ES;
     const int nkc = p.Kc / KE;
-    const int nsteps = nkc * 9;
-    int pstep = 0, pkc = 0, pj = 0, pbuf = 0;          // producer: next (slice, tap) to stage
-    auto b_issue = [&]() {
-        const size_t off = ((size_t)pj * p.Kc) * ES + (size_t)pkc * 128;
-        unsigned char* lb = smem + A_BYTES + pbuf * CH_BBYTES + (w * LOADS) * 1024;
+    // weight tile of (slice kc, tap j) -> ring slot j % 3
+    auto b_issue = [&](int kc, auto j_tag) {
+        constexpr int j = decltype(j_tag)::value;
+#if !(CH_ABL & 1)
+        const unsigned char* src = wtile + ((size_t)j * p.Kc) * ES + (size_t)kc * 128;
+        unsigned char* lb = smem + A_BYTES + (j % RING) * CH_BBYTES + (w * LOADS) * 1024;
 #pragma unroll
-        for (int i = 0; i < LOADS; ++i) ch_glds16(bptr[i] + off, lb + i * 1024);
-        ++pstep;
-        if (++pj == 9) { pj = 0; ++pkc; }
-        pbuf = (pbuf + 1 == RING) ? 0 : pbuf + 1;
+        for (int i = 0; i < LOADS; ++i) ch_glds16(src + blane[i], lb + i * 1024);
+#endif
     };
 
     // ---- fragment addresses
@@ -245,9 +276,8 @@ __global__ __launch_bounds__(512) void conv_halo_k(const ChArgs p) {
     for (int mt = 0; mt < MT; ++mt)
         abase[mt] = lds0 + (unsigned)fg * CH_PLANE + (unsigned)(fg >> 1) * 32 + (unsigned)((wr * MT + mt) * CH_PW + fi) * 16;
     const int fsw = (fi >> 1) & 7;
-    unsigned offB[2];
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk) offB[kk] = lds0 + A_BYTES + (unsigned)(wc * NTW * 16 + fi) * 128 + (unsigned)(((4 * kk + fg) ^ fsw) * 16);
+    const unsigned offB0 = lds0 + A_BYTES + (unsigned)(wc * NTW * 16 + fi) * 128 + (unsigned)(((0 + fg) ^ fsw) * 16);
+    const unsigned offB1 = lds0 + A_BYTES + (unsigned)(wc * NTW * 16 + fi) * 128 + (unsigned)(((4 + fg) ^ fsw) * 16);
 
     f32x4_t acc[MT][NTW];
 #pragma unroll
@@ -255,21 +285,25 @@ __global__ __launch_bounds__(512) void conv_halo_k(const ChArgs p) {
 #pragma unroll
         for (int nt = 0; nt < NTW; ++nt) acc[mt][nt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-    // One 32-k half of a step: MT + NTW fragment reads (inline asm, counted waits: see gather_gemm.hip) and MT x NTW MFMAs
-    unsigned ta[MT];                         // this step's patch read addresses (buffer + tap shift folded in)
-    bool first_reads = true;
-    auto read_half = [&](unsigned bslot, auto kk_tag, u32x4_t (&fa)[MT], u32x4_t (&fb)[NTW]) {
-        constexpr int kk = decltype(kk_tag)::value;
-#if CH_ABL & 4
-        if (!first_reads) return;
-#endif
+    // One 32-k half of a step: MT + NTW fragment reads (inline asm, counted waits: see gather_gemm.hip) and MT x NTW
+    // MFMAs.  The tap and the ring slot are compile-time constants (the nine taps of a slice are unrolled): the tap's
+    // shift of the patch and the weight tile's slot are immediate offsets of the reads.
+    unsigned ta[MT];                         // patch read addresses of the slice being read (buffer folded in)
+    auto set_slice = [&](int kc) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) ta[mt] = abase[mt] + (unsigned)((kc & 1) * CH_ABUF);
+    };
+    auto read_half = [&](auto j_tag, auto kk_tag, u32x4_t (&fa)[MT], u32x4_t (&fb)[NTW]) {
+        constexpr int j = decltype(j_tag)::value, kk = decltype(kk_tag)::value;
+        constexpr int aoff = kk * CH_KKOFF + ((j / 3) * CH_PW + (j % 3)) * 16;
+        constexpr int boff = (j % RING) * CH_BBYTES;
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
-            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fa[mt]) : "v"(ta[mt]), "n"(kk * CH_KKOFF));
-        const unsigned ab_ = offB[kk] + bslot;
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fa[mt]) : "v"(ta[mt]), "n"(aoff));
+        const unsigned ab_ = kk == 0 ? offB0 : offB1;
 #pragma unroll
         for (int nt = 0; nt < NTW; ++nt)
-            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fb[nt]) : "v"(ab_), "n"(nt * 2048));
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fb[nt]) : "v"(ab_), "n"(boff + nt * 2048));
     };
     auto landed = [&](auto younger_tag, u32x4_t (&fa)[MT], u32x4_t (&fb)[NTW]) {
         constexpr int YOUNGER = decltype(younger_tag)::value;
@@ -283,89 +317,99 @@ __global__ __launch_bounds__(512) void conv_halo_k(const ChArgs p) {
 #pragma unroll
             for (int nt = 0; nt < NTW; ++nt) ChMma<T>::run(acc[mt][nt], fb[nt], fa[mt]);
     };
+    // The same MFMA group with patch piece I of slice kcn riding in it: its GroupNorm + swish arithmetic fills the
+    // vector-issue slots between the MFMAs (done as one block at the slice boundary it left the matrix pipe idle for
+    // ~2000 cycles per slice: +8 % kernel time), then the piece goes to the other patch buffer.
+    auto mma_half_stage = [&](const u32x4_t (&fa)[MT], const u32x4_t (&fb)[NTW], int kcn, auto i_tag) {
+        constexpr int I = decltype(i_tag)::value;
+        const u32x4_t v = gn_piece(areg[I], kcn, pixr[I]);
+        mma_half(fa, fb);
+        if constexpr (GN && ES == 2) {
+#pragma unroll
+            for (int k = 0; k < MT * NTW; ++k) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);     // 1 MFMA
+                __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);     // 3 VALU
+                __builtin_amdgcn_sched_group_barrier(0x400, 1, 0);     // 1 transcendental
+            }
+        }
+        asm volatile("" ::"v"(v));                  // the piece is finished HERE, not inside the store's branch
+        __builtin_amdgcn_sched_barrier(0);
+        piece_write(v, kcn & 1, I, pixr[I]);
+    };
     using K0 = std::integral_constant<int, 0>;
     using K1 = std::integral_constant<int, 1>;
     using Younger = std::integral_constant<int, MT + NTW>;
     using None = std::integral_constant<int, 0>;
-    // consumer state: step s = (slice ckc, tap cj); ring slot cslot
-    int ckc = 0, cj = 0, cslot = 0;
-    auto set_tap = [&]() {
-        const unsigned sh = (unsigned)((ckc & 1) * CH_ABUF) + (unsigned)((cj / 3) * CH_PW + (cj % 3)) * 16;
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) ta[mt] = abase[mt] + sh;
-    };
-    // after the barrier of step (ckc, cj): stage the weights RING-1 steps ahead; the next slice's patch goes to registers
-    // at tap 0 and into the other patch buffer at tap 8 (its last reader finished a slice ago; the barrier of the next
-    // step publishes it)
-    auto post_barrier = [&]() {
-#if CH_ABL & 1
-        if (pstep < nsteps) { ++pstep; if (++pj == 9) { pj = 0; ++pkc; } pbuf = (pbuf + 1 == RING) ? 0 : pbuf + 1; }
-#else
-        if (pstep < nsteps) b_issue();
-#endif
-#if CH_ABL & 8
-        return;
-#endif
-        if (cj == 0 && ckc + 1 < nkc) a_load(ckc + 1);
-        if (cj == 8 && ckc + 1 < nkc) {
-            a_landed(std::integral_constant<int, 8 * LOADS>{}, areg);
-            __builtin_amdgcn_sched_barrier(0);
-            a_write(ckc + 1, (ckc + 1) & 1);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    };
-    // before the barrier of the step after (ckc, cj) = step s+1: its weight tile has landed.  Younger operations that may
-    // stay in flight: the RING-2 tiles behind it, and the patch loads when they were issued after it (taps 1..RING-1)
-    auto pre_barrier = [&](int s_next) {
-        const bool tail = nsteps - s_next - 1 < RING - 2;            // fewer tiles behind it than the ring holds
-        const int nj = cj + 1 == 9 ? 0 : cj + 1;
-        const bool patch = nj >= 1 && nj <= RING - 1 && ckc + 1 < nkc;
-        if (tail) ch_wait_barrier<0>();
-        else if (patch) ch_wait_barrier<(RING - 2) * LOADS + CH_NA>();
-        else ch_wait_barrier<(RING - 2) * LOADS>();
-    };
 
-    // ---- prologue: patch of slice 0, the first RING-1 weight tiles
+    // ---- prologue: patch of slice 0, the first two weight tiles
     a_load(0);
-#pragma unroll
-    for (int i = 0; i < RING - 1; ++i)
-        if (pstep < nsteps) b_issue();
+    b_issue(0, std::integral_constant<int, 0>{});
+    b_issue(0, std::integral_constant<int, 1>{});
     a_landed(std::integral_constant<int, 0>{}, areg);
     a_write(0, 0);
     ch_wait_barrier<0>();
-    post_barrier();                    // stages step RING-1; loads the patch of slice 1
+    b_issue(0, std::integral_constant<int, 2>{});
     u32x4_t fa0[MT], fb0[NTW], fa1[MT], fb1[NTW];
-    set_tap();
-    read_half(0u, K0{}, fa0, fb0);
-    for (int s = 0; s + 1 < nsteps; ++s) {
-        const unsigned bcur = (unsigned)cslot * CH_BBYTES;
-        read_half(bcur, K1{}, fa1, fb1);
-        first_reads = false;
-        landed(Younger{}, fa0, fb0);
-        __builtin_amdgcn_sched_barrier(0);
-        mma_half(fa0, fb0);
-        __builtin_amdgcn_sched_barrier(0);
-        landed(None{}, fa1, fb1);
-        pre_barrier(s + 1);
-        if (++cj == 9) { cj = 0; ++ckc; }
-        cslot = (cslot + 1 == RING) ? 0 : cslot + 1;
-        post_barrier();
-        set_tap();
-        read_half((unsigned)cslot * CH_BBYTES, K0{}, fa0, fb0);
-        __builtin_amdgcn_sched_barrier(0);
-        mma_half(fa1, fb1);
-        __builtin_amdgcn_sched_barrier(0);
+    set_slice(0);
+    read_half(K0{}, K0{}, fa0, fb0);
+
+    // ---- main loop: slices of 128 bytes of channels, the nine taps unrolled.  Software pipeline over the 32-k halves
+    // as in gather_gemm.hip: the barrier of step s+1 sits between the two MFMA groups of step s.  After that barrier
+    // (every wave is done reading step s-1... and the tile of step s+1 has landed): stage the weight tile two steps
+    // ahead; the NEXT slice's patch goes to registers at tap 1, its GroupNorm coefficients at tap 2, the loads are
+    // waited for at tap 3, and at taps 3..8 one piece per step rides in the MFMA group into the other patch buffer
+    // (whose last reader finished a slice ago; the barrier of the next slice's first step publishes the last piece).
+    auto slice = [&](int kc, auto more_tag) {
+        constexpr bool more = decltype(more_tag)::value;       // another slice follows (the last slice is its own instance)
+        ch_static_for<0, 9>([&](auto j_tag) {
+            constexpr int j = decltype(j_tag)::value;
+            constexpr int nj = (j + 1) % 9;                  // tap of the next step
+            using NJ = std::integral_constant<int, nj>;
+            read_half(j_tag, K1{}, fa1, fb1);
+            landed(Younger{}, fa0, fb0);
+            __builtin_amdgcn_sched_barrier(0);
+            mma_half(fa0, fb0);
+            __builtin_amdgcn_sched_barrier(0);
+            landed(None{}, fa1, fb1);
+            if constexpr (j == 8 && !more) {                 // the very last step reads nothing ahead
+                __builtin_amdgcn_sched_barrier(0);
+                mma_half(fa1, fb1);
+            } else {
+                const int kn = j == 8 ? kc + 1 : kc;         // slice of the next step
+                // does a slice follow the NEXT step's slice?  (compile-time inside a slice; at the hand-over to the
+                // next slice it is the one run-time question of the body)
+                const bool moren = j == 8 ? kn + 1 < nkc : more;
+                // the next step's weight tile has landed; younger operations that may stay in flight: the tile behind
+                // it (none behind the very last step), and at taps 2 and 3 the patch loads issued behind it
+                if constexpr (nj == 8 && !more) ch_wait_barrier<0>();
+                else if constexpr ((nj == 2 || nj == 3) && more) ch_wait_barrier<LOADS + CH_NA>();
+                else ch_wait_barrier<LOADS>();
+                // behind the barrier: the weight tile two steps ahead
+                if constexpr (nj + 2 < 9) b_issue(kn, std::integral_constant<int, (nj + 2) % 9>{});
+                else if (moren) b_issue(kn + 1, std::integral_constant<int, (nj + 2) % 9>{});
+#if !(CH_ABL & 8)
+                if constexpr (nj == 1 && more) a_load(kn + 1);
+                if constexpr (nj == 2 && more) gn_coeffs(kn + 1);
+                if constexpr (nj == 3 && more) a_landed(std::integral_constant<int, 2 * LOADS>{}, areg);   // behind them: the tiles of taps 4, 5
+#endif
+                if constexpr (nj == 0) set_slice(kn);
+                read_half(NJ{}, K0{}, fa0, fb0);
+                __builtin_amdgcn_sched_barrier(0);
+#if !(CH_ABL & 8)
+                if constexpr (nj >= 3 && nj < 3 + CH_NA && more) mma_half_stage(fa1, fb1, kn + 1, std::integral_constant<int, nj - 3>{});
+                else
+#endif
+                    mma_half(fa1, fb1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        });
+    };
+    for (int kcl = 0; kcl + 1 < nkc; ++kcl) {
+        int kc = kcl;
+        asm volatile("" : "+s"(kc));        // opaque: no per-tap address induction variables across the slice loop
+        slice(kc, std::true_type{});
     }
-    {
-        read_half((unsigned)cslot * CH_BBYTES, K1{}, fa1, fb1);
-        landed(Younger{}, fa0, fb0);
-        __builtin_amdgcn_sched_barrier(0);
-        mma_half(fa0, fb0);
-        __builtin_amdgcn_sched_barrier(0);
-        landed(None{}, fa1, fb1);
-        __builtin_amdgcn_sched_barrier(0);
-        mma_half(fa1, fb1);
-    }
+    slice(nkc - 1, std::false_type{});
     __syncthreads();
 
     // ---- epilogue, register phase: bias; lane owns pixel fi, channels 4*fg..+3 of each 16 x 16 tile
@@ -531,7 +575,7 @@ __global__ void gn_affine_k(const float* __restrict__ mean, const float* __restr
     shift[i] = beta[c] - mean[sg] * sc;
 }
 
-template <typename T, int RING>
+template <typename T, int RING, bool GN>
 static int launch_ch(const ChArgs& a, hipStream_t st) {
     constexpr int ES = sizeof(T);
     const size_t lds = (size_t)ch_lds_main<T, RING>() + CH_BM * 4 + CH_NSLOT_PAD * 4 + (a.gn_scale ? (size_t)2 * a.Kc * 4 : 0) + 16;
@@ -539,10 +583,10 @@ static int launch_ch(const ChArgs& a, hipStream_t st) {
     (void)ES;
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute((const void*)conv_halo_k<T, RING>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)conv_halo_k<T, RING, GN>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
-    hipLaunchKernelGGL((conv_halo_k<T, RING>), dim3(a.total), dim3(512), lds, st, a);
+    hipLaunchKernelGGL((conv_halo_k<T, RING, GN>), dim3(a.total), dim3(512), lds, st, a);
     RBVAE_CHECK_LAUNCH("conv3x3_halo");
     return RBVAE_OK;
 }
@@ -589,9 +633,8 @@ extern "C" int rbvae_conv3x3_halo(int dtype, const void* A, const void* W, void*
     RBVAE_CHECK_ARG(total < (1l << 30), "conv3x3_halo: too many tiles");
     a.total = (int)total;
     hipStream_t st = (hipStream_t)stream;
-    static const int ring = getenv("RBVAE_CH_RING") ? atoi(getenv("RBVAE_CH_RING")) : 3;
-    if (dtype == RBVAE_F32) return launch_ch<float, 3>(a, st);
-    return ring == 4 ? launch_ch<bf16_t, 4>(a, st) : launch_ch<bf16_t, 3>(a, st);
+    if (dtype == RBVAE_F32) return gn_scale ? launch_ch<float, 3, true>(a, st) : launch_ch<float, 3, false>(a, st);
+    return gn_scale ? launch_ch<bf16_t, 3, true>(a, st) : launch_ch<bf16_t, 3, false>(a, st);
 }
 
 extern "C" size_t rbvae_conv3x3_halo_stats_floats(int Nimg, int OH, int OW, int Nout, int cg) {

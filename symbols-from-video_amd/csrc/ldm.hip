@@ -392,6 +392,36 @@ int rbvae_groupnorm_stats(int dtype, const void* x, float* stats_ws, size_t ws_f
     return RBVAE_OK;
 }
 
+/* the apply pass alone, from given statistics: y = swish?((x - mean) * rstd * gamma + beta) */
+int rbvae_groupnorm_apply(int dtype, const void* x, void* y, const float* mean, const float* rstd, const float* gamma,
+                          const float* beta, int N, int HW, int C, int ldx, int ldy, int groups, int swish, void* stream) {
+    RBVAE_CHECK_ARG(x && y && mean && rstd && gamma && beta && N > 0 && HW > 0 && C > 0, "groupnorm_apply: bad arguments");
+    RBVAE_CHECK_ARG(groups > 0 && C % groups == 0 && ldx >= C && ldy >= C, "groupnorm_apply: C=%d groups=%d", C, groups);
+    hipStream_t st = (hipStream_t)stream;
+    const long rows = (long)N * HW;
+    const bool vec = gn_tiled_ok(dtype, C, ldx, ldy, groups) && rows * (C / (dtype == RBVAE_F32 ? 4 : 8)) < (1l << 32) &&
+                     ((uintptr_t)x | (uintptr_t)y | (uintptr_t)gamma | (uintptr_t)beta) % 16 == 0;
+    if (vec) {
+        DISPATCH_T(dtype,
+                   hipLaunchKernelGGL(gn_apply_vec_k<float>, dim3(grid_n(rows * (C / 4), 16384)), dim3(256), 0, st,
+                                      (const float*)x, (float*)y, mean, rstd, gamma, beta, (unsigned)rows, HW, C, ldx, ldy,
+                                      groups, swish),
+                   hipLaunchKernelGGL(gn_apply_vec_k<bf16_t>, dim3(grid_n(rows * (C / 8), 16384)), dim3(256), 0, st,
+                                      (const bf16_t*)x, (bf16_t*)y, mean, rstd, gamma, beta, (unsigned)rows, HW, C, ldx, ldy,
+                                      groups, swish),
+                   "groupnorm_apply")
+    } else {
+        DISPATCH_T(dtype,
+                   hipLaunchKernelGGL(gn_apply_k<float>, dim3(grid_n(rows * C)), dim3(256), 0, st, (const float*)x,
+                                      (float*)y, mean, rstd, gamma, beta, rows, HW, C, ldx, ldy, groups, swish),
+                   hipLaunchKernelGGL(gn_apply_k<bf16_t>, dim3(grid_n(rows * C)), dim3(256), 0, st, (const bf16_t*)x,
+                                      (bf16_t*)y, mean, rstd, gamma, beta, rows, HW, C, ldx, ldy, groups, swish),
+                   "groupnorm_apply")
+    }
+    RBVAE_CHECK_LAUNCH("groupnorm_apply");
+    return RBVAE_OK;
+}
+
 int rbvae_softmax_rows(int dtype, const void* x, void* y, long rows, int n, int ld, void* stream) {
     RBVAE_CHECK_ARG(x && y && rows > 0 && n > 0 && ld >= n, "softmax_rows: bad arguments");
     hipStream_t st = (hipStream_t)stream;

@@ -96,3 +96,56 @@ def tr_asm_hazards(asm_text, kernel_prefix="_ZN5rbvae12wgrad_gemm_k", read_ops=(
                 work.append((nx, tuple(reads)))
         out += [f"{m.group(1)}: {x}" for x in sorted(msgs)]
     return out
+
+
+
+_VM_OPS = ("global_load", "global_store", "global_atomic", "buffer_load", "buffer_store", "buffer_atomic", "scratch_load",
+           "scratch_store", "flat_load", "flat_store")
+
+
+def asm_vmem_load_hazards(asm_text, kernel_prefix, load_op="global_load_dwordx4"):
+    """The same proof for register-destination loads issued as inline asm (conv_halo_k's patch pieces): between such a
+    load (inside ;;#ASMSTART / ;;#ASMEND) and the s_waitcnt vmcnt(N) that covers it, nothing may touch its destination.
+    vmcnt counts every vector-memory operation in issue order (LDS-DMA and stores included): the queue holds them all,
+    only the asm loads carry registers."""
+    out = []
+    for m in re.finditer(r"^(" + re.escape(kernel_prefix) + r"\w+):.*?s_endpgm", asm_text, re.S | re.M):
+        # mark asm regions line by line, then run the CFG walk on (instruction, in_asm) pairs
+        body, marked, inasm = m.group(0), [], False
+        for raw in body.splitlines():
+            if "#ASMSTART" in raw:
+                inasm = True
+                continue
+            if "#ASMEND" in raw:
+                inasm = False
+                continue
+            marked.append(raw + (" ;@asm" if inasm else ""))
+        blocks, succ = _blocks("\n".join(marked).replace(" ;@asm", " @asm"))
+        seen, work, msgs = set(), [("^", ())], set()
+        while work:
+            name, state = work.pop()
+            if (name, state) in seen or name not in blocks:
+                continue
+            seen.add((name, state))
+            if len(seen) > 200000:
+                msgs.add("state explosion: check aborted"); break
+            q = list(state)                       # in-order queue: frozenset of destination registers (empty = no registers)
+            for ln in blocks[name]:
+                asm = ln.endswith("@asm")
+                ln = ln.replace(" @asm", "")
+                op, _, rest = ln.partition(" ")
+                if op == "s_waitcnt" and "vmcnt" in rest:
+                    n = int(re.search(r"vmcnt\((\d+)\)", rest).group(1))
+                    q = q[len(q) - n:] if n else []
+                    continue
+                pending = set().union(*q) if q else set()
+                if pending and _regs(rest) & pending and not (asm and op == load_op and not (_regs(rest.partition(",")[0]) & pending)):
+                    hit = _regs(rest) & pending
+                    msgs.add(f"touches in-flight v{sorted(hit)}: {ln}")
+                if any(op.startswith(v) for v in _VM_OPS):
+                    q.append(frozenset(_regs(rest.partition(",")[0])) if (asm and op == load_op) else frozenset())
+                    q = q[-63:]
+            for nx in succ[name]:
+                work.append((nx, tuple(q)))
+        out += [f"{m.group(1)}: {x}" for x in sorted(msgs)]
+    return out
