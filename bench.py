@@ -45,22 +45,57 @@ def _free_port():
     return p
 
 
-def self_launch(n, argv):
+def self_launch(n, argv, cmd=None, deadline_s=None, poll_s=0.2):
     """`python bench.py --gpus N` typed as is: N rank processes, started before this one has made any GPU call
-    (it never makes one), environment as torch.distributed.run would set it.  Returns the exit code."""
+    (it never makes one), environment as torch.distributed.run would set it.  Returns the exit code.
+
+    Every child is polled: the first non-zero exit (a rank that died before or after rendezvous) terminates the others
+    and becomes the exit code, and so does an overall deadline (RBVAE_BENCH_DEADLINE seconds, default 540: below the
+    driver's 600 s limit) -- a sibling's crash never leaves rank 0 waiting in init_process_group.  Rank 0's stdout is
+    relayed; every rank's stderr goes to this process's stderr.  cmd: the rank command (tests launch a stub)."""
     port = _free_port()
+    deadline_s = float(os.environ.get("RBVAE_BENCH_DEADLINE", "540")) if deadline_s is None else deadline_s
+    cmd = [sys.executable, os.path.abspath(__file__)] + list(argv) if cmd is None else list(cmd)
     procs = []
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out, _ = procs[0].communicate()
-    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
-    sys.stdout.write(out.decode())
+        procs.append(subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    import threading
+    out = []
+    reader = threading.Thread(target=lambda: out.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    t0, code, why = time.monotonic(), 0, None
+    while True:
+        codes = [p.poll() for p in procs]
+        bad = next(((r, c) for r, c in enumerate(codes) if c not in (None, 0)), None)
+        if bad is not None:
+            code, why = bad[1], f"rank {bad[0]} exited with code {bad[1]}"
+            break
+        if all(c == 0 for c in codes):
+            break
+        if time.monotonic() - t0 > deadline_s:
+            code, why = 124, f"deadline of {deadline_s:.0f} s passed"
+            break
+        time.sleep(poll_s)
+    if why is not None:
+        sys.stderr.write(f"bench.py: {why}; terminating the other ranks\n")
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        t1 = time.monotonic()
+        while any(p.poll() is None for p in procs) and time.monotonic() - t1 < 5.0:
+            time.sleep(0.05)
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+        for p in procs:
+            p.wait()
+    reader.join(timeout=5.0)
+    sys.stdout.write(b"".join(out).decode())
     sys.stdout.flush()
-    return next((c for c in codes if c), 0)
+    return code if code else 0
 
 
 class KernelTimer:
@@ -222,6 +257,102 @@ def cpu_baseline(seconds_budget=15.0):
                       f"fwd+bwd+Adam, torch {torch.__version__} CPU, {cores} threads, {cpu_model}"}
 
 
+def other_configs(dev):
+    """The other configurations of BASELINE.json, measured in the SAME run on rank 0 (a few seconds each): frames/s,
+    ms per step and the fraction of each one's own roof (SURVEY.md 8d / BASELINE.md 3).  A configuration that fails is
+    reported with its error; the headline never depends on this leg."""
+    import torch
+    import sfv_amd as sfv
+
+    def timed(fn, warm, it):
+        for _ in range(warm):
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(it):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / it
+
+    def entry(frames, dt, dtype, roofs, note):
+        fps = frames / dt
+        bound, roof = min(roofs.items(), key=lambda kv: kv[1])
+        return {"frames_per_s": round(fps, 1), "ms_per_step": round(dt * 1e3, 4), "frames_per_step": frames, "dtype": dtype,
+                "roof": {"bound": bound, "frames_per_s": round(roof, 1), "frac": round(fps / roof, 4),
+                         "all": {k: round(v, 1) for k, v in roofs.items()}}, "workload": note}
+
+    def train_cfg(variant, cin, hw, item_shape, dtype, latent, pair_loss=None, uniform=False, it=20):
+        torch.manual_seed(0)
+        m = sfv.Seq2SeqBinaryVAE(cin, cin, latent, latent, variant=variant, input_hw=hw, compute_dtype=dtype).to(dev).train()
+        g = torch.Generator(device="cpu").manual_seed(1234)
+        item = (torch.rand(*item_shape, generator=g) if uniform else torch.randn(*item_shape, generator=g)).to(dev)
+        tr = sfv.FusedTrainer(m, alpha=ALPHA, beta_kl=BETA, bernoulli_p=BERN_P, noise_ratio=NOISE_R, device_noise=True,
+                              use_graph=True, seed=1234, pair_loss=pair_loss)
+        dt = timed(lambda: tr.step(item, TAU), 5, it)
+        if not bool(torch.isfinite(tr.losses).all()):
+            raise RuntimeError(f"non-finite losses {tr.losses.tolist()}")
+        return dt
+
+    out = {}
+
+    def run(name, fn):
+        try:
+            out[name] = fn()
+        except Exception as e:      # noqa: BLE001 -- reported, never fatal for the headline
+            out[name] = {"error": f"{type(e).__name__}: {e}"[:300]}
+        torch.cuda.empty_cache()
+
+    # cfg 3: contrastive_RBVAE on raw 256x256 RGB, 128 frames per step.  2629.9 MFLOP, 62.92 MB (f32) per frame
+    cfg3 = (8, 2, 8, 3, 256, 256)
+    run("cfg3_contrastive_256x256_f32", lambda: entry(
+        128, train_cfg("contrastive", 3, (256, 256), cfg3, "f32", 32, uniform=True, it=10), "f32",
+        {"hbm": 8.0e12 / 62.92e6, "f32_compute": 157.3e12 / 2629.9e6}, "item [8,2,8,3,256,256] ~ U[0,1), latent 32, fused step"))
+    run("cfg3_contrastive_256x256_bf16", lambda: entry(
+        128, train_cfg("contrastive", 3, (256, 256), cfg3, "bf16", 32, uniform=True), "bf16",
+        {"hbm": 8.0e12 / 31.46e6, "mfma": 2.5e15 / 2629.9e6}, "item [8,2,8,3,256,256] ~ U[0,1), latent 32, fused step"))
+    # percep_RBVAE at the reference's native latent size 4x88x160: 8196.8 MFLOP, 49.57 MB (f32) per frame
+    nat = (8, 2, 8, 4, 88, 160)
+    run("native_percep_4x88x160_bf16", lambda: entry(
+        128, train_cfg("percep", 4, (88, 160), nat, "bf16", 32), "bf16",
+        {"hbm": 8.0e12 / 24.785e6, "mfma": 2.5e15 / 8196.8e6}, "item [8,2,8,4,88,160] ~ N(0,1), latent 32, fused step"))
+    run("native_percep_4x88x160_f32", lambda: entry(
+        128, train_cfg("percep", 4, (88, 160), nat, "f32", 32, it=10), "f32",
+        {"hbm": 8.0e12 / 49.57e6, "f32_compute": 157.3e12 / 8196.8e6}, "item [8,2,8,4,88,160] ~ N(0,1), latent 32, fused step"))
+    # the headline workload at the reference's largest swept latent size
+    run("cfg2_latent100_bf16", lambda: entry(
+        256, train_cfg("percep", C_IN, HW, (B_ITEMS, 2, T_STATES, C_IN, *HW), "bf16", 100, it=100), "bf16",
+        {"hbm": ROOF_HBM_FPS, "mfma": ROOF_MFMA_FPS}, "headline item shape, latent_dim 100 (LSTM stacks of 100 units)"))
+
+    # cfg 5 front end: the frozen LDM VAE encoder on 512x512 frames (1116.7 GFLOP per frame)
+    def ldm():
+        torch.manual_seed(0)
+        enc = sfv.LDMEncoder(compute_dtype="bf16").to(dev)
+        x = (torch.rand(4, 3, 512, 512, generator=torch.Generator().manual_seed(3)) * 2 - 1).to(dev)
+        dt = timed(lambda: enc.encode(x, sample=False), 2, 5)
+        return entry(4, dt, "bf16", {"mfma": 2.5e15 / 1116.7e9}, "LDMEncoder.encode, 4 frames of 3x512x512, posterior mode")
+    run("ldm_encode_512x512_bf16", ldm)
+
+    # cfg 5 composition: frames -> LDM encode on the fly -> percep-style RBVAE (4x64x64 latents) with the triplet term
+    def cfg5():
+        from importlib import import_module
+        compose = import_module("symbols-from-video_amd.compose")
+        torch.manual_seed(0)
+        enc = sfv.LDMEncoder(compute_dtype="bf16").to(dev)
+        m = sfv.Seq2SeqBinaryVAE(4, 4, 32, 32, variant="percep", input_hw=(64, 64), compute_dtype="bf16").to(dev).train()
+        tr = sfv.FusedTrainer(m, alpha=ALPHA, beta_kl=BETA, bernoulli_p=BERN_P, device_noise=True, use_graph=True, seed=1234,
+                              pair_loss="triplet", margin=0.2)
+        pipe = compose.OnTheFlyLatentTrainer(enc, tr, frames_per_chunk=4)
+        frames = (torch.rand(1, 2, 4, 3, 512, 512, generator=torch.Generator().manual_seed(4)) * 2 - 1).to(dev)
+        dt = timed(lambda: pipe.step(frames, TAU, sample=False), 2, 4)
+        if not bool(torch.isfinite(tr.losses).all()):
+            raise RuntimeError(f"non-finite losses {tr.losses.tolist()}")
+        # per frame: the encoder's 1116.7 GFLOP + the RBVAE part's 2384.7 MFLOP (SURVEY.md 8d)
+        return entry(8, dt, "bf16", {"mfma": 2.5e15 / (1116.7e9 + 2384.7e6)},
+                     "frames [1,2,4,3,512,512] -> LDM encode -> triplet-trained percep RBVAE on 4x64x64 latents, one step")
+    run("cfg5_on_the_fly_512x512_bf16", cfg5)
+    return out
+
+
 def load_profile_json(name):
     try:
         with open(os.path.join(ROOT, "profiles", name)) as f:
@@ -238,6 +369,7 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--no-roofline", action="store_true", help="skip the per-kernel event legs")
+    ap.add_argument("--no-others", action="store_true", help="skip the other BASELINE configurations (rank 0, 1 GPU only)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     args = ap.parse_args()
 
@@ -297,6 +429,18 @@ def main():
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
     dt = float(t.item())
     losses = [float(v) for v in tr.losses.tolist()]
+    graphs_captured = sum(len([g for g in gs if g is not None]) for gs in tr._graphs.values())
+    if world == 1:
+        schedule = "one HIP graph per step"
+    elif not tr.ddp_overlap:
+        schedule = "backward graph | all-reduce | update graph"
+    elif tr.ddp_ingraph:
+        schedule = "one HIP graph, both bucket all-reduces captured on a communication stream"
+    else:
+        schedule = "3 graphs: tail-bucket all-reduce (async) beside the encoder-CNN backward graph, head after it, update"
+    dist_info = {"backend": (torch.distributed.get_backend() if world > 1 else None),
+                 "dist_world_size": (torch.distributed.get_world_size() if world > 1 else 1), "schedule": schedule,
+                 "devices_visible": torch.cuda.device_count()}
 
     roof = None
     roof_all = None
@@ -333,6 +477,11 @@ def main():
                 "timing": "HIP events on the launching stream, same multi-stream schedule as the captured graph "
                           "(side streams on); `isolated` = the kernel alone on one stream",
                 "event_pair_overhead_us_subtracted": round(ev_us, 2)}
+    others = None
+    if rank == 0 and world == 1 and not args.no_others:
+        del tr, ds, plan, table                  # release the headline's buffers before the larger configurations
+        torch.cuda.empty_cache()
+        others = other_configs(dev)
     if rank == 0 and world == 1 and not args.no_cpu:
         cpu = cpu_baseline()
     if world > 1:
@@ -358,10 +507,10 @@ def main():
                                        "+ fwd+bwd+losses+Adam), item [16,2,8,4,32,32] per GPU = 256 frames/step/GPU "
                                        "(latents of 256x256 frames), latent 32, 4-layer LSTMs, dropout on",
                            "frames_per_step_per_gpu": frames_per_step, "global_frames_per_step": frames_per_step * world,
-                           "parallelism": f"dp{world}", "graph": not args.no_graph,
-                           "graphs_captured": len(tr._graphs), "launcher": "torch.distributed.run or self-spawned ranks",
+                           "parallelism": f"dp{world}", "graph": not args.no_graph, **dist_info,
+                           "graphs_captured": graphs_captured, "launcher": "torch.distributed.run or self-spawned ranks",
                            "last_losses": {"total": losses[0], "recon": losses[1], "kl": losses[2], "pair": losses[3]}},
-                "roofline": roof, "roofline_all_mfma_kernels": roof_all, "cpu_baseline": cpu}
+                "roofline": roof, "roofline_all_mfma_kernels": roof_all, "cpu_baseline": cpu, "other_configs": others}
         print(json.dumps(line))
     if world > 1:
         torch.distributed.destroy_process_group()

@@ -10,8 +10,11 @@ import torch
 import torch.distributed as dist
 
 
-def init_from_env(backend=None):
-    """Initialise torch.distributed from RANK/WORLD_SIZE/MASTER_* (torchrun). Returns (rank, world, local_rank)."""
+def init_from_env(backend=None, timeout_s=None):
+    """Initialise torch.distributed from RANK/WORLD_SIZE/MASTER_* (torchrun). Returns (rank, world, local_rank).
+    timeout_s (default RBVAE_DIST_TIMEOUT or 180 s): rendezvous and collective timeout -- a rank that never arrives or a
+    collective that never completes becomes an error on the surviving ranks instead of an indefinite wait (the
+    reference has no failure handling at all; SURVEY.md 5 asks the data-parallel layer to time out at least)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -22,7 +25,11 @@ def init_from_env(backend=None):
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         if backend == "nccl":
             torch.cuda.set_device(local % max(torch.cuda.device_count(), 1))
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        import datetime
+        if timeout_s is None:
+            timeout_s = float(os.environ.get("RBVAE_DIST_TIMEOUT", "180"))
+        dist.init_process_group(backend=backend, rank=rank, world_size=world,
+                                timeout=datetime.timedelta(seconds=float(timeout_s)))
     return rank, world, local
 
 

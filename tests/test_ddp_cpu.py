@@ -107,3 +107,74 @@ def test_shard_items():
     assert sorted(sum((ddp.shard_items(16, r, 8) for r in range(8)), [])) == list(range(16))
     with pytest.raises(ValueError):
         ddp.shard_items(10, 0, 4)
+
+
+def _bench():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("rbvae_bench", os.path.join(ROOT, "bench.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_self_launch_kills_the_survivors_when_a_rank_dies(capfd):
+    """bench.self_launch: rank 1 exits with code 3 before rendezvous while rank 0 would wait for it forever; the
+    parent must come back non-zero within seconds, with no rank left behind, and relay what rank 0 printed."""
+    import time
+    bench = _bench()
+    stub = ("import os, sys, time\n"
+            "r = int(os.environ['RANK'])\n"
+            "assert os.environ['WORLD_SIZE'] == '2' and os.environ['MASTER_ADDR'] == '127.0.0.1'\n"
+            "print('hello from rank', r, flush=True)\n"
+            "if r == 1: sys.exit(3)\n"
+            "open(os.environ['PIDFILE'], 'w').write(str(os.getpid()))\n"
+            "time.sleep(600)\n")
+    pidfile = os.path.join(ROOT, ".pytest_cache", f"rank0_{os.getpid()}.pid")
+    os.makedirs(os.path.dirname(pidfile), exist_ok=True)
+    os.environ["PIDFILE"] = pidfile
+    try:
+        t0 = time.monotonic()
+        code = bench.self_launch(2, [], cmd=[sys.executable, "-c", stub])
+        dt = time.monotonic() - t0
+    finally:
+        os.environ.pop("PIDFILE", None)
+    assert code == 3 and dt < 20.0
+    out = capfd.readouterr()
+    assert "hello from rank 0" in out.out and "rank 1 exited with code 3" in out.err
+    pid = int(open(pidfile).read())
+    os.remove(pidfile)
+    with pytest.raises(ProcessLookupError):
+        os.kill(pid, 0)                      # rank 0 is gone
+
+
+def test_self_launch_deadline_and_clean_exit(capfd):
+    import time
+    bench = _bench()
+    t0 = time.monotonic()
+    code = bench.self_launch(2, [], cmd=[sys.executable, "-c", "import time; time.sleep(600)"], deadline_s=1.0)
+    assert code == 124 and time.monotonic() - t0 < 15.0
+    assert bench.self_launch(3, [], cmd=[sys.executable, "-c", "import os; print(os.environ['RANK'])"]) == 0
+    assert capfd.readouterr().out.strip().splitlines()[-1] == "0"          # only rank 0's stdout is relayed
+
+
+def test_process_group_timeout_is_set():
+    """ddp.init_from_env passes a finite timeout to init_process_group (a missing rank is an error, not a hang)."""
+    import importlib
+    import datetime
+    ddp = importlib.import_module("symbols-from-video_amd.ddp")
+    seen = {}
+    real = dist.init_process_group
+
+    def fake(**kw):
+        seen.update(kw)
+
+    env = dict(os.environ)
+    os.environ.update(WORLD_SIZE="2", RANK="0", LOCAL_RANK="0", RBVAE_DIST_TIMEOUT="7")
+    dist.init_process_group = fake
+    try:
+        ddp.init_from_env("gloo")
+    finally:
+        dist.init_process_group = real
+        os.environ.clear()
+        os.environ.update(env)
+    assert seen["timeout"] == datetime.timedelta(seconds=7) and seen["world_size"] == 2

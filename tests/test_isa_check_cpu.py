@@ -97,3 +97,32 @@ def test_built_kernels_are_clean_when_the_listing_exists():
         path = os.path.join(HERE, "..", "symbols-from-video_amd", "build", src + ".s")
         if os.path.exists(path):
             assert isa_check.tr_asm_hazards(open(path).read(), prefix, ops) == []
+
+
+def test_asm_vmem_load_check_flags_a_copy_before_the_wait():
+    """isa_check.asm_vmem_load_hazards (conv_halo_k's register-staged patch pieces): a compiler move of an asm load's
+    destination before the counted vmcnt wait is flagged; LDS-DMA and stores count in the queue but carry no registers;
+    the same code with the move behind the wait is clean."""
+    import importlib
+    ic = importlib.import_module("symbols-from-video_amd.isa_check")
+    head = "_ZN5rbvae11conv_halo_kTEST:\n"
+    body_bad = (head +
+                "\t;;#ASMSTART\n\tglobal_load_dwordx4 v[10:13], v[2:3], off\n\t;;#ASMEND\n"
+                "\tglobal_load_lds_dwordx4 v[4:5], off\n"
+                "\tv_mov_b32_e32 v20, v11\n"
+                "\t;;#ASMSTART\n\ts_waitcnt vmcnt(1)\n\t;;#ASMEND\n"
+                "\ts_endpgm\n")
+    bad = ic.asm_vmem_load_hazards(body_bad, "_ZN5rbvae11conv_halo_k")
+    assert len(bad) == 1 and "v_mov_b32_e32 v20, v11" in bad[0]
+    body_ok = body_bad.replace("\tv_mov_b32_e32 v20, v11\n", "") .replace("\ts_endpgm", "\tv_mov_b32_e32 v20, v11\n\ts_endpgm")
+    assert ic.asm_vmem_load_hazards(body_ok, "_ZN5rbvae11conv_halo_k") == []
+    # the wait must really cover the load: two younger operations, vmcnt(2) leaves it in flight
+    body_short = body_ok.replace("vmcnt(1)", "vmcnt(2)")
+    assert ic.asm_vmem_load_hazards(body_short, "_ZN5rbvae11conv_halo_k")
+    # a loop-carried destination copied on the back edge before the wait (the bug this check was written for)
+    loop = (head + ".LBB0_1:\n"
+            "\tv_mov_b32_e32 v30, v10\n"
+            "\t;;#ASMSTART\n\ts_waitcnt vmcnt(0)\n\t;;#ASMEND\n"
+            "\t;;#ASMSTART\n\tglobal_load_dwordx4 v[10:13], v[2:3], off\n\t;;#ASMEND\n"
+            "\ts_cbranch_scc1 .LBB0_1\n\ts_endpgm\n")
+    assert any("v_mov_b32_e32 v30, v10" in m for m in ic.asm_vmem_load_hazards(loop, "_ZN5rbvae11conv_halo_k"))
