@@ -95,6 +95,13 @@ int rbvae_pairdist_fwd(const float* x1, const float* x2, long stride1, long stri
 int rbvae_pairdist_bwd(const float* x1, const float* x2, long stride1, long stride2, int rows, int L,
                        int label, float margin, float eps, float scale, const float* gscale_dev,
                        float* dx1, float* dx2, long dstride1, long dstride2, int accumulate, void* stream);
+/* contrast_loss 'cosine' branch (percep_RBVAE_train.py:94-96; never taken by the reference's trainers):
+ *   d = 1 - x1.x2 / (max(|x1|, eps) * max(|x2|, eps)),  eps = 1e-8 (torch.nn.functional.cosine_similarity), then as above. */
+int rbvae_paircos_fwd(const float* x1, const float* x2, long stride1, long stride2, int rows, int L, int label,
+                      float margin, float eps, float* out_mean, void* stream);
+int rbvae_paircos_bwd(const float* x1, const float* x2, long stride1, long stride2, int rows, int L, int label,
+                      float margin, float eps, float scale, const float* gscale_dev, float* dx1, float* dx2, long dstride1,
+                      long dstride2, void* stream);
 /* The trainer's whole contrastive term in one launch (percep_RBVAE_train.py:534-543):
  *   mean_{b,t} d(h0,h1)^2 + 1/(T-1) sum_s mean_b max(1 - d(h0[:,s],h0[:,s+1]),0)^2, eps 1e-6.
  * h0,h1: [B,T,L] contiguous.  bwd WRITES dh0,dh1 (scale * d term/dh). */
@@ -462,6 +469,26 @@ int rbvae_gn_finish_tiles(const float* stats_part, const float* gamma, const flo
                           void* stream);
 int rbvae_gn_affine(const float* mean, const float* rstd, const float* gamma, const float* beta, float* scale,
                     float* shift, int N, int C, int groups, void* stream);
+
+/* ---- halo-resident transposed 3x3 convolution, stride 2 (csrc/deconv_halo.hip) --------------------------
+ * ConvTranspose2d(cin, cout, 3, stride 2, padding 1, output_padding 1) forward of the RBVAE decoder
+ * (models/percep_RBVAE/percep_RBVAE_model.py:76-81) and, with the data-gradient weight order, the input gradient of
+ * the encoder's Conv2d(3, stride 2, padding 1) (autograd of :54-57 under total_loss.backward(), percep_RBVAE_train.py:552):
+ * the four output-parity classes of rbvae_gather_gemm's "dgrad" descriptor in ONE workgroup per 128 (two workgroups per
+ * CU) or 256 input-grid positions x 64 output channels, the input patch staged in LDS once per channel slice and shared by the nine taps.
+ *   A [Nimg*TH*TW][lda] (the TH x TW input grid), Out [Nimg*2TH*2TW][ldo], W packed [Nout][9][Kc] (tap index kh*3+kw);
+ *   epilogue = rbvae_gather_gemm's (bias, relu, scale, drop_mode 0 / 1 keyed hash / 2 explicit mask with the same element
+ *   indices, gate, per-tile column sums of the stored values into colsum_ws [rbvae_deconv3x3s2_halo_colsum_rows][Nout]).
+ * rbvae_deconv3x3s2_halo_ok: 1 when covered (TW % 4 == 0, Kc % 64 (bf16) / 32 (f32) == 0, Nout % 64 == 0, patch fits). */
+int rbvae_deconv3x3s2_halo_ok(int dtype, int Nimg, int TH, int TW, int Kc, int Nout);
+/* input-grid positions per workgroup the shape runs with: 128 (two 4-wave workgroups per CU), 256 (one 8-wave workgroup:
+ * grids whose patch rows do not fit the 80 KB form, e.g. 4 x 4 and 11 x 20), 0 = not covered */
+int rbvae_deconv3x3s2_halo_tile_rows(int dtype, int Nimg, int TH, int TW, int Kc, int Nout);
+int rbvae_deconv3x3s2_halo_colsum_rows(int dtype, int Nimg, int TH, int TW, int Kc, int Nout);
+int rbvae_deconv3x3s2_halo(int dtype, const void* A, const void* W, void* Out, const float* bias, const void* gate,
+                           const void* mask, const void* zero_page, int Nimg, int TH, int TW, int Kc, int Nout, int lda,
+                           int ldo, int relu, int drop_mode, float drop_p, float scale, unsigned long long seed,
+                           const unsigned long long* seed_dev, float* colsum_ws, void* stream);
 
 #ifdef __cplusplus
 }

@@ -1,4 +1,4 @@
-"""ReLU-tie handling shared by the gradient parity tests.
+"""ReLU-tie handling shared by the gradient parity checks (tests/ and __graft_entry__.smoke()).
 
 Millions of pre-activations pass through a ReLU per step; the few that lie within rounding of zero may be resolved
 either way by two correct implementations, and ONE tie resolved differently moves a small-norm gradient tensor (a sum of

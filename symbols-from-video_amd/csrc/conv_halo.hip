@@ -100,6 +100,10 @@ template <int I, int N, typename F> __device__ __forceinline__ void ch_static_fo
     }
 }
 
+// workgroup barrier that orders LDS traffic only.  __syncthreads() also waits vmcnt(0): behind the epilogue's global stores
+// every barrier then costs a full store round trip (the epilogue ran at half the HBM write rate because of it).
+__device__ __forceinline__ void ch_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 template <int N> __device__ __forceinline__ void ch_wait_barrier() {
 #if CH_ABL & 2
     asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)" ::"n"(N) : "memory");
@@ -437,7 +441,7 @@ __global__ __launch_bounds__(512) void conv_halo_k(const ChArgs p) {
             }
         }
     }
-    __syncthreads();
+    ch_lds_barrier();
 
     // ---- store phase: whole 16-B chunks of NHWC rows (+ residual); the stored values stay in the LDS tile for the statistics
     const int sch = tid % CPR, rl = tid / CPR;
@@ -470,7 +474,7 @@ __global__ __launch_bounds__(512) void conv_halo_k(const ChArgs p) {
         // GroupNorm partial statistics of the stored tile: per group (cg consecutive channels) the tile's mean and the
         // sum of squared deviations from it (two passes over the LDS tile: as stable as torch's), merged across tiles
         // by gn_finish_tiles_k with the parallel-variance formula.  Pass 1: channel sums -> group means.
-        __syncthreads();
+        ch_lds_barrier();
         float* red = (float*)(smem + CH_BM * PITCH);      // [RL][BN] channel sums, then [BN / cg] group means
         const int cg = p.stats_cg, ng = CH_BN / cg;
 #pragma unroll
@@ -478,20 +482,20 @@ __global__ __launch_bounds__(512) void conv_halo_k(const ChArgs p) {
         // number of valid pixels of the tile (the same for every channel)
         const int vr = min(CH_T, p.OH - r0), vc = min(CH_T, p.OW - c0);
         const float cnt = (float)(vr * vc) * (float)cg;
-        __syncthreads();
+        ch_lds_barrier();
         float* gmean = red + RL * CH_BN;
         if (tid < CH_BN) {
             float t = 0.f;
             for (int k = 0; k < RL; ++k) t += red[k * CH_BN + tid];
             red[tid] = t;                                  // row 0 := channel totals (each thread its own column)
         }
-        __syncthreads();
+        ch_lds_barrier();
         if (tid < ng) {
             float t = 0.f;
             for (int c = 0; c < cg; ++c) t += red[tid * cg + c];
             gmean[tid] = t / cnt;
         }
-        __syncthreads();
+        ch_lds_barrier();
         // pass 2: squared deviations from the group mean
 #pragma unroll
         for (int e = 0; e < EC; ++e) csum[e] = 0.f;
@@ -508,16 +512,16 @@ __global__ __launch_bounds__(512) void conv_halo_k(const ChArgs p) {
                 for (int e = 0; e < EC; ++e) { const float d = Elem<T>::load(ev + e) - gm[e]; csum[e] += d * d; }
             }
         }
-        __syncthreads();
+        ch_lds_barrier();
 #pragma unroll
         for (int e = 0; e < EC; ++e) red[rl * CH_BN + sch * EC + e] = csum[e];
-        __syncthreads();
+        ch_lds_barrier();
         if (tid < CH_BN) {
             float t = 0.f;
             for (int k = 0; k < RL; ++k) t += red[k * CH_BN + tid];
             red[tid] = t;                                  // its own column only
         }
-        __syncthreads();
+        ch_lds_barrier();
         if (tid < ng) {
             float t = 0.f;
             for (int c = 0; c < cg; ++c) t += red[tid * cg + c];

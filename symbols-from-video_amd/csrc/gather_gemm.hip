@@ -556,12 +556,13 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void gather_gemm_k(const GgArgs p)
     }
     GG_STAMP(5);
     if (p.colsum_ws) {
-        // bias gradient: column sums of this tile's stored rows, reduced over the row lanes in LDS
-        __syncthreads();
+        // bias gradient: column sums of this tile's stored rows, reduced over the row lanes in LDS.  LDS-only barriers:
+        // __syncthreads() also waits vmcnt(0), i.e. for the round trip of the tile's global stores just issued
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         float* red = (float*)smem;                     // [RL][BN]
 #pragma unroll
         for (int e = 0; e < EC; ++e) red[rl * BN + sch * EC + e] = csum[e];
-        __syncthreads();
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         if (tid < BN && n0 + tid < p.Nout) {
             float t = 0.f;
 #pragma unroll

@@ -173,6 +173,63 @@ __global__ void pairdist_bwd_k(const float* __restrict__ x1, const float* __rest
     }
 }
 
+// ---- contrast_loss, 'cosine' branch (percep_RBVAE_train.py:94-96): dist = 1 - cosine_similarity(x1, x2) ----------
+// torch.nn.functional.cosine_similarity: x1.x2 / (max(|x1|, eps) * max(|x2|, eps)), eps 1e-8.  One wave per row.
+__device__ __forceinline__ void row_cos(const float* a, const float* b, int L, int lane, float& dot, float& na, float& nb) {
+    float d = 0.f, sa = 0.f, sb = 0.f;
+    for (int k = lane; k < L; k += 64) {
+        d += a[k] * b[k];
+        sa += a[k] * a[k];
+        sb += b[k] * b[k];
+    }
+    dot = wave_sum(d);
+    na = sqrtf(wave_sum(sa));
+    nb = sqrtf(wave_sum(sb));
+}
+
+__global__ __launch_bounds__(RED_THREADS) void paircos_fwd_k(const float* __restrict__ x1, const float* __restrict__ x2,
+                                                             long s1, long s2, int rows, int L, int label, float margin,
+                                                             float eps, float* out) {
+    __shared__ float red[RED_THREADS / 64];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    float acc = 0.f;
+    for (int r = wid; r < rows; r += RED_THREADS / 64) {
+        float dot, na, nb;
+        row_cos(x1 + r * s1, x2 + r * s2, L, lane, dot, na, nb);
+        const float d = 1.f - dot / (fmaxf(na, eps) * fmaxf(nb, eps));
+        const float m = fmaxf(margin - d, 0.f);
+        acc += label ? m * m : d * d;
+    }
+    acc = (lane == 0) ? acc : 0.f;
+    const float tot = block_sum(acc, red);
+    if (threadIdx.x == 0) out[0] = tot / (float)rows;
+}
+
+__global__ void paircos_bwd_k(const float* __restrict__ x1, const float* __restrict__ x2, long s1, long s2, int rows, int L,
+                              int label, float margin, float eps, float scale, const float* __restrict__ gs, float* dx1,
+                              float* dx2, long ds1, long ds2) {
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    const float* a = x1 + r * s1;
+    const float* b = x2 + r * s2;
+    float dot, na, nb;
+    row_cos(a, b, L, lane, dot, na, nb);
+    const float ca = fmaxf(na, eps), cb = fmaxf(nb, eps);
+    const float cs = dot / (ca * cb), d = 1.f - cs;
+    float w = scale / (float)rows;
+    if (gs) w *= gs[0];
+    // dloss/dcos: label 0: d(d^2) = -2 d;  label 1: d(max(m - d, 0)^2) = +2 max(m - d, 0)
+    const float g = label ? 2.f * w * fmaxf(margin - d, 0.f) : -2.f * w * d;
+    // dcos/da = b / (ca cb) - [na > eps] cos a / na^2   (the clamped norm is a constant below eps)
+    const float ia = na > eps ? cs / (na * na) : 0.f, ib = nb > eps ? cs / (nb * nb) : 0.f;
+    const float inv = 1.f / (ca * cb);
+    for (int k = lane; k < L; k += 64) {
+        if (dx1) dx1[r * ds1 + k] = g * (b[k] * inv - ia * a[k]);
+        if (dx2) dx2[r * ds2 + k] = g * (a[k] * inv - ib * b[k]);
+    }
+}
+
 // ---- trainer's contrastive term, one launch --------------------------------
 __global__ __launch_bounds__(RED_THREADS) void contrast_term_fwd_k(const float* __restrict__ h0,
                                                                    const float* __restrict__ h1, int B, int T,
@@ -518,6 +575,25 @@ int rbvae_pairdist_bwd(const float* x1, const float* x2, long s1, long s2, int r
     hipLaunchKernelGGL(pairdist_bwd_k, dim3(cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, x1, x2, s1, s2,
                        rows, L, label, margin, eps, scale, gscale_dev, dx1, dx2, ds1, ds2, accumulate);
     RBVAE_CHECK_LAUNCH("pairdist_bwd");
+    return RBVAE_OK;
+}
+
+int rbvae_paircos_fwd(const float* x1, const float* x2, long s1, long s2, int rows, int L, int label, float margin,
+                      float eps, float* out, void* stream) {
+    RBVAE_CHECK_ARG(x1 && x2 && out && rows > 0 && L > 0, "paircos_fwd: bad arguments");
+    hipLaunchKernelGGL(paircos_fwd_k, dim3(1), dim3(RED_THREADS), 0, (hipStream_t)stream, x1, x2, s1, s2, rows, L, label,
+                       margin, eps, out);
+    RBVAE_CHECK_LAUNCH("paircos_fwd");
+    return RBVAE_OK;
+}
+
+int rbvae_paircos_bwd(const float* x1, const float* x2, long s1, long s2, int rows, int L, int label, float margin,
+                      float eps, float scale, const float* gscale_dev, float* dx1, float* dx2, long ds1, long ds2,
+                      void* stream) {
+    RBVAE_CHECK_ARG(x1 && x2 && rows > 0 && L > 0, "paircos_bwd: bad arguments");
+    hipLaunchKernelGGL(paircos_bwd_k, dim3(cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, x1, x2, s1, s2, rows, L,
+                       label, margin, eps, scale, gscale_dev, dx1, dx2, ds1, ds2);
+    RBVAE_CHECK_LAUNCH("paircos_bwd");
     return RBVAE_OK;
 }
 

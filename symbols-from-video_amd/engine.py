@@ -258,6 +258,9 @@ class Engine:
         self._ks_small = int(os.environ.get("RBVAE_WG_KS_SMALL", "3"))
         self._wg_nt4 = os.environ.get("RBVAE_WG_NT4", "0") == "1"
         self.fc_gemm = os.environ.get("RBVAE_FC_GEMM", "1") == "1"               # dedicated kernel for the K = 64 fc products
+        # halo-resident kernel for the transposed 3x3 / stride-2 launches (csrc/deconv_halo.hip) from this many workgroups up
+        self.deconv_halo = os.environ.get("RBVAE_DECONV_HALO", "1") == "1"
+        self._dh_min_wgs = 1024
         self.lstm_pair_bwd = os.environ.get("RBVAE_LSTM_PAIR_BWD", "1") == "1"   # both stacks' BPTT in one launch
         self.keep_dz = os.environ.get("RBVAE_KEEP_DZ", "0") == "1"                # also store the codes' gradient
         self._wg_nt4_slab = int(os.environ.get("RBVAE_WG_NT4_SLAB", "8"))     # cap on a weight's f32 slabs, M floats
@@ -533,6 +536,24 @@ class Engine:
             # the two fc products at the latent bottleneck: 0.13 GFLOP each, latency-bound (csrc/fc_gemm.hip)
             L.call("rbvae_fc_gemm", self.dt, A, W, out, bias, colsum_ws, nimg, kc, nout, lda, ldo)
             return
+        if (cls_key == "dgrad" and self.k == 3 and self.deconv_halo and sa == 1 and so == 2 and taps == 9
+                and (oh, ow) == (2 * th, 2 * tw) and (ih, iw) == (th, tw) and colsum_ws is None
+                and L.query("rbvae_deconv3x3s2_halo_tile_rows", self.dt, nimg, th, tw, kc, nout) == 128):
+            # transposed 3x3 / stride 2 (decoder forward, encoder input gradients): the four parity classes in one
+            # workgroup over an LDS-resident input patch (csrc/deconv_halo.hip).  Launches of several rounds of
+            # workgroups only: a one-round launch (the 256-frame step's 8x8 grids: 512 workgroups) runs as long as the
+            # four class launches of the gather GEMM (35 vs 34 us), measured 7-25 % faster from 1 000 workgroups up; the
+            # 128-row form only (two workgroups per CU): the 256-row form measured slower than the class launches
+            rows4 = L.query("rbvae_deconv3x3s2_halo_colsum_rows", self.dt, nimg, th, tw, kc, nout)
+            wgs = (rows4 // 4) * (nout // 64)
+            if wgs >= self._dh_min_wgs:
+                ws = None
+                if bias_grad is not None:
+                    ws = self._buf(("colsum_dh", tag), rows4 * nout)
+                    self._jobs.add(JOB_ROWS, ws, bias_grad, (1, 1, nout), (0, 0, 1), nslab=rows4, slab=nout)
+                L.call("rbvae_deconv3x3s2_halo", self.dt, A, W, out, bias, gate, mask, self.zero, nimg, th, tw, kc, nout, lda,
+                       ldo, relu, drop_mode, float(drop_p), float(scale), int(seed), seed_dev, ws)
+                return
         if cls_key == "one":
             desc, ncls = self._desc("one", ONE_TAP), 1
         elif cls_key == "conv":

@@ -101,11 +101,43 @@ class _PairDist(torch.autograd.Function):
         return da.reshape(shape), db.reshape(shape), None, None
 
 
+class _PairCos(torch.autograd.Function):
+    """contrast_loss's 'cosine' branch (percep_RBVAE_train.py:94-96): F.cosine_similarity reduces over dim 1."""
+
+    @staticmethod
+    def forward(ctx, x1, x2, label, margin):
+        _need_cuda(x1, "contrast_loss")
+        if x1.shape != x2.shape or x1.dim() < 2:
+            raise RuntimeError(f"contrast_loss: shapes {tuple(x1.shape)} and {tuple(x2.shape)}")
+        a = x1.detach().float().movedim(1, -1).contiguous()
+        b = x2.detach().float().movedim(1, -1).contiguous()
+        Ld = a.shape[-1]
+        a2, b2 = a.reshape(-1, Ld), b.reshape(-1, Ld)
+        out = torch.empty(1, device=x1.device)
+        L.call("rbvae_paircos_fwd", a2, b2, Ld, Ld, a2.shape[0], Ld, int(label), float(margin), 1e-8, out)
+        ctx.save_for_backward(a2, b2)
+        ctx.cfg = (int(label), float(margin), a.shape)
+        return out.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        a2, b2 = ctx.saved_tensors
+        label, margin, shape = ctx.cfg
+        da, db = torch.empty_like(a2), torch.empty_like(b2)
+        Ld = a2.shape[1]
+        L.call("rbvae_paircos_bwd", a2, b2, Ld, Ld, a2.shape[0], Ld, label, margin, 1e-8, 1.0,
+               g.reshape(1).float().contiguous(), da, db, Ld, Ld)
+        return da.reshape(shape).movedim(-1, 1), db.reshape(shape).movedim(-1, 1), None, None
+
+
 def contrast_loss(x1, x2, label, margin: float = 1.0, dist="euclidean"):
-    if dist != "euclidean":
-        raise NotImplementedError("only the 'euclidean' branch is on the hot path (the reference never uses 'cosine')")
+    if dist not in ("euclidean", "cosine"):
+        # the reference falls through with the string as the "distance" and fails inside torch.pow
+        raise TypeError(f"contrast_loss: dist must be 'cosine' or 'euclidean', got {dist!r}")
     if label not in (0, 1):
         raise ValueError("label must be 0 (similar) or 1 (dissimilar)")
+    if dist == "cosine":
+        return _PairCos.apply(x1, x2, label, margin)
     return _PairDist.apply(x1, x2, label, margin)
 
 
@@ -134,9 +166,13 @@ class _Triplet(torch.autograd.Function):
 
 def triplet_loss(anchor, pos, neg, margin=1.0, p=2.0, eps=1e-08, swap=True, size_average=None, reduce=None,
                  reduction="mean"):
-    if p != 2.0 or reduction != "mean":
-        raise NotImplementedError("the hot path covers p=2, reduction='mean' (what the reference trainer calls)")
-    return _Triplet.apply(anchor, pos, neg, margin, eps, swap)
+    if size_average is not None or reduce is not None:       # torch's legacy switches (F.triplet_margin_loss)
+        reduction = "mean" if (size_average in (None, True) and reduce in (None, True)) else ("sum" if reduce in (None, True) else "none")
+    if p != 2.0 or reduction not in ("mean", "sum"):
+        raise NotImplementedError("triplet_loss covers p=2 with reduction 'mean' (what the reference trainer calls, "
+                                  "triplet_RBVAE_train.py:82-96) or 'sum'")
+    out = _Triplet.apply(anchor, pos, neg, margin, eps, swap)
+    return out * _rows(anchor).shape[0] if reduction == "sum" else out
 
 
 def l1_loss(q_logits, lamb):

@@ -289,8 +289,9 @@ class FusedTrainer:
         self._set_schedule(float(temperature))
         st = self._static.get(key[:2])
         if st is None:
-            st = {"x": torch.empty(B, 2, T, C, H, W, device=self.dev),
-                  "U": torch.empty(2 * B * T, Ld, device=self.dev)}
+            # zeros, not empty: in set_data mode the capture's warm-up steps run before the first batch is gathered
+            st = {"x": torch.zeros(B, 2, T, C, H, W, device=self.dev),
+                  "U": torch.zeros(2 * B * T, Ld, device=self.dev)}
             self._static[key[:2]] = st
         if item.data_ptr() != st["x"].data_ptr() or not item.is_contiguous():
             st["x"].copy_(item)          # skipped when the caller fills input_buffer() in place
@@ -434,7 +435,11 @@ class FusedTrainer:
         if "seed" in sd:
             self.seed = int(sd["seed"])
             self._noise_key = noise_key(self.seed, self.rank)
-            self._graphs.clear()          # the noise key is a by-value kernel argument of the captured launches
+        # betas / eps / the noise key are by-value arguments of the captured launches (the update job table is keyed by
+        # them and rebuilt by the next capture's warm-up steps); the static input buffer holds the batch gathered for the OLD step counter: drop every captured graph
+        # and re-prime (a bare torch.optim.Adam state_dict with other betas would otherwise be ignored by the graphs)
+        self._graphs.clear()
+        self._primed = False
         self.steps = int(sd.get("steps", int(self.step_dev.item())))
 
     def set_data(self, table: torch.Tensor, plan: torch.Tensor):
@@ -455,8 +460,8 @@ class FusedTrainer:
         nb, B, _, T = plan.shape
         flat = plan.reshape(nb, B * 2 * T).to(self.dev).contiguous()
         old = self._data
-        if old is not None and old[0].data_ptr() == table.data_ptr() and old[1].shape == flat.shape:
-            old[1].copy_(flat)
+        if old is not None and old[0].data_ptr() == table.data_ptr() and old[1].shape == flat.shape and old[2:] == (B, T):
+            old[1].copy_(flat)                   # same table, same batch geometry: the captured graphs stay
         else:
             self._data = (table, flat, B, T)
             self._graphs = {k: g for k, g in self._graphs.items() if not k[4]}
@@ -469,8 +474,8 @@ class FusedTrainer:
         step() saves the device-to-device copy of the batch."""
         st = self._static.get((B, T))
         if st is None:
-            st = {"x": torch.empty(B, 2, T, C, H, W, device=self.dev),
-                  "U": torch.empty(2 * B * T, self.model.latent_dim, device=self.dev)}
+            st = {"x": torch.zeros(B, 2, T, C, H, W, device=self.dev),
+                  "U": torch.zeros(2 * B * T, self.model.latent_dim, device=self.dev)}
             self._static[(B, T)] = st
         return st["x"]
 

@@ -46,8 +46,10 @@ def test_on_the_fly_triplet_step_matches_oracles_f32():
     got = pipe.step(frames.cuda(), tau, eps=eps.cuda(), U=U.cuda()).cpu().tolist()
     buf = tr.input_buffer(B, T, 4, *lat_hw)
     assert float((buf.cpu() - lat).abs().max()) < 2e-4                      # the latents landed in the step's buffer
-    # the RBVAE half is checked on the latents the device produced, under the device's own ReLU decisions (_gates.py)
-    from _gates import count_ties, device_gates
+    # the RBVAE half is checked on the latents the device produced, under the device's own ReLU decisions (symbols-from-video_amd/_gates.py)
+    from importlib import import_module
+    _g = import_module("symbols-from-video_amd._gates")
+    count_ties, device_gates = _g.count_ties, _g.device_gates
     gates, pre = device_gates(tr, B, T), []
     ref = O.step_losses("percep", params, buf.cpu(), [U[0], U[1]], tau, r, p, alpha, beta, margin, pair_loss="triplet",
                         gates=gates, pre=pre)
@@ -97,3 +99,44 @@ def test_on_the_fly_bf16_graph_runs_and_tracks():
     assert float((tr.input_buffer(B, T, 4, *lat_hw).cpu() - lat).norm() / lat.norm()) < 5e-2
     with pytest.raises(ValueError):
         pipe.step(torch.zeros(1, 2, 3, 3, 128, 128, device="cuda"), 0.7)
+
+
+@pytest.mark.timeout(900)
+def test_cfg5_at_512x512_frames():
+    """BASELINE configs[4] at its stated size: 512x512 frames through LDMEncoder.encode -- the halo
+    convolutions with fused GroupNorm at 512/256/128/64-pixel images, the asymmetric-pad downsamples and the 4096-token
+    mid-block attention -- into the triplet-trained percep RBVAE on 4x64x64 latents (get_percep_embeddings.py:101-103,
+    triplet_RBVAE_train.py:461-468).  Properties: the encoder's chunking does not change a latent (ragged chunks of 3
+    against all frames at once), one frame's latent sits within 5e-2 of the f32 oracle encoder's, and the pipeline's
+    steps stay finite with a falling loss."""
+    import sfv_amd as sfv
+    torch.manual_seed(80)
+    enc = sfv.LDMEncoder(compute_dtype="bf16")
+    enc_params = {k: v.clone() for k, v in enc.state_dict().items()}
+    enc = enc.cuda()
+    torch.manual_seed(81)
+    m = sfv.Seq2SeqBinaryVAE(4, 4, 32, 32, variant="percep", input_hw=(64, 64), compute_dtype="bf16").cuda().train()
+    tr = sfv.FusedTrainer(m, lr=1e-3, alpha=1.0, beta_kl=1.0, bernoulli_p=0.1, margin=0.2, device_noise=True,
+                          use_graph=True, pair_loss="triplet", seed=2)
+    B, T = 1, 2
+    g = torch.Generator().manual_seed(82)
+    # smooth frames (a few low-frequency waves + noise): closer to video than white noise, same for device and oracle
+    yy, xx = torch.meshgrid(torch.linspace(0, 1, 512), torch.linspace(0, 1, 512), indexing="ij")
+    base = torch.stack([torch.sin(6.3 * (k + 1) * xx + k) * torch.cos(4.1 * (k + 2) * yy) for k in range(3)])
+    frames = (0.6 * base[None, None, None] + 0.25 * torch.randn(B, 2, T, 3, 512, 512, generator=g)).clamp(-1, 1)
+    dev_frames = frames.cuda()
+    # (a) chunking: 4 frames as 3 + 1 == all at once
+    flat = dev_frames.reshape(-1, 3, 512, 512)
+    whole = enc.encode(flat, sample=False)
+    pipe = sfv.OnTheFlyLatentTrainer(enc, tr, frames_per_chunk=3)
+    buf = pipe.encode_into(dev_frames, sample=False)
+    assert tuple(buf.shape) == (B, 2, T, 4, 64, 64)
+    assert torch.equal(buf.reshape(-1, 4, 64, 64), whole)
+    # (b) one frame against the oracle encoder (f32 on the CPU; bf16 storage on the device)
+    with torch.no_grad():
+        ref = LO.encode(enc_params, frames.reshape(-1, 3, 512, 512)[:1], None)
+    rel = float((whole[:1].cpu() - ref).norm() / ref.norm())
+    assert rel < 5e-2, rel
+    # (c) the pipeline trains: finite, falling
+    hist = [pipe.step(dev_frames, 0.7, sample=False)[0].item() for _ in range(8)]
+    assert all(abs(h) < 1e4 for h in hist) and hist[-1] < hist[0], hist

@@ -134,3 +134,28 @@ def test_device_majority_vote_equals_np_unique(F, L, n_states):
     ravg, rpct = O.state_consistency(codes.numpy(), labels, n_states)
     assert abs(avg - ravg) < 1e-12 and np.allclose(pct, rpct), (pct, rpct)
     assert pct[n_states - 1] == 0.0
+
+
+def test_set_data_rebuilds_when_the_batch_geometry_changes():
+    """a new plan with the same number of rows per batch but another (B, T) must not be copied into the old
+    plan buffer (the trainer would keep stepping with the old item shape)."""
+    import sfv_amd as sfv
+    torch.manual_seed(1)
+    m = sfv.Seq2SeqBinaryVAE(4, 4, 16, 16, variant="percep", input_hw=(16, 16), compute_dtype="f32").cuda().train()
+    tr = sfv.FusedTrainer(m, device_noise=True, use_graph=True, seed=2)
+    table = torch.randn(64, 4, 16, 16, device="cuda")
+    g = torch.Generator().manual_seed(3)
+    plan_a = torch.randint(0, 64, (3, 4, 2, 2), generator=g)          # B = 4, T = 2: 16 rows per batch
+    plan_b = torch.randint(0, 64, (3, 2, 2, 4), generator=g)          # B = 2, T = 4: 16 rows per batch too
+    tr.set_data(table, plan_a)
+    tr.step(None, 0.7)
+    assert tr._data[2:] == (4, 2)
+    tr.set_data(table, plan_b)
+    assert tr._data[2:] == (2, 4) and torch.equal(tr._data[1].cpu(), plan_b.reshape(3, 16))
+    tr.step(None, 0.7)
+    assert tr.input_buffer(2, 4, 4, 16, 16).shape == (2, 2, 4, 4, 16, 16) and bool(torch.isfinite(tr.losses).all())
+    # same geometry again: the plan is copied in place, the graphs stay
+    n_graphs = len(tr._graphs)
+    buf = tr._data[1].data_ptr()
+    tr.set_data(table, torch.randint(0, 64, (3, 2, 2, 4), generator=g))
+    assert tr._data[1].data_ptr() == buf and len(tr._graphs) == n_graphs

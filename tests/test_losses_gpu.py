@@ -178,3 +178,34 @@ def test_contrast_term_fused_matches_two_launch_form(L):
         L.call("rbvae_combine_losses", None, 0, 0.0, one, one, 0, 0.0, parts, n, 1.0 / (B * T), 1.0 / (B * (T - 1)), 1.0, 1.0,
                out4, None, 0.0, None, 0.0, 0.0, None)
         assert abs(out4[3].item() - ref.item()) < 1e-5 * max(1.0, abs(ref.item()))
+
+
+def test_contrast_loss_cosine_branch_and_triplet_sum():
+    """contrast_loss(dist='cosine') (percep_RBVAE_train.py:94-96: 1 - F.cosine_similarity, then the same two loss forms)
+    and triplet_loss(reduction='sum') against plain torch on the CPU.  The reference's trainers never take these
+    branches, so no fixture of the reference covers them: parity is pinned to torch's own functions (the reference's
+    call is exactly F.cosine_similarity(x1, x2) / F.triplet_margin_loss), not to a reference run."""
+    import torch.nn.functional as F
+    import sfv_amd as sfv
+    gen = torch.Generator().manual_seed(21)
+    for shape in ((6, 32), (5, 25), (3, 7, 16)):               # 3-D: cosine_similarity reduces over dim 1 like torch
+        for label in (0, 1):
+            x1 = torch.randn(*shape, generator=gen).requires_grad_()
+            x2 = (torch.randn(*shape, generator=gen) + 0.3).requires_grad_()
+            d = 1 - F.cosine_similarity(x1, x2)
+            ref = ((1 - label) * d.pow(2) + label * torch.clamp(0.8 - d, min=0.0).pow(2)).mean()
+            g1, g2 = torch.autograd.grad(ref * 1.5, (x1, x2))
+            a, b = x1.detach().cuda().requires_grad_(), x2.detach().cuda().requires_grad_()
+            got = sfv.losses.contrast_loss(a, b, label, margin=0.8, dist="cosine")
+            assert abs(got.item() - ref.item()) < 2e-6 * max(1.0, abs(ref.item()))
+            (got * 1.5).backward()
+            np.testing.assert_allclose(a.grad.cpu().numpy(), g1.numpy(), atol=2e-6)
+            np.testing.assert_allclose(b.grad.cpu().numpy(), g2.numpy(), atol=2e-6)
+    with pytest.raises(TypeError):
+        sfv.losses.contrast_loss(a, b, 0, dist="manhattan")
+    a, p, n = (torch.randn(7, 20, generator=gen) for _ in range(3))
+    ref = F.triplet_margin_loss(a, p, n, margin=0.2, p=2, eps=1e-8, swap=True, reduction="sum")
+    got = sfv.losses.triplet_loss(a.cuda(), p.cuda(), n.cuda(), margin=0.2, reduction="sum")
+    assert abs(got.item() - ref.item()) < 1e-5
+    with pytest.raises(NotImplementedError):
+        sfv.losses.triplet_loss(a.cuda(), p.cuda(), n.cuda(), p=1.0)

@@ -137,11 +137,13 @@ def test_bf16_mode_tracks_f32(sfv, name):
         ref = float(g[f"loss/{k}"])
         assert abs(res[k].item() - ref) < 2e-2 * max(abs(ref), 1.0), (k, res[k].item(), ref)
     # Gradients -- direction, not just norm: the same case through the fused trainer (which exposes the device's ReLU
-    # decisions, tests/_gates.py) against the f64 oracle under those decisions, every tensor by relative L2.  bf16
+    # decisions, symbols-from-video_amd/_gates.py) against the f64 oracle under those decisions, every tensor by relative L2.  bf16
     # storage resolves thousands of ReLU ties differently from an f32 run; against a reference that does not share them
     # a 128-element LSTM bias of norm 1e-6 moves by 30 % (measured), which says nothing about the kernels.
     from importlib import import_module
-    from _gates import count_ties, device_gates
+    from importlib import import_module
+    _g = import_module("symbols-from-video_amd._gates")
+    count_ties, device_gates = _g.count_ties, _g.device_gates
     FusedTrainer = import_module("symbols-from-video_amd.trainer").FusedTrainer
     _, m2 = build(sfv, g, dtype="bf16")
     m2.train(train)

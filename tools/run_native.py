@@ -4,7 +4,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, sfv_amd as sfv
 from importlib import import_module
 FusedTrainer = import_module("symbols-from-video_amd.trainer").FusedTrainer
-for dtype in ("bf16", "f32"):
+import sys
+for dtype in (sys.argv[1:] or ["bf16", "f32"]):
     torch.manual_seed(0)
     m = sfv.Seq2SeqBinaryVAE(4, 4, 32, 32, variant="percep", compute_dtype=dtype).cuda().train()
     item = torch.randn(8, 2, 8, 4, 88, 160, device="cuda")
