@@ -83,7 +83,7 @@ __device__ __forceinline__ unsigned ch_plane_off(int chunk) { return (unsigned)(
 template <typename T, int RING> constexpr int ch_lds_main() {
     constexpr int ES = sizeof(T);
     constexpr int ring = 2 * CH_ABUF + RING * CH_BBYTES;
-    constexpr int epi = CH_BM * (CH_BN * ES + 16) + (512 / (CH_BN / (16 / ES))) * CH_BN * 4 + 512;
+    constexpr int epi = CH_BM * (CH_BN * ES + 16);          // (the statistics scratch reuses the tile)
     return ring > epi ? ring : epi;
 }
 
@@ -123,9 +123,8 @@ __global__ __launch_bounds__(512) void conv_halo_k(const ChArgs p) {
     constexpr int CPR = CH_BN / EC;              // 16-B chunks per tile row
     constexpr int RL = 512 / CPR;                // row lanes of the store phase
     constexpr int ITERS = CH_BM / RL;
-    constexpr int RED_BYTES = RL * CH_BN * 4 + 512;      // statistics scratch behind the epilogue tile
     constexpr int RINGB = ch_lds_main<T, RING>();
-    static_assert(CH_BM * PITCH + RED_BYTES <= RINGB && A_BYTES + RING * CH_BBYTES <= RINGB, "LDS carve");
+    static_assert(CH_BM * PITCH <= RINGB && A_BYTES + RING * CH_BBYTES <= RINGB, "LDS carve");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     int* s_orow = (int*)(smem + RINGB);            // [256]
     int* s_pix = s_orow + CH_BM;                   // [336]
@@ -443,90 +442,123 @@ __global__ __launch_bounds__(512) void conv_halo_k(const ChArgs p) {
     }
     ch_lds_barrier();
 
-    // ---- store phase: whole 16-B chunks of NHWC rows (+ residual); the stored values stay in the LDS tile for the statistics
+    // ---- store phase: whole 16-B chunks of NHWC rows (+ residual).  The residual chunks of all eight passes are fetched
+    // before the first is used and the stores go out back to back (a load -> add -> store chain per pass left one
+    // round trip exposed per pass).
     const int sch = tid % CPR, rl = tid / CPR;
     const int scol = n0 + sch * EC;
-    float csum[EC];
+    int orow_[ITERS];
+    u32x4_t av[ITERS], vals[ITERS];
 #pragma unroll
-    for (int e = 0; e < EC; ++e) csum[e] = 0.f;
+    for (int it = 0; it < ITERS; ++it) {
+        orow_[it] = s_orow[it * RL + rl];
+        if (p.addend) av[it] = *(const u32x4_t*)(p.addend + ((size_t)(orow_[it] < 0 ? 0 : orow_[it]) * p.ldo + scol) * ES);
+    }
 #pragma unroll
     for (int it = 0; it < ITERS; ++it) {
         const int row = it * RL + rl;
-        const int orow = s_orow[row];
-        if (orow >= 0) {
-            u32x4_t val = *(const u32x4_t*)(tile + row * PITCH + sch * 16);
+        u32x4_t val = *(const u32x4_t*)(tile + row * PITCH + sch * 16);
+        if (p.addend) {
             T* ev = (T*)&val;
-            if (p.addend) {
-                const u32x4_t a4 = *(const u32x4_t*)(p.addend + ((size_t)orow * p.ldo + scol) * ES);
-                const T* ae = (const T*)&a4;
+            const T* ae = (const T*)&av[it];
 #pragma unroll
-                for (int e = 0; e < EC; ++e) Elem<T>::store(ev + e, Elem<T>::load(ev + e) + Elem<T>::load(ae + e));
-                if (p.stats) *(u32x4_t*)(tile + row * PITCH + sch * 16) = val;
-            }
-            *(u32x4_t*)(p.Out + ((size_t)orow * p.ldo + scol) * ES) = val;
-            if (p.stats) {
-#pragma unroll
-                for (int e = 0; e < EC; ++e) csum[e] += Elem<T>::load(ev + e);
-            }
+            for (int e = 0; e < EC; ++e) Elem<T>::store(ev + e, Elem<T>::load(ev + e) + Elem<T>::load(ae + e));
         }
+        vals[it] = val;
+        if (orow_[it] >= 0) *(u32x4_t*)(p.Out + ((size_t)orow_[it] * p.ldo + scol) * ES) = val;
     }
     if (p.stats) {
-        // GroupNorm partial statistics of the stored tile: per group (cg consecutive channels) the tile's mean and the
-        // sum of squared deviations from it (two passes over the LDS tile: as stable as torch's), merged across tiles
-        // by gn_finish_tiles_k with the parallel-variance formula.  Pass 1: channel sums -> group means.
-        ch_lds_barrier();
-        float* red = (float*)(smem + CH_BM * PITCH);      // [RL][BN] channel sums, then [BN / cg] group means
-        const int cg = p.stats_cg, ng = CH_BN / cg;
+        // GroupNorm partial statistics of the STORED tile, per group of cg consecutive channels: the tile's mean and its sum
+        // of squared deviations from that mean (gn_finish_tiles_k merges tiles with the parallel-variance formula).  Every
+        // thread reduces its own rows (two passes over its registers: exact mean first), then the partials (count, sum,
+        // M2) merge over the row lanes and over a group's channels by the same formula: as stable as torch's two passes.
+        float sum[EC], m2[EC];
+        int cnt = 0;
 #pragma unroll
-        for (int e = 0; e < EC; ++e) red[rl * CH_BN + sch * EC + e] = csum[e];
-        // number of valid pixels of the tile (the same for every channel)
-        const int vr = min(CH_T, p.OH - r0), vc = min(CH_T, p.OW - c0);
-        const float cnt = (float)(vr * vc) * (float)cg;
-        ch_lds_barrier();
-        float* gmean = red + RL * CH_BN;
-        if (tid < CH_BN) {
-            float t = 0.f;
-            for (int k = 0; k < RL; ++k) t += red[k * CH_BN + tid];
-            red[tid] = t;                                  // row 0 := channel totals (each thread its own column)
-        }
-        ch_lds_barrier();
-        if (tid < ng) {
-            float t = 0.f;
-            for (int c = 0; c < cg; ++c) t += red[tid * cg + c];
-            gmean[tid] = t / cnt;
-        }
-        ch_lds_barrier();
-        // pass 2: squared deviations from the group mean
-#pragma unroll
-        for (int e = 0; e < EC; ++e) csum[e] = 0.f;
-        float gm[EC];
-#pragma unroll
-        for (int e = 0; e < EC; ++e) gm[e] = gmean[(sch * EC + e) / cg];
+        for (int e = 0; e < EC; ++e) { sum[e] = 0.f; m2[e] = 0.f; }
 #pragma unroll
         for (int it = 0; it < ITERS; ++it) {
-            const int row = it * RL + rl;
-            if (s_orow[row] >= 0) {
-                const u32x4_t val = *(const u32x4_t*)(tile + row * PITCH + sch * 16);
-                const T* ev = (const T*)&val;
+            if (orow_[it] >= 0) {
+                ++cnt;
+                const T* ev = (const T*)&vals[it];
 #pragma unroll
-                for (int e = 0; e < EC; ++e) { const float d = Elem<T>::load(ev + e) - gm[e]; csum[e] += d * d; }
+                for (int e = 0; e < EC; ++e) sum[e] += Elem<T>::load(ev + e);
             }
         }
-        ch_lds_barrier();
+        const float inv = cnt ? 1.f / (float)cnt : 0.f;
 #pragma unroll
-        for (int e = 0; e < EC; ++e) red[rl * CH_BN + sch * EC + e] = csum[e];
+        for (int it = 0; it < ITERS; ++it) {
+            if (orow_[it] >= 0) {
+                const T* ev = (const T*)&vals[it];
+#pragma unroll
+                for (int e = 0; e < EC; ++e) { const float d = Elem<T>::load(ev + e) - sum[e] * inv; m2[e] += d * d; }
+            }
+        }
+        // merge over the row lanes of a wave (bf16: lanes l, l+16, l+32, l+48 hold the same channels; f32: l, l+32) in
+        // registers ...
+        float fcnt = (float)cnt;
+#pragma unroll
+        for (int off = CPR; off <= 32; off <<= 1) {
+            const float ocnt = __shfl_xor(fcnt, off, 64);
+            const float ncnt = fcnt + ocnt;
+            const float wgt = ncnt > 0.f ? fcnt * ocnt / ncnt : 0.f;
+            const float ia = fcnt > 0.f ? 1.f / fcnt : 0.f, ib = ocnt > 0.f ? 1.f / ocnt : 0.f;
+#pragma unroll
+            for (int e = 0; e < EC; ++e) {
+                const float osum = __shfl_xor(sum[e], off, 64), om2 = __shfl_xor(m2[e], off, 64);
+                const float d = osum * ib - sum[e] * ia;
+                m2[e] = m2[e] + om2 + d * d * wgt;
+                sum[e] += osum;
+            }
+            fcnt = ncnt;
+        }
+        ch_lds_barrier();                                  // every thread has read its tile rows: the tile's LDS is scratch now
+        // ... then over the eight waves and over a group's channels through LDS
+        float* r_sum = (float*)smem;                       // [8 waves][BN]
+        float* r_m2 = r_sum + 8 * CH_BN;                   // [8][BN]
+        float* r_cnt = r_m2 + 8 * CH_BN;                   // [8]
+        float* c_mean = r_cnt + 8;                         // [BN] channel means, then [BN] channel M2
+        float* c_m2 = c_mean + CH_BN;
+        static_assert(CPR == 16 || CPR == 32, "row-lane merge above: 16 (bf16) or 32 (f32) chunk columns per row");
+        if (lane < CPR) {
+#pragma unroll
+            for (int e = 0; e < EC; ++e) {
+                r_sum[w * CH_BN + sch * EC + e] = sum[e];
+                r_m2[w * CH_BN + sch * EC + e] = m2[e];
+            }
+            if (lane == 0) r_cnt[w] = fcnt;
+        }
         ch_lds_barrier();
+        const int cg = p.stats_cg, ng = CH_BN / cg;
         if (tid < CH_BN) {
-            float t = 0.f;
-            for (int k = 0; k < RL; ++k) t += red[k * CH_BN + tid];
-            red[tid] = t;                                  // its own column only
+            float S = 0.f, N = 0.f;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { S += r_sum[k * CH_BN + tid]; N += r_cnt[k]; }
+            const float mean = N > 0.f ? S / N : 0.f;
+            float M2 = 0.f;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const float nk = r_cnt[k];
+                const float d = nk > 0.f ? r_sum[k * CH_BN + tid] / nk - mean : 0.f;
+                M2 += r_m2[k * CH_BN + tid] + nk * d * d;
+            }
+            c_mean[tid] = mean;
+            c_m2[tid] = M2;
+            if (tid == 0) c_m2[CH_BN] = N;
         }
         ch_lds_barrier();
         if (tid < ng) {
-            float t = 0.f;
-            for (int c = 0; c < cg; ++c) t += red[tid * cg + c];
+            const float N = c_m2[CH_BN];
+            float gm = 0.f;
+            for (int c = 0; c < cg; ++c) gm += c_mean[tid * cg + c];
+            gm /= (float)cg;
+            float gM2 = 0.f;
+            for (int c = 0; c < cg; ++c) {
+                const float d = c_mean[tid * cg + c] - gm;
+                gM2 += c_m2[tid * cg + c] + N * d * d;
+            }
             const int G = p.Nout / cg;
-            ((float2*)p.stats)[(size_t)mtile * G + n0 / cg + tid] = make_float2(gmean[tid], t);
+            ((float2*)p.stats)[(size_t)mtile * G + n0 / cg + tid] = make_float2(gm, gM2);
         }
     }
 }

@@ -54,13 +54,30 @@ def _regs(text):
     return used
 
 
+def _mark_asm(body):
+    """kernel text with ' @asm' appended to the instructions between ;;#ASMSTART and ;;#ASMEND"""
+    marked, inasm = [], False
+    for raw in body.splitlines():
+        if "#ASMSTART" in raw:
+            inasm = True
+            continue
+        if "#ASMEND" in raw:
+            inasm = False
+            continue
+        code = raw.split(";")[0].rstrip()
+        marked.append(code + " @asm" if (inasm and code.strip()) else raw)
+    return "\n".join(marked)
+
+
 def tr_asm_hazards(asm_text, kernel_prefix="_ZN5rbvae12wgrad_gemm_k", read_ops=("ds_read_b64_tr_b16",)):
     """Returns a list of 'kernel: message' strings (empty = clean).  Forward data flow over the kernel's CFG;
-    the state is the in-order queue of in-flight reads (each a set of destination registers), one visit per
-    (block, state)."""
+    the state is the in-order queue of in-flight LDS operations, one visit per (block, state).  Only the reads issued
+    as inline asm carry registers (the compiler waits for its own reads itself); every other LDS operation -- the
+    compiler's reads and writes -- takes a register-less place in the queue, so a compiler wait such as lgkmcnt(4)
+    behind five of its own reads is read for what it covers."""
     out = []
     for m in re.finditer(r"^(" + re.escape(kernel_prefix) + r"\w+):.*?s_endpgm", asm_text, re.S | re.M):
-        blocks, succ = _blocks(m.group(0))
+        blocks, succ = _blocks(_mark_asm(m.group(0)))
         seen, work, msgs = set(), [("^", ())], set()
         while work:
             name, state = work.pop()
@@ -71,8 +88,10 @@ def tr_asm_hazards(asm_text, kernel_prefix="_ZN5rbvae12wgrad_gemm_k", read_ops=(
                 msgs.add("state explosion: check aborted"); break
             reads = list(state)
             for ln in blocks[name]:
+                asm = ln.endswith("@asm")
+                ln = ln.replace(" @asm", "")
                 op, _, rest = ln.partition(" ")
-                if op in read_ops:
+                if op in read_ops and asm:
                     dst, _, addr = rest.partition(",")
                     pending = set().union(*reads) if reads else set()
                     if _regs(addr) & pending:
@@ -84,19 +103,20 @@ def tr_asm_hazards(asm_text, kernel_prefix="_ZN5rbvae12wgrad_gemm_k", read_ops=(
                     continue
                 if op == "s_waitcnt" and "lgkmcnt" in rest:
                     n = int(re.search(r"lgkmcnt\((\d+)\)", rest).group(1))
-                    # LDS returns in order: at most the n youngest operations are still outstanding (other
-                    # LGKM operations in between only make this more conservative)
+                    # LDS returns in order: at most the n youngest operations are still outstanding
                     reads = reads[len(reads) - n:] if n else []
                     continue
                 if reads:
                     hit = _regs(rest) & set().union(*reads)
                     if hit:
                         msgs.add(f"touches in-flight v{sorted(hit)}: {ln}")
+                if op.startswith("ds_"):
+                    reads.append(frozenset())          # a compiler LDS operation: a place in the queue, no registers
+                    reads = reads[-15:]
             for nx in succ[name]:
                 work.append((nx, tuple(reads)))
         out += [f"{m.group(1)}: {x}" for x in sorted(msgs)]
     return out
-
 
 
 _VM_OPS = ("global_load", "global_store", "global_atomic", "buffer_load", "buffer_store", "buffer_atomic", "scratch_load",
@@ -110,17 +130,7 @@ def asm_vmem_load_hazards(asm_text, kernel_prefix, load_op="global_load_dwordx4"
     only the asm loads carry registers."""
     out = []
     for m in re.finditer(r"^(" + re.escape(kernel_prefix) + r"\w+):.*?s_endpgm", asm_text, re.S | re.M):
-        # mark asm regions line by line, then run the CFG walk on (instruction, in_asm) pairs
-        body, marked, inasm = m.group(0), [], False
-        for raw in body.splitlines():
-            if "#ASMSTART" in raw:
-                inasm = True
-                continue
-            if "#ASMEND" in raw:
-                inasm = False
-                continue
-            marked.append(raw + (" ;@asm" if inasm else ""))
-        blocks, succ = _blocks("\n".join(marked).replace(" ;@asm", " @asm"))
+        blocks, succ = _blocks(_mark_asm(m.group(0)))
         seen, work, msgs = set(), [("^", ())], set()
         while work:
             name, state = work.pop()

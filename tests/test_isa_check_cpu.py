@@ -12,8 +12,15 @@ spec.loader.exec_module(isa_check)
 PFX = "_ZN5rbvae12wgrad_gemm_k"
 
 
-def kernel(body):
-    return f"{PFX}ItLi2ELi3EEEvNS_6WgArgsE:\n" + body + "\n\ts_endpgm\n"
+def kernel(body, asm_ops=("ds_read_b64_tr_b16",)):
+    """the fragment reads as the kernels issue them: inline asm (between the compiler's ;;#ASMSTART / ;;#ASMEND marks)"""
+    lines = []
+    for ln in body.splitlines():
+        if ln.strip().split(" ")[0] in asm_ops:
+            lines += ["\t;;#ASMSTART", ln, "\t;;#ASMEND"]
+        else:
+            lines.append(ln)
+    return f"{PFX}ItLi2ELi3EEEvNS_6WgArgsE:\n" + "\n".join(lines) + "\n\ts_endpgm\n"
 
 
 def check(body):
@@ -126,3 +133,21 @@ def test_asm_vmem_load_check_flags_a_copy_before_the_wait():
             "\t;;#ASMSTART\n\tglobal_load_dwordx4 v[10:13], v[2:3], off\n\t;;#ASMEND\n"
             "\ts_cbranch_scc1 .LBB0_1\n\ts_endpgm\n")
     assert any("v_mov_b32_e32 v30, v10" in m for m in ic.asm_vmem_load_hazards(loop, "_ZN5rbvae11conv_halo_k"))
+
+
+def test_compiler_reads_take_a_place_in_the_queue_but_carry_no_registers():
+    """a compiler-issued LDS read (outside the asm marks) is the compiler's to wait for: its counted wait behind a mix of
+    its own reads is read for what it covers, and its destination is never 'in flight' for this check"""
+    body = """
+	ds_read_b128 v[14:17], v19 offset:16384
+	ds_read_b32 v21, v1
+	ds_read_b128 v[10:13], v19 offset:16400
+	s_waitcnt lgkmcnt(2)
+	v_add_u32_e32 v18, v15, v14
+"""
+    assert isa_check.tr_asm_hazards(kernel(body, asm_ops=()), PFX, ("ds_read_b128",)) == []
+    # the same first read as inline asm, waited for one operation short: flagged
+    bad = isa_check.tr_asm_hazards(kernel(body.replace("lgkmcnt(2)", "lgkmcnt(3)"), asm_ops=("ds_read_b128",)), PFX, ("ds_read_b128",))
+    assert any("touches in-flight" in b for b in bad)
+    # ... and with the exact count it is clean (the ds_read_b32 between them holds its place in the in-order queue)
+    assert isa_check.tr_asm_hazards(kernel(body, asm_ops=("ds_read_b128",)), PFX, ("ds_read_b128",)) == []
