@@ -167,16 +167,6 @@ int rbvae_fc_gemm_ok(int dtype, int M, int K, int N, int lda, int ldo);
 int rbvae_fc_gemm(int dtype, const void* A, const void* W, void* Out, const float* bias, float* colsum_ws, int M, int K,
                   int N, int lda, int ldo, void* stream);
 
-/* ---- row-streaming GEMM with resident weights (bf16, K = 64) ---------------------------------
- * Out[m][n] = epi( sum_{k<64} A[m][k] * W[n][k] ) for the HBM-bound 3/4-channel ends of the CNNs: the first
- * Conv2d forward on its im2col matrix (percep_RBVAE_model.py:51) and the last ConvTranspose2d's input gradient
- * (autograd of :82).  Same epilogue, element for element, as rbvae_gather_gemm (bias, relu, scale, keyed dropout
- * drop_mode 1, gate); colsum_ws [rbvae_stream_gemm_blocks(M)][Nout] receives per-workgroup column sums. */
-int rbvae_stream_gemm_blocks(int M);
-int rbvae_stream_gemm(const void* A, const void* W, void* Out, const float* bias, const void* gate, int M, int Nout,
-                      int ldo, int relu, int drop_mode, float drop_p, float scale, unsigned long long seed,
-                      const unsigned long long* seed_dev, float* colsum_ws, void* stream);
-
 /* ---- weight-gradient GEMM ---------------------------------------------------------
  * dW[ks][co][t][ci] = sum over K-slice ks of Dy[p][co] * In[idx[t][p]][ci]  (f32 slabs, one per
  * K-slice; sum them with rbvae_permute_reduce).  idx = rbvae_conv_gather_index table or NULL

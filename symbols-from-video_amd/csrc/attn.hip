@@ -182,7 +182,7 @@ static int launch_attn_bq(const void* Q, const void* K, const void* V, void* O, 
 template <int D>
 static int launch_attn(const void* Q, const void* K, const void* V, void* O, int N, int hw, int ldq, int ldk, int ldv,
                        int ldo, float scale, hipStream_t st) {
-    static const int bq = getenv("RBVAE_ATTN_BQ") ? atoi(getenv("RBVAE_ATTN_BQ")) : 64;
+    constexpr int bq = 64;
     if (bq == 128) return launch_attn_bq<D, 128>(Q, K, V, O, N, hw, ldq, ldk, ldv, ldo, scale, st);
     return launch_attn_bq<D, 64>(Q, K, V, O, N, hw, ldq, ldk, ldv, ldo, scale, st);
 }

@@ -579,7 +579,7 @@ static int dh_tile_rows(int dtype, int Nimg, int TH, int TW, int Kc, int Nout) {
     const int sc = dh_strip_cols(TW);
     if (!sc) return 0;
     if ((long)Nimg * (TW / sc) >= (1l << 19)) return 0;          // strip index in 19 bits of the patch-row table
-    static const int force = getenv("RBVAE_DH_BM") ? atoi(getenv("RBVAE_DH_BM")) : 0;
+    constexpr int force = 0;
     if (force != 256 && dh_max_patch_rows(TH, 128 / sc) <= 176 / (sc + 1)) return 128;
     if (force != 128 && dh_max_patch_rows(TH, 256 / sc) <= (sc == 16 ? 320 : sc == 8 ? 352 : 416) / (sc + 1)) return 256;
     return 0;

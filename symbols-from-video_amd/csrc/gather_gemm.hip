@@ -601,24 +601,24 @@ static int launch_gg(const GgArgs& a, hipStream_t st) {
 template <typename T>
 static int dispatch_gg(const GgArgs& a, hipStream_t st, int max_steps) {
     const long blocks = (long)cdiv(a.Nimg * a.TH * a.TW, GG_BM) * cdiv(a.Nout, a.Nout > 64 ? 128 : 64) * a.nclass;
-    static const int force = getenv("RBVAE_GG_NS") ? atoi(getenv("RBVAE_GG_NS")) : 0;
-    static const int dbg = getenv("RBVAE_GG_DBG") ? atoi(getenv("RBVAE_GG_DBG")) : 0;
+    constexpr int force = 0;
+    constexpr int dbg = 0;
     int ns = max_steps <= 2 ? 1 : (blocks > 256 ? 2 : 3);
     if (force) ns = force;
     if (a.Nout <= 64) return ns == 1 ? launch_gg<T, 2, 4, 1>(a, st) : launch_gg<T, 2, 4, 2>(a, st);
     // deep-K problems with too few 128x128 tiles for the 256 CUs: narrower tiles (more workgroups, shorter steps)
-    static const int small = getenv("RBVAE_GG_SMALL") ? atoi(getenv("RBVAE_GG_SMALL")) : 2;
+    constexpr int small = 2;
     if (ns == 3 && !force && !dbg && small) {
         // 64 x 64 tiles for the 64-block problems (conv3 forward, first deconv's input gradient at 256 frames): the same
         // 256 workgroups as 128 x 32 tiles at 16 KB instead of 20 KB of operands per K step.  The fused column sums keep
         // the 128-row tiles (their partial-sum rows are counted in 128-row tiles by the callers); xcd_order too.
-        static const int sq = getenv("RBVAE_GG_SQUARE") ? atoi(getenv("RBVAE_GG_SQUARE")) : 1;
+        constexpr int sq = 1;
         if (sq && small >= 2 && blocks <= 64 && !a.colsum_ws && !a.xcd_order && sizeof(T) == 2)
             return launch_gg<T, 2, 4, 3, 1, 64>(a, st);
         if (small >= 2 && blocks <= 64) return launch_gg<T, 1, 4, 3>(a, st);
         if (blocks <= 128) return launch_gg<T, 2, 4, 3>(a, st);
     }
-    static const int one = getenv("RBVAE_GG_ONE") ? atoi(getenv("RBVAE_GG_ONE")) : 1;
+    constexpr int one = 1;
     if (ns == 1 && one >= 1 && blocks > 512) return launch_gg<T, 2, 4, 1, 4>(a, st);
     // few 128-wide tiles (the fc products at 256 frames: 64): 128 x 32 tiles put a workgroup on every CU
     if (ns == 1 && one >= 2 && blocks <= 64) return launch_gg<T, 1, 4, 1>(a, st);
@@ -678,9 +678,9 @@ extern "C" int rbvae_gather_gemm(int dtype, const void* A, const void* W, void* 
     a.relu = relu; a.drop_mode = drop_mode; a.scale = scale; a.seed = seed; a.seed_dev = seed_dev; a.colsum_ws = colsum_ws;
     a.drop_thresh = (unsigned)((double)drop_p * 4294967296.0);
     a.nclass = nclass;
-    static const int dephase = getenv("RBVAE_GG_DEPHASE") ? atoi(getenv("RBVAE_GG_DEPHASE")) : 1;
+    constexpr int dephase = 1;
     a.dephase = dephase;
-    static const int xcd = getenv("RBVAE_GG_XCD") ? atoi(getenv("RBVAE_GG_XCD")) : 0;
+    constexpr int xcd = 0;
     a.xcd_order = xcd && cdiv(Nimg * TH * TW, GG_BM) % 8 == 0 && (nclass > 1 || cdiv(Nout, Nout > 64 ? 128 : 64) > 1);
     a.stamps = g_gg_stamps;
     auto log2_or_neg = [](int v) { int s = 0; while ((1 << s) < v) ++s; return (1 << s) == v ? s : -1; };

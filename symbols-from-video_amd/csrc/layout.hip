@@ -604,7 +604,7 @@ static int im2col_impl(int dtype, const float* src, FrameMap fm, long sc, long s
     const bool fast = tot < (1l << 31) - 256 && span < (1l << 31) && (long)N * OH * OW * Kpad < (1l << 40) &&
                       sn >= 0 && sc >= 0 && sh >= 0 && sw >= 0;
     // LDS-staged form: measured on the bench step, same GPU, 3 runs each: 0.516 ms (gather form) vs 0.527 ms: off
-    static const int lds_on = getenv("RBVAE_IM2COL_LDS") ? atoi(getenv("RBVAE_IM2COL_LDS")) : 0;
+    constexpr int lds_on = 0;
     const size_t tile_bytes = (size_t)C * (2 * IM_R + 1) * (IW + 2) * sizeof(float);
     if (lds_on && fast && KH == 3 && KW == 3 && stride == 2 && pad == 1 && C <= 4 && tile_bytes <= 48 * 1024 &&
         OH == (IH + 2 - 3) / 2 + 1 && OW == (IW + 2 - 3) / 2 + 1) {
@@ -657,7 +657,7 @@ size_t rbvae_col2im_ws_floats(void) { return 5 * 4096; }
 int rbvae_col2im_nparts(long n_out) { return grid_for(n_out, 256, 4096); }
 
 static bool col2im_pix_ok(bool small, int Cout) {
-    static const int pix_on = getenv("RBVAE_COL2IM_PIX") ? atoi(getenv("RBVAE_COL2IM_PIX")) : 1;
+    constexpr int pix_on = 1;
     return pix_on && small && Cout <= 4;
 }
 

@@ -1560,7 +1560,7 @@ int rbvae_lstm_pair_bwd(const float* wblk_enc, const float* wblk_dec, const floa
 static int launch_lstm_wgrad(const float* dG, const float* hs_all, const float* hprev, float* gblk, const float* dG2,
                              const float* hs_all2, const float* hprev2, float* gblk2, int S, int T, int L, int layers,
                              int accumulate, void* stream) {
-    static const int use_mfma = getenv("RBVAE_LSTM_WGRAD_MFMA") ? atoi(getenv("RBVAE_LSTM_WGRAD_MFMA")) : 1;
+    constexpr int use_mfma = 1;
     if (use_mfma) {
         dim3 mgrid(cdiv(4 * L, 16) * cdiv(L + 1, 16), 2, dG2 ? 2 * layers : layers);
         hipLaunchKernelGGL(lstm_wgrad_mfma_k, mgrid, dim3(256), 0, (hipStream_t)stream, dG, hs_all, hprev, gblk, dG2,

@@ -566,7 +566,7 @@ static int launch_wg(const WgArgs& a, hipStream_t st) {
     // more workgroups than CUs: two per CU (double buffer) when two rings + index tables fit the 160 KB LDS
     const long blocks = (long)cdiv(a.Co, WG_BM) * cdiv(a.Ci, 64 * NT) * a.taps * a.ksplit;
     const size_t lds2 = (size_t)2 * BK * (WG_BM + 64 * NT) * ES + (size_t)a.Pper * sizeof(int);
-    static const int force = getenv("RBVAE_WG_NS") ? atoi(getenv("RBVAE_WG_NS")) : 0;
+    constexpr int force = 0;
     const bool two = force ? force == 2 : (blocks > 256 && 2 * lds2 <= 160 * 1024);
     if constexpr (ES == 2) {
         if (force == 4 && a.Pper <= 2560) return launch_wg_ns<T, NT, 4>(a, st);
@@ -625,7 +625,7 @@ int rbvae_wgrad_gemm(int dtype, const void* Dy, const void* In, float* dW_slabs,
     // XCD-ordered workgroups: the same step time (0.4454 on vs 0.4456 ms off, same GPU, 4 runs each -- the K step is bound
     // by the CU's intake, not by where the rows come from) but a third less traffic behind the L2s: 66.9 vs 103.1 MB
     // fetched by the 252-workgroup launch, 68.4 vs 86.3 (216), 21.1 vs 25.9 (108) (FETCH_SIZE, tools/pmc_traffic_env.sh)
-    static const int xcd = getenv("RBVAE_WG_XCD") ? atoi(getenv("RBVAE_WG_XCD")) : 1;
+    constexpr int xcd = 1;
     a.xcd_order = xcd && ksplit > 1;
     RBVAE_CHECK_ARG(a.Pper <= WG_MAXP, "wgrad_gemm: %d pixels per K-slice exceed %d: raise ksplit (>= %d)", a.Pper,
                     WG_MAXP, cdiv(P, WG_MAXP));

@@ -240,61 +240,55 @@ class Engine:
         self._jobs: Optional[JobList] = None
         self._wg_cus = 256
         self.first_launch_jobs = None  # extra job rows for the repack launch at the start of a forward(repack=True)
-        self._job_blocks = int(os.environ.get("RBVAE_JOB_BLOCKS", "256"))      # workgroups per job of a batched job launch
+        self._job_blocks = 256      # workgroups per job of a batched job launch
         self._sides: List[Optional[torch.cuda.Stream]] = [None, None]
         # weight-gradient work of the decoder runs on a side stream beside the LSTM backward chain (RBVAE_OVERLAP=0:
         # everything in issue order on one stream)
-        self.overlap = os.environ.get("RBVAE_OVERLAP", "1") == "1"
-        self.pack_late_split = os.environ.get("RBVAE_PACK_LATE", "0") == "1" or bool(int(os.environ.get("RBVAE_SIDE", "14")) & 128)
+        self.overlap = True
+        self.pack_late_split = False or bool(14 & 128)
         # default 14 = pair term + decoder weight gradients + their reductions (same-GPU sweep, ms/step: 14 0.547,
         # 12 0.553, 6 0.554, 30 0.556, 4 0.556, 63 0.568, 0 0.591: the weight repack, the loss bookkeeping and the
         # LSTM weight gradients are better left on the main stream)
-        self.side_mask = int(os.environ.get("RBVAE_SIDE", "14"))
+        self.side_mask = 14
         # Program order at a fork: the main stream's continuation is issued BEFORE the side work (the side stream
         # already waits on the fork point).  Graph capture hands the forking node's queue to the branch created
         # first; created second, the main chain paid the cross-queue hand-off (~10 us idle at every fork).
-        self.main_first = os.environ.get("RBVAE_MAIN_FIRST", "1") == "1"
-        self._ks_force = int(os.environ.get("RBVAE_WG_KS", "0"))
-        self._ks_small = int(os.environ.get("RBVAE_WG_KS_SMALL", "3"))
-        self._wg_nt4 = os.environ.get("RBVAE_WG_NT4", "0") == "1"
-        self.fc_gemm = os.environ.get("RBVAE_FC_GEMM", "1") == "1"               # dedicated kernel for the K = 64 fc products
+        self.main_first = True
+        self._ks_force = 0
+        self._ks_small = 3
+        self._wg_nt4 = os.environ.get("RBVAE_WG_NT4", "0") == "1"     # the library reads the same switch (wgrad_gemm.hip)
+        self.fc_gemm = True               # dedicated kernel for the K = 64 fc products
         # halo-resident kernel for the transposed 3x3 / stride-2 launches (csrc/deconv_halo.hip) from this many workgroups up
-        self.deconv_halo = os.environ.get("RBVAE_DECONV_HALO", "1") == "1"
+        self.deconv_halo = True
         self._dh_min_wgs = 1024
-        self.lstm_pair_bwd = os.environ.get("RBVAE_LSTM_PAIR_BWD", "1") == "1"   # both stacks' BPTT in one launch
-        self.keep_dz = os.environ.get("RBVAE_KEEP_DZ", "0") == "1"                # also store the codes' gradient
-        self._wg_nt4_slab = int(os.environ.get("RBVAE_WG_NT4_SLAB", "8"))     # cap on a weight's f32 slabs, M floats
-        self._ks_narrow = int(os.environ.get("RBVAE_WG_KS_NARROW", "0"))
-        self.book_with_dec = os.environ.get("RBVAE_BOOK_WITH_DEC", "1") == "1"
-        self.wfc_side = os.environ.get("RBVAE_WFC_SIDE", "1") == "1"
-        self.lstm_wgrad_tail = os.environ.get("RBVAE_LSTM_WGRAD_TAIL", "1") == "1"
-        self.tail_wgrads = int(os.environ.get("RBVAE_TAIL_WGRADS", "0"))
-        self.side_wg_cap = os.environ.get("RBVAE_SIDE_WG_CAP", "1") == "1"
-        self.mid_reduce = os.environ.get("RBVAE_MID_REDUCE", "0") == "1"
+        self.lstm_pair_bwd = True   # both stacks' BPTT in one launch
+        self.keep_dz = False                # also store the codes' gradient
+        self._wg_nt4_slab = 8     # cap on a weight's f32 slabs, M floats
+        self._ks_narrow = 0
+        self.book_with_dec = True
+        self.wfc_side = True
+        self.lstm_wgrad_tail = True
+        self.tail_wgrads = 0
+        self.side_wg_cap = True
+        self.mid_reduce = False
         # RBVAE_WFC_SWAP=1: the encoder fc's weight gradient with rows / columns swapped (full 128-row tiles on the 64-column
         # kernel instance).  Same box, 2 x 2 runs: 0.4696 (swapped) vs 0.4666 ms/step -- the launch rides the side tail
         # either way -- so the plain form stays.
-        self.wfc_swap = os.environ.get("RBVAE_WFC_SWAP", "0") == "1"
-        # RBVAE_STREAM_GEMM=1 sends the K = 64 products of the 3/4-channel ends to the row-streaming kernel
-        # (rbvae_stream_gemm) instead of the tiled gather GEMM.  Bit-identical results; measured on the bench shapes
-        # (tools/abl_stream.py): conv1 forward 17.5 -> 15.4-16.6 us, last-deconv backward (gate + column sums)
-        # 19.3 -> 27 us, step 0.597 -> 0.603 ms -- both kernels are bound by the per-element epilogue ALU work,
-        # not by HBM -- so it stays off.
-        self.stream_gemm = os.environ.get("RBVAE_STREAM_GEMM", "0") == "1"
+        self.wfc_swap = False
         # The fc products on either side of the LSTM stacks (M = frames, 32 outputs, K = thousands) run K-split over
         # 4x the workgroups, and the LSTM kernels sum the slabs while staging their input (RBVAE_FC_SPLIT=1: one
         # group, 32 CUs busy at 256 frames).  Needs the wavefront LSTM kernels (latent <= 32).
         ks_unit = 32 if dtype == "bf16" else 16
-        want = int(os.environ.get("RBVAE_FC_SPLIT", "4"))
+        want = 4
         wave_ok = latent <= 32 and self.v.lstm_layers * _ru(4 * latent, 64) <= 1024 and not self.v.simple_order
         self.fc_split = want if (want > 1 and wave_ok and self.F3 % (want * ks_unit) == 0 and self.F3 >= 2048) else 1
         # ... and write the bf16 / padded copy of their output that the next GEMM reads (rbvae_cast_pad otherwise)
-        self.lstm_cast = wave_ok and os.environ.get("RBVAE_LSTM_CAST", "1") == "1"
+        self.lstm_cast = wave_ok and True
         # ... and, in forward passes that run both stacks, go as one launch with the binarisation between them
-        self.lstm_pair = wave_ok and os.environ.get("RBVAE_LSTM_PAIR", "1") == "1"
-        self.bin_bwd_fused = wave_ok and os.environ.get("RBVAE_BIN_BWD_FUSED", "1") == "1"
-        self.deconv_fused = os.environ.get("RBVAE_DECONV_FUSED", "1") == "1"
-        self.conv_first_fused = os.environ.get("RBVAE_CONV_FIRST_FUSED", "1") == "1"
+        self.lstm_pair = wave_ok and True
+        self.bin_bwd_fused = wave_ok and True
+        self.deconv_fused = True
+        self.conv_first_fused = True
         self._alloc_packed()
 
     # ---- packed weights -------------------------------------------------------
@@ -519,17 +513,6 @@ class Engine:
         """bias_grad: f32 [nout] tensor that receives the column sums of the stored output (a reduce job
         over the kernel's per-tile partial sums, run with the other jobs at the end of backward)."""
         seed_dev = self.seed_dev
-        if (self.stream_gemm and self.dt == BF16 and cls_key == "one" and kc == 64 and lda == 64 and nout <= 256
-                and nout % 8 == 0 and nimg >= 8192 and ih * iw * th * tw * oh * ow == 1 and mask is None
-                and drop_mode != 2 and colsum_ws is None):
-            ws = None
-            if bias_grad is not None:
-                nb = L.query("rbvae_stream_gemm_blocks", nimg)
-                ws = self._buf(("colsum_sg", tag), nb * nout)
-                self._jobs.add(JOB_ROWS, ws, bias_grad, (1, 1, nout), (0, 0, 1), nslab=nb, slab=nout)
-            L.call("rbvae_stream_gemm", A, W, out, bias, gate, nimg, nout, ldo, relu, drop_mode, float(drop_p),
-                   float(scale), int(seed), seed_dev, ws)
-            return
         if (self.fc_gemm and cls_key == "one" and gate is None and mask is None and drop_mode == 0 and not relu
                 and scale == 1.0 and bias_grad is None and nimg <= 4096 and nout >= 1024
                 and ih * iw * th * tw * oh * ow == 1 and L.query("rbvae_fc_gemm_ok", self.dt, nimg, kc, nout, lda, ldo)):
@@ -619,7 +602,7 @@ class Engine:
         slabs = self._buf(("slabs", tag), ks * Co * taps * Ci)
         L.call("rbvae_wgrad_gemm", self.dt, Dy, In, slabs, idx, self.zero, P, In.numel() // ldi, Co, Ci, ldy, ldi, taps, ks)
         if (taps > 1 and taps <= 16 and tuple(dims) == (Co, Ci, taps) and tuple(strides) == (taps * Ci, 1, Ci)
-                and Ci % 4 == 0 and os.environ.get("RBVAE_CONV_REDUCE", "1") == "1"):
+                and Ci % 4 == 0 and True):
             # conv / conv-transpose weight: the coalesced row kernel (16-byte loads of the slabs' [t][ci] rows, LDS
             # transpose, 16-byte stores of the torch-layout row)
             self._jobs.add_conv_reduce(slabs, out, Co, Ci, taps, ks)
@@ -1006,7 +989,7 @@ class Engine:
                 decoder_wgrads_()
             finally:
                 self._wg_cus = 256
-        self._job_blocks = int(os.environ.get("RBVAE_JOB_BLOCKS", "256"))      # workgroups per job of a batched job launch
+        self._job_blocks = 256      # workgroups per job of a batched job launch
 
         def decoder_wgrads_():
             if g_xr is None and sv.b3_parts is not None:

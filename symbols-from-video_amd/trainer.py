@@ -92,7 +92,7 @@ class FusedTrainer:
         self.eng = None
         self.instrument = None       # optional callable(name, flops) -> context manager (bench roofline leg)
         import os
-        self.one_graph = os.environ.get("RBVAE_ONE_GRAPH", "1") == "1"
+        self.one_graph = True
         # world > 1: the backward pass is cut where the decoder CNN's and the LSTM stacks' gradients are final (the
         # contiguous tail of the flat buffer, 51 % of it at the headline config); that tail is all-reduced on the
         # collective's own stream beside the encoder CNN's backward graph, the head after it.  RBVAE_DDP_OVERLAP=0:
@@ -106,28 +106,28 @@ class FusedTrainer:
         # are captured INTO the step's single graph on a communication stream -- no graph boundary at the cut, no
         # host-side choreography between replays
         self.ddp_ingraph = os.environ.get("RBVAE_DDP_INGRAPH", "0") == "1"
-        self.fused_pair = os.environ.get("RBVAE_FUSED_PAIR", "1") == "1"
+        self.fused_pair = True
         # RBVAE_EARLY_UPDATE=1 (single GPU, experiment, off): the optimiser update and the weight repack run per parameter
         # group as soon as the group's gradients are final, on the side stream beside the rest of the backward pass
         # (engine.backward(updates=...)), instead of reduce -> Adam -> (next step) repack in series at the step boundary.
         # Measured on one GPU (tools/sweep_env.sh, same box): 0.475 vs 0.470 ms/step -- the byte-moving kernels and the
         # GEMMs beside them share the memory system, each slows the other by what the overlap would have saved
         # (last data-gradient GEMM 32 -> 50 us, Adam on half the buffer 15.5 us instead of 6.5): default = the plain order.
-        self.early_update = self.world == 1 and os.environ.get("RBVAE_EARLY_UPDATE", "0") == "1"
+        self.early_update = self.world == 1 and False
         self._packed_ver = None
         self._red = None
         # RBVAE_PREFETCH_DATA=1: gather the NEXT step's batch on the side stream during the backward pass instead of at
         # the start of the step.  Measured (same box, 2 x 2 runs): 0.4542 vs 0.4508 ms/step -- the 5.6 us gather already
         # hides in the gap between two graph launches -- so it is off.
-        self.prefetch_data = os.environ.get("RBVAE_PREFETCH_DATA", "0") == "1"
+        self.prefetch_data = False
         # The optimiser step AND the weight repack as ONE batched job launch (engine.update_jobs): every parameter tensor's
         # job applies Adam to its slice of the flat buffers and writes the packed copies from the new values while it
         # holds them; in set_data mode the same launch gathers the next step's batch.  The step then opens directly with
         # the first convolution: no repack launch, no gather launch, no separate Adam launch.
         # RBVAE_FUSED_UPDATE=0: rbvae_adam_step at the end, repack (+ gather) job launch at the start of the next step.
-        self.fused_update = os.environ.get("RBVAE_FUSED_UPDATE", "1") == "1" and not self.early_update
+        self.fused_update = True and not self.early_update
         self._primed = False          # set_data mode: the input buffer holds the batch of the coming step
-        self.gather_in_pack = os.environ.get("RBVAE_GATHER_IN_PACK", "1") == "1"
+        self.gather_in_pack = True
 
     # ---- the two halves of a step (plain launches; captured below) ------------------
     def _fwd_bwd(self, x, U, tau, B, T, cut=None, masks=None):

@@ -423,32 +423,6 @@ def test_binarize_parts_and_combine(sfv):
     np.testing.assert_allclose(wb.cpu().numpy(), wa.cpu().numpy(), atol=1e-7, rtol=0)
 
 
-@pytest.mark.parametrize("M,Nout", [(1000, 256), (4096, 64), (777, 136)])
-def test_stream_gemm_equals_gather_gemm(sfv, M, Nout):
-    """rbvae_stream_gemm (row-streaming, resident weights) gives the tiled gather GEMM's result bit for bit:
-    same MFMA chain per element, same keyed dropout mask, same gate; column sums to f32 rounding."""
-    g = torch.Generator().manual_seed(18)
-    K = 64
-    A = torch.randn(M, K, generator=g).bfloat16().cuda()
-    Wt = (torch.randn(Nout, K, generator=g) / 8).bfloat16().cuda()
-    bias = torch.randn(Nout, generator=g).cuda()
-    gate = torch.randn(M, Nout, generator=g).bfloat16().cuda()
-    for use_gate, drop, relu, use_bias in ((False, 1, 1, True), (True, 0, 0, False), (True, 1, 1, True)):
-        ref = torch.empty(M, Nout, dtype=torch.bfloat16, device="cuda")
-        out = torch.full((M, Nout), 7.0, dtype=torch.bfloat16, device="cuda")
-        mt = -(-M // 128)
-        ws_ref = torch.zeros(mt, Nout, device="cuda")
-        gemm(sfv, DT["bf16"][0], A, Wt, ref, bias if use_bias else None, gate if use_gate else None, None,
-             (M, 1, 1, 1, 1, 1, 1, 1, 1), K, Nout, 1, [1, 0, 0, 0, 0, 0], 1, relu=relu, drop_mode=drop, drop_p=0.2,
-             scale=1.25, seed=23, colsum_ws=ws_ref)
-        nb = sfv._lib.query("rbvae_stream_gemm_blocks", M)
-        ws = torch.zeros(nb, Nout, device="cuda")
-        sfv._lib.call("rbvae_stream_gemm", A, Wt, out, bias if use_bias else None, gate if use_gate else None, M, Nout,
-                      Nout, relu, drop, 0.2, 1.25, 23, None, ws)
-        assert torch.equal(out, ref), (use_gate, drop)
-        np.testing.assert_allclose(ws.sum(0).cpu().numpy(), ws_ref.sum(0).cpu().numpy(), rtol=1e-5, atol=1e-3)
-
-
 def test_split_fc_slabs_feed_the_lstm_kernels(sfv):
     """rbvae_skinny_linear_parts + rbvae_lstm_fwd_ex / _bwd_ex == the unsplit product fed to rbvae_lstm_fwd /
     _bwd (slab sums differ from the one-pass product only by f32 summation order)."""
