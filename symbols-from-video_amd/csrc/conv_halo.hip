@@ -387,7 +387,8 @@ __global__ __launch_bounds__(512) void conv_halo_k(const ChArgs p) {
                 if constexpr (nj == 8 && !more) ch_wait_barrier<0>();
                 else if constexpr ((nj == 2 || nj == 3) && more) ch_wait_barrier<LOADS + CH_NA>();
                 else ch_wait_barrier<LOADS>();
-                // behind the barrier: the weight tile two steps ahead
+                // behind the barrier: the weight tile two steps ahead.  (Waves 4-7 issuing it behind the MFMA group
+                // instead -- gather_gemm.hip's dephasing of the two waves of a SIMD -- measured 1-3 % slower here.)
                 if constexpr (nj + 2 < 9) b_issue(kn, std::integral_constant<int, (nj + 2) % 9>{});
                 else if (moren) b_issue(kn + 1, std::integral_constant<int, (nj + 2) % 9>{});
 #if !(CH_ABL & 8)
