@@ -190,7 +190,11 @@ __device__ __forceinline__ void conv_pack_rows(const Job& j, unsigned char* lds_
 // change order through LDS and leave as 16-byte stores of the contiguous [ci][t] row.
 constexpr int CRD_CI = 256, CRD_MAXKK = 16, CRD_ACC = CRD_CI * CRD_MAXKK / 4 / 256;      // float4 accumulators per thread
 __device__ __forceinline__ void conv_reduce_rows(const Job& j, float* tile) {
+#ifdef JOBS_ABL_ONE_SLAB
+    const unsigned Co = (unsigned)j.d0, Ci = (unsigned)j.d1, kk = (unsigned)j.d2, ns = 1;      // ablation partner of WG_ABL=5
+#else
     const unsigned Co = (unsigned)j.d0, Ci = (unsigned)j.d1, kk = (unsigned)j.d2, ns = (unsigned)j.nslab;
+#endif
     const unsigned ncb = (Ci + CRD_CI - 1) / CRD_CI;
     float* out = (float*)j.dst;
     for (unsigned b = blockIdx.x; b < Co * ncb; b += gridDim.x) {

@@ -509,6 +509,9 @@ __global__ __launch_bounds__(512, WG_NS == 2 ? 2 : 1) void wgrad_gemm_k(const Wg
     WG_STAMP(3);
     // D[row = ci 4g+r][col = co i]: lane owns 4 consecutive ci of one co -> one 16-B store
     float* slab = p.dW + (size_t)ks * p.Co * p.taps * p.Ci;
+#if WG_ABL == 5
+    if (ks > 0) return;          // ablation: only the first K-slice's slab leaves the chip (wrong sums; bounds what slab-free would buy)
+#endif
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
         const int co = co0 + (wr * MT + mt) * 16 + fi;

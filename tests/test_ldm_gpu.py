@@ -122,3 +122,37 @@ def test_halo_resnet_path_equals_gather_path(dtype, tol):
     assert float((ma - mb).norm() / mb.norm()) < tol
     with pytest.raises(ValueError):
         sfv.LDMEncoder(conv_impl="cudnn")
+
+
+def test_captured_encode_equals_eager_and_follows_new_weights():
+    """LDMEncoder(use_graph=True): the second call of an input shape captures the encode into a HIP graph,
+    later calls replay it.  Replays on NEW frames are bit-identical to the eager launches on those frames; another shape
+    gets its own graph; loading weights drops the graphs (they hold the packed copies' addresses) and the next encodes
+    follow the new weights."""
+    import sfv_amd as sfv
+    torch.manual_seed(9)
+    g = sfv.LDMEncoder(compute_dtype="bf16", use_graph=True).cuda()
+    e = sfv.LDMEncoder(compute_dtype="bf16").cuda()
+    e.load_state_dict(g.state_dict())
+    gen = torch.Generator().manual_seed(10)
+    xs = [(torch.rand(2, 3, 64, 64, generator=gen) * 2 - 1).cuda() for _ in range(4)]
+    for i, x in enumerate(xs):
+        assert torch.equal(g.encode(x, sample=False), e.encode(x, sample=False)), f"call {i}"
+    assert len(g._graphs) == 1 and not e._graphs
+    eps = torch.randn(2, 4, 8, 8, generator=gen).cuda()
+    assert torch.equal(g.encode(xs[0], eps=eps), e.encode(xs[0], eps=eps))
+    m1 = g.moments(xs[1])
+    m2 = g.moments(xs[2])                       # public moments are copies: the second replay does not rewrite the first
+    assert torch.equal(m1, e.moments(xs[1])) and torch.equal(m2, e.moments(xs[2]))
+    y = (torch.rand(1, 3, 64, 128, generator=gen) * 2 - 1).cuda()
+    for _ in range(3):
+        assert torch.equal(g.encode(y, sample=False), e.encode(y, sample=False))
+    assert len(g._graphs) == 2
+    sd = {k: (v * 1.5 if k.endswith("conv_in.weight") else v) for k, v in g.state_dict().items()}
+    g.load_state_dict(sd)
+    e.load_state_dict(sd)
+    assert not g._graphs
+    for _ in range(3):
+        assert torch.equal(g.encode(xs[3], sample=False), e.encode(xs[3], sample=False))
+    with pytest.raises(ValueError):
+        g.encode(torch.zeros(1, 3, 60, 64, device="cuda"))

@@ -18,11 +18,16 @@ for i, r in enumerate(rows):
         break
 names = [r["Kernel_Name"] for r in rows]
 # one marker per step: the first kernel of a step (the batch gather), else the first conv
+import os as _os
 marks = [i for i, n in enumerate(names) if "gather_frames_k" in n]
+if _os.environ.get("PROF_MARK"):                 # any other kernel that opens a step (e.g. im2col_fast_k for the LDM encoder)
+    marks = [i for i, n in enumerate(names) if _os.environ["PROF_MARK"] in n]
 if len(marks) < 12:
     marks = [i for i, n in enumerate(names) if "conv_first_fused_k<4, 0>" in n or "conv_first_fused_k<3, 0>" in n]
 if len(marks) < 12:
     marks = [i for i, n in enumerate(names) if "combine_losses_k" in n]
+if len(marks) < 17:
+    marks = [marks[0]] * (17 - len(marks)) + marks
 a, b = marks[-16], marks[-6]          # 10 graph-replayed steps (the last few before the cut are the eager warm-ups of the instrumented leg)
 steps = 10
 agg = collections.OrderedDict()

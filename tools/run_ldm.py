@@ -3,12 +3,13 @@ import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, sfv_amd as sfv
 torch.manual_seed(0)
-m = sfv.LDMEncoder(compute_dtype="bf16").cuda()
-for (N, S) in ((8, 256), (4, 512)):
+m = sfv.LDMEncoder(compute_dtype="bf16", use_graph=bool(int(os.environ.get("LDM_GRAPH", "0")))).cuda()
+shapes = [(int(a.split("x")[0]), int(a.split("x")[1])) for a in sys.argv[1:]] or [(8, 256), (4, 512)]     # e.g. 4x512
+for (N, S) in shapes:
     x = torch.rand(N, 3, S, S, device="cuda") * 2 - 1
     for _ in range(2): m.encode(x, sample=False)
     torch.cuda.synchronize(); t0 = time.perf_counter()
-    it = 5
+    it = int(os.environ.get("LDM_ITERS", "5"))
     for _ in range(it): lat = m.encode(x, sample=False)
     torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / it
     gf = 1116.7 * (S / 512) ** 2          # GFLOP per frame (SURVEY 8d estimate at 512^2)

@@ -1,4 +1,5 @@
-"""Per-row timing of the two batched job launches (weight pack, gradient reduce) of the bench workload."""
+"""Per-row timing of the batched job launches (weight pack, gradient reduce, fused update) of the bench workload, the
+native 4x88x160 percep model or cfg 3: python3 tools/time_jobs.py [bench|native|cfg3]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -8,8 +9,16 @@ trainer_mod = import_module("symbols-from-video_amd.trainer")
 L = sfv._lib
 dev = torch.device("cuda", 0)
 torch.manual_seed(1234)
-model = sfv.Seq2SeqBinaryVAE(4, 4, 32, 32, variant="percep", input_hw=(32, 32), compute_dtype="bf16").to(dev).train()
-item = torch.randn(16, 2, 8, 4, 32, 32, device=dev)
+cfg = sys.argv[1] if len(sys.argv) > 1 else "bench"          # bench | native | cfg3
+if cfg == "native":
+    model = sfv.Seq2SeqBinaryVAE(4, 4, 32, 32, variant="percep", compute_dtype="bf16").to(dev).train()
+    item = torch.randn(8, 2, 8, 4, 88, 160, device=dev)
+elif cfg == "cfg3":
+    model = sfv.Seq2SeqBinaryVAE(3, 3, 32, 32, variant="contrastive", compute_dtype="bf16").to(dev).train()
+    item = torch.rand(8, 2, 8, 3, 256, 256, device=dev)
+else:
+    model = sfv.Seq2SeqBinaryVAE(4, 4, 32, 32, variant="percep", input_hw=(32, 32), compute_dtype="bf16").to(dev).train()
+    item = torch.randn(16, 2, 8, 4, 32, 32, device=dev)
 tr = trainer_mod.FusedTrainer(model, lr=1e-3, alpha=1.0, beta_kl=1.0, bernoulli_p=0.1, noise_ratio=0.1,
                               device_noise=True, use_graph=False)
 for _ in range(3):
