@@ -54,6 +54,7 @@ ISA_CHECKED = {
     "gather_gemm.hip": ("_ZN5rbvae13gather_gemm_k", ("ds_read_b128",)),
     "conv_halo.hip": ("_ZN5rbvae11conv_halo_k", ("ds_read_b128",)),
     "deconv_halo.hip": ("_ZN5rbvae13deconv_halo_k", ("ds_read_b128",)),
+    "wgrad_halo.hip": ("_ZN5rbvae12wgrad_halo_k", ("ds_read_b64_tr_b16",)),
 }
 
 

@@ -215,6 +215,17 @@ __device__ __forceinline__ void conv_reduce_rows(const Job& j, float* tile) {
             off[a] = tp * Ci + 4 * q;
         }
         unsigned k = 0;
+        if (na == 1) {
+            // narrow weights (64 x 64 x 9: 144 chunks per slab and output channel): eight slabs' loads in flight -- with two,
+            // the 128-256 slabs of a 2 M-pixel layer were 64-128 dependent round trips (35-40 us for 19 MB)
+            for (; k + 8 <= ns; k += 8) {
+                float4 v[8];
+#pragma unroll
+                for (int s8 = 0; s8 < 8; ++s8) v[s8] = *(const float4*)(base + (size_t)(k + s8) * j.slab + off[0]);
+#pragma unroll
+                for (int s8 = 0; s8 < 8; ++s8) { acc[0].x += v[s8].x; acc[0].y += v[s8].y; acc[0].z += v[s8].z; acc[0].w += v[s8].w; }
+            }
+        }
         for (; k + 2 <= ns; k += 2) {                              // two slabs' loads in flight; added in slab order
             float4 v[2][CRD_ACC];
 #pragma unroll
@@ -272,6 +283,7 @@ __device__ __forceinline__ void conv_reduce_rows(const Job& j, float* tile) {
 __global__ __launch_bounds__(256) void run_jobs_k(const Job* __restrict__ jobs) {
     __shared__ __attribute__((aligned(16))) unsigned char lds_raw[CPK_LDS_BYTES];
     static_assert(CPK_LDS_BYTES >= (int)sizeof(float) * CRD_MAXKK * (CRD_CI + 1), "the reduce tile fits the pack tile");
+    static_assert(CPK_LDS_BYTES >= 256 * 16, "the wide row reduction's tree fits");
     const Job j = jobs[blockIdx.y];
     if (j.type == 3) {
         if (j.dtype == RBVAE_F32) conv_pack_rows<float>(j, lds_raw); else conv_pack_rows<bf16_t>(j, lds_raw);
@@ -325,6 +337,48 @@ __global__ __launch_bounds__(256) void run_jobs_k(const Job* __restrict__ jobs) 
     // this job may need fewer blocks than the launch provides
     if (blockIdx.x * (j.type == 2 ? 4u : 256u) >= n) return;
     if (j.type == 2) {
+        const unsigned nsl = (unsigned)j.nslab, slb = (unsigned)j.slab;
+        if (nsl >= 1024 && (n & 3) == 0 && (slb & 3) == 0 && ((size_t)j.src & 15) == 0) {
+            // thousands of partial rows (the per-tile column sums of a 2 M-pixel layer): a workgroup owns FOUR columns, its
+            // 256 threads walk the rows 16 bytes at a time (eight loads in flight each), then a fixed-order tree over the
+            // threads -- one wave per column walked 16 384 rows with 64-way uncoalesced dword loads (50 us for 4 MB)
+            float4* red = (float4*)lds_raw;
+            float* out = (float*)j.dst;
+            for (unsigned cb = blockIdx.x; cb < n / 4; cb += gridDim.x) {
+                float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+                const float* col = j.src + 4 * cb;
+                unsigned k = threadIdx.x;
+                for (; k + 7 * 256 < nsl; k += 8 * 256) {
+                    float4 v[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) v[u] = *(const float4*)(col + (size_t)(k + u * 256) * slb);
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) { a.x += v[u].x; a.y += v[u].y; a.z += v[u].z; a.w += v[u].w; }
+                }
+                for (; k < nsl; k += 256) {
+                    const float4 v = *(const float4*)(col + (size_t)k * slb);
+                    a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+                }
+                red[threadIdx.x] = a;
+                __syncthreads();
+                for (unsigned s = 128; s > 0; s >>= 1) {
+                    if (threadIdx.x < s) {
+                        const float4 o = red[threadIdx.x + s];
+                        float4 m = red[threadIdx.x];
+                        m.x += o.x; m.y += o.y; m.z += o.z; m.w += o.w;
+                        red[threadIdx.x] = m;
+                    }
+                    __syncthreads();
+                }
+                if (threadIdx.x < 4) {
+                    const float* r = (const float*)red;
+                    const float t = r[threadIdx.x] * j.scale;
+                    out[4 * cb + threadIdx.x] = j.accumulate ? out[4 * cb + threadIdx.x] + t : t;
+                }
+                __syncthreads();
+            }
+            return;
+        }
         // out[c] = scale * sum_k src[k*slab + c]; one wave per output, lanes stride the slabs, shuffle-reduce
         const int lane = threadIdx.x & 63;
         const unsigned wave = blockIdx.x * 4 + (threadIdx.x >> 6), nw = gridDim.x * 4;

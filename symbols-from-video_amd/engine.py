@@ -261,6 +261,11 @@ class Engine:
         # halo-resident kernel for the transposed 3x3 / stride-2 launches (csrc/deconv_halo.hip) from this many workgroups up
         self.deconv_halo = True
         self._dh_min_wgs = 1024
+        # nine-taps-per-workgroup weight gradient of the 3x3 stride-2 layers (csrc/wgrad_halo.hip) when every workgroup
+        # gets at least this many 8 x 8 pixel blocks
+        self.wgrad_halo = True
+        self._wh_min_steps = 8
+        self._wh_max_tiles = 2
         self.lstm_pair_bwd = True   # both stacks' BPTT in one launch
         self.keep_dz = False                # also store the codes' gradient
         self._wg_nt4_slab = 8     # cap on a weight's f32 slabs, M floats
@@ -578,8 +583,26 @@ class Engine:
         self._conv_idx(N, h1, w1, h2, w2)
         self._conv_idx(N, h2, w2, h3, w3)
 
-    def _wgrad(self, Dy, In, idx, P, Co, Ci, ldy, ldi, taps, out, dims, strides, tag=None):
-        """wgrad GEMM into K-slice slabs; their fixed-order reduction into the torch layout is a job."""
+    def _wgrad(self, Dy, In, idx, P, Co, Ci, ldy, ldi, taps, out, dims, strides, tag=None, geom=None):
+        """wgrad GEMM into K-slice slabs; their fixed-order reduction into the torch layout is a job.
+        geom = (Nimg, OH, OW, IH, IW) of a 3x3 stride-2 layer (Dy rows at OH x OW, In rows at IH x IW): with the nine taps
+        in one workgroup (csrc/wgrad_halo.hip) when the launch gives every workgroup enough pixel blocks."""
+        if (geom is not None and self.wgrad_halo and self.dt == BF16 and self.k == 3 and taps == 9 and idx is not None
+                and geom[3] == 2 * geom[1] and geom[4] == 2 * geom[2] and Co % 64 == 0 and Ci % 64 == 0
+                and L.query("rbvae_wgrad3x3s2_halo_ok", self.dt, geom[0], geom[1], geom[2], Co, Ci)):
+            nimg, oh, ow = geom[:3]
+            nblk = L.query("rbvae_wgrad3x3s2_halo_blocks", nimg, oh, ow)
+            ntile = (Co // 64) * (Ci // 64)
+            # K-slices: one round of workgroups on the CUs this launch can count on; at most ~40 MB of f32 slabs
+            ks = max(1, min(self._wg_cus // ntile, nblk, (40 << 20) // (Co * taps * Ci * 4)))
+            # measured (tools/time_wgrad_halo.py): 64 x 64 channels 178 -> 81 us (cfg 3 conv2) and 52 -> 30 us (conv3); with 16
+            # channel tiles per pixel block (256 x 256) the 64 KB stage per block is fetched at 39 GB/s per CU (one stage in
+            # flight against ~1.6 us of latency) and the launch loses to rbvae_wgrad_gemm (231 vs 176 us): narrow layers only
+            if nblk // ks >= self._wh_min_steps and ntile <= self._wh_max_tiles:
+                slabs = self._buf(("slabs", tag), ks * Co * taps * Ci)
+                L.call("rbvae_wgrad3x3s2_halo", self.dt, Dy, In, slabs, self.zero, nimg, oh, ow, Co, Ci, ldy, ldi, ks)
+                self._wgrad_reduce(slabs, out, Co, Ci, taps, ks, dims, strides)
+                return
         nt4 = self._wg_nt4 and self.dt == BF16 and Ci % 256 == 0        # 128 x 256 tiles (wgrad_gemm.hip)
         blocks = -(-Co // 128) * -(-Ci // (256 if nt4 else 128 if Ci > 64 else 64)) * taps
         # K-slices: one round of workgroups on the 256 CUs, each with >= 256 pixels, and at most ~16 MB of f32
@@ -601,8 +624,11 @@ class Engine:
         ks = max(ks, -(-P // (2048 if nt4 else 4096)))   # the kernel keeps a K-slice's gather indices in LDS
         slabs = self._buf(("slabs", tag), ks * Co * taps * Ci)
         L.call("rbvae_wgrad_gemm", self.dt, Dy, In, slabs, idx, self.zero, P, In.numel() // ldi, Co, Ci, ldy, ldi, taps, ks)
+        self._wgrad_reduce(slabs, out, Co, Ci, taps, ks, dims, strides)
+
+    def _wgrad_reduce(self, slabs, out, Co, Ci, taps, ks, dims, strides):
         if (taps > 1 and taps <= 16 and tuple(dims) == (Co, Ci, taps) and tuple(strides) == (taps * Ci, 1, Ci)
-                and Ci % 4 == 0 and True):
+                and Ci % 4 == 0):
             # conv / conv-transpose weight: the coalesced row kernel (16-byte loads of the slabs' [t][ci] rows, LDS
             # transpose, 16-byte stores of the torch-layout row)
             self._jobs.add_conv_reduce(slabs, out, Co, Ci, taps, ks)
@@ -1001,9 +1027,11 @@ class Engine:
             self._wgrad(sv.d2, col3, None, P1, c1, self.K3, c1, self.K3, 1, G(f"decoder_cnn.deconv.{i2}.weight"),
                         (c1, oc, kk), (self.K3, 1, oc), tag=(N, "V3"))
             self._wgrad(sv.d1, dd2, self._conv_idx(N, h1, w1, h2, w2), P2, c2, c1, c2, c1, kk,
-                        G(f"decoder_cnn.deconv.{i1}.weight"), (c2, c1, kk), (kk * c1, 1, c1), tag=(N, "V2"))
+                        G(f"decoder_cnn.deconv.{i1}.weight"), (c2, c1, kk), (kk * c1, 1, c1), tag=(N, "V2"),
+                        geom=(N, h2, w2, h1, w1))
             self._wgrad(sv.f, dd1, self._conv_idx(N, h2, w2, h3, w3), P3, c3, c2, c3, c2, kk,
-                        G(f"decoder_cnn.deconv.{i0}.weight"), (c3, c2, kk), (kk * c2, 1, c2), tag=(N, "V1"))
+                        G(f"decoder_cnn.deconv.{i0}.weight"), (c3, c2, kk), (kk * c2, 1, c2), tag=(N, "V1"),
+                        geom=(N, h3, w3, h2, w2))
             # decoder fc: bias = per (position, channel) sum over frames, permuted to the torch (c, hw) order
             nf = L.query("rbvae_colsum_ws_floats", N, self.F3)
             wsf = self._buf((N, "bdfc"), nf)
@@ -1204,7 +1232,7 @@ class Engine:
         # --- conv3
         idx3, idx2 = self._conv_idx(N, h2, w2, h3, w3), self._conv_idx(N, h1, w1, h2, w2)
         on_tail(1, lambda: self._wgrad(da3, sv.a2, idx3, P3, c3, c2, c3, c2, kk, G(f"encoder_cnn.conv.{i2}.weight"),
-                                       (c3, c2, kk), (kk * c2, 1, c2), tag=(N, "W3")))
+                                       (c3, c2, kk), (kk * c2, 1, c2), tag=(N, "W3"), geom=(N, h3, w3, h2, w2)))
         da2 = tmp("da2", P2, c2)
         self._gemm(da3, self.W3d, da2, None, sv.a2, None, N, h3, w3, h3, w3, 1, h2, w2, 2, c3, c2, c3, c2, kk, "dgrad",
                    scale=gs, bias_grad=G(f"encoder_cnn.conv.{i1}.bias"), tag=(N, "da2"))
@@ -1219,7 +1247,7 @@ class Engine:
             cut()
         # --- conv2
         on_tail(2, lambda: self._wgrad(da2, sv.a1, idx2, P2, c2, c1, c2, c1, kk, G(f"encoder_cnn.conv.{i1}.weight"),
-                                       (c2, c1, kk), (kk * c1, 1, c1), tag=(N, "W2")))
+                                       (c2, c1, kk), (kk * c1, 1, c1), tag=(N, "W2"), geom=(N, h2, w2, h1, w1)))
         if early_upd:
             # the mid group (conv2, conv3, encoder fc) is complete: its reduction, optimiser update and repack go to the
             # side stream (issued with the deferred side work below); only conv1's pieces remain for the end

@@ -740,7 +740,7 @@ def test_conv_pack_job_both_orders(sfv, dtype, Co, Ci, kk):
 
 
 @pytest.mark.parametrize("Co,Ci,kk,ks,acc", [(256, 256, 9, 7, 0), (64, 64, 9, 3, 1), (128, 64, 16, 2, 0), (8, 520, 9, 5, 0),
-                                             (16, 12, 4, 1, 0)])
+                                             (16, 12, 4, 1, 0), (64, 64, 9, 19, 0), (64, 64, 9, 256, 1)])
 def test_conv_reduce_job_matches_permute_reduce(sfv, Co, Ci, kk, ks, acc):
     """rbvae_run_jobs kind 4 (coalesced rows, LDS transpose) == rbvae_permute_reduce (one thread per output), bit for
     bit: both add the slabs in slab order."""
@@ -755,6 +755,26 @@ def test_conv_reduce_job_matches_permute_reduce(sfv, Co, Ci, kk, ks, acc):
     want = slabs.sum(0).permute(0, 2, 1) * 0.5 + (base if acc else 0)
     assert torch.allclose(out, want, atol=1e-5, rtol=1e-5)
     assert torch.equal(out, ref)
+
+
+@pytest.mark.parametrize("rows,C,acc", [(16384, 64, 0), (3840, 256, 1), (1030, 4, 0), (1000, 64, 0), (5000, 3, 0)])
+def test_reduce_rows_job_over_thousands_of_partial_rows(sfv, rows, C, acc):
+    """rbvae_run_jobs kind 2 (the per-tile column sums of a layer -> its bias gradient): from 1024 rows and a column count
+    divisible by 4 up a workgroup owns four columns and walks the rows 16 bytes at a time; below (or with 3 columns) one
+    wave per column.  Either way: the sums, in an order that does not depend on the run (bit-identical twice)."""
+    g = torch.Generator().manual_seed(rows + C)
+    ws = torch.randn(rows, C, generator=g).cuda()
+    base = torch.randn(C, generator=g).cuda()
+    outs = []
+    for _ in range(2):
+        out = base.clone()
+        tab = torch.tensor([_job_row(2, ws, out, 1, 1, C, nslab=rows, slab=C, accumulate=acc, scale=0.25)],
+                           dtype=torch.int64).cuda()
+        sfv._lib.call("rbvae_run_jobs", tab, 1, 256)
+        outs.append(out)
+    want = ws.double().sum(0) * 0.25 + (base.double() if acc else 0)
+    assert torch.allclose(outs[0].double(), want, atol=2e-4, rtol=1e-5)
+    assert torch.equal(outs[0], outs[1])
 
 
 @pytest.mark.parametrize("variant,in_ch,dtype,Ld,hw", [("percep", 4, "bf16", 32, (16, 16)), ("percep", 4, "f32", 25, (16, 24)),
