@@ -182,12 +182,13 @@ int rbvae_wgrad_gemm(int dtype, const void* Dy, const void* In, float* dW_slabs,
 /* ---- weight gradient of the 3x3 stride-2 pad-1 convolutions, nine taps per workgroup (bf16) ----------------------
  * dW[ks][a][t][b] = sum over the K-slice's pixels p = (n, r, c) of S[p][a] * G[(n, 2r + kh - 1, 2c + kw - 1)][b],
  * t = 3 kh + kw, rows outside the image zero: rbvae_wgrad_gemm's sum for idx = rbvae_conv_gather_index(.., 3, 3, 2, 1)
- * and taps = 9, in the same slab layout (the same reduction jobs follow), with S and the 17 x 17 patch of G around an
- * 8 x 8 pixel block fetched once for all nine taps instead of once per tap.  Conv2d(c, c, 3, 2, 1) weights: S = the output
+ * and taps = 9, in the same slab layout (the same reduction jobs follow), with S and the 9 x 17 patch of G around a
+ * 4 x 8 pixel block fetched once for all nine taps instead of once per tap.  Conv2d(c, c, 3, 2, 1) weights: S = the output
  * gradient [Nimg*OH*OW][lds], G = the layer's input [Nimg*2OH*2OW][ldg] (percep_RBVAE_model.py:51-57);
  * ConvTranspose2d(c, c, 3, 2, 1, 1) weights: S = the layer's input, G = its output gradient (:76-81); autograd as run by
  * percep_RBVAE_train.py:552.  Covered (rbvae_wgrad3x3s2_halo_ok): bf16, Ca and Cb multiples of 64.  K-slices are runs
- * of rbvae_wgrad3x3s2_halo_blocks(..) / ksplit pixel blocks; grid = (Ca/64) * (Cb/64) * ksplit workgroups. */
+ * of rbvae_wgrad3x3s2_halo_blocks(..) / ksplit pixel blocks; grid = (Ca/64) * (Cb/64) * ksplit workgroups (ksplit rounded up
+ * to a multiple of 8: one K-slice group per XCD). */
 int rbvae_wgrad3x3s2_halo_ok(int dtype, int Nimg, int OH, int OW, int Ca, int Cb);
 int rbvae_wgrad3x3s2_halo_blocks(int Nimg, int OH, int OW);
 int rbvae_wgrad3x3s2_halo(int dtype, const void* S, const void* G, float* dW_slabs, const void* zero_page, int Nimg, int OH,

@@ -262,7 +262,7 @@ class Engine:
         self.deconv_halo = True
         self._dh_min_wgs = 1024
         # nine-taps-per-workgroup weight gradient of the 3x3 stride-2 layers (csrc/wgrad_halo.hip) when every workgroup
-        # gets at least this many 8 x 8 pixel blocks
+        # gets at least this many 4 x 8 pixel blocks
         self.wgrad_halo = True
         self._wh_min_steps = 8
         self._wh_max_tiles = 2
@@ -595,9 +595,10 @@ class Engine:
             ntile = (Co // 64) * (Ci // 64)
             # K-slices: one round of workgroups on the CUs this launch can count on; at most ~40 MB of f32 slabs
             ks = max(1, min(self._wg_cus // ntile, nblk, (40 << 20) // (Co * taps * Ci * 4)))
-            # measured (tools/time_wgrad_halo.py): 64 x 64 channels 178 -> 81 us (cfg 3 conv2) and 52 -> 30 us (conv3); with 16
-            # channel tiles per pixel block (256 x 256) the 64 KB stage per block is fetched at 39 GB/s per CU (one stage in
-            # flight against ~1.6 us of latency) and the launch loses to rbvae_wgrad_gemm (231 vs 176 us): narrow layers only
+            # measured (tools/time_wgrad_halo.py): 64 x 64 channels 178 -> 71 us (cfg 3 conv2: the HBM time of its operands)
+            # and 52 -> 27 us (conv3).  With 16 channel tiles per pixel block (256 x 256) a block's 32 KB stage is re-fetched
+            # by every tile: the LDS-DMA alone takes 173 us (11 TB/s through the L2s), the MFMAs + fragment reads alone 137,
+            # together 245 against rbvae_wgrad_gemm's 172 -- narrow layers only
             if nblk // ks >= self._wh_min_steps and ntile <= self._wh_max_tiles:
                 slabs = self._buf(("slabs", tag), ks * Co * taps * Ci)
                 L.call("rbvae_wgrad3x3s2_halo", self.dt, Dy, In, slabs, self.zero, nimg, oh, ow, Co, Ci, ldy, ldi, ks)
