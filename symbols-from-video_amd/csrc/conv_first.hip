@@ -84,9 +84,13 @@ __device__ __forceinline__ float cf_row_sum(float v) {
 }
 __device__ __forceinline__ bool cf_bf16_pos(unsigned v16) { return (v16 - 1u) < 0x7f80u; }    // 0 < v <= +inf, NaN excluded
 
-template <int CIN, int MODE> __global__ __launch_bounds__(512, 4) void conv_first_fused_k(const CfArgs p) {
+// NQ = 64-channel quads of the tile: 4 (Nout <= 256: wave = 64 pixels x one quad) or 1 (Nout <= 64, the cfg 3 widths: wave =
+// 16 pixels x the one quad -- with the 256-wide tile three of four waves multiplied and staged zero weights and sat out the
+// epilogue; 8 KB of weights instead of 32 and 16 accumulators per lane let four workgroups share a CU)
+template <int CIN, int MODE, int NQ> __global__ __launch_bounds__(512, NQ == 1 ? 8 : 4) void conv_first_fused_k(const CfArgs p) {
+    constexpr int MT = NQ == 4 ? 4 : 1;                                          // 16-pixel tiles per wave
     __shared__ __attribute__((aligned(16))) unsigned char s_a[128 * 128];        // im2col rows, swizzled chunks
-    __shared__ __attribute__((aligned(16))) unsigned char s_b[256 * 128];        // weights in fragment-row order
+    __shared__ __attribute__((aligned(16))) unsigned char s_b[64 * NQ * 128];    // weights in fragment-row order
     __shared__ float s_patch[4 * CF_PA * CF_PP];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int tb_n = (p.OW + CF_TB - 1) / CF_TB, ta_n = (p.OH + CF_TA - 1) / CF_TA;
@@ -101,7 +105,7 @@ template <int CIN, int MODE> __global__ __launch_bounds__(512, 4) void conv_firs
     // lane's accumulators of a tile quad are 16 consecutive channels (32 bytes per pixel, 128 per pixel and wave)
     {
         const int srow = lane >> 3, schunk = lane & 7;
-        for (int q = w; q < 32; q += 8) {                    // 32 instructions of 8 rows
+        for (int q = w; q < 8 * NQ; q += 8) {                // 8 NQ instructions of 8 rows
             const int r = q * 8 + srow;
             const int ct = r >> 4, j = r & 15;
             const int ch = 64 * (ct >> 2) + 16 * (j >> 2) + 4 * (ct & 3) + (j & 3);
@@ -111,7 +115,7 @@ template <int CIN, int MODE> __global__ __launch_bounds__(512, 4) void conv_firs
     }
     // bias and dropout key early: their latency hides behind the patch loads, and the epilogue's stores are never waited on
     const int fi = lane & 15, fg = lane >> 4;
-    const int wq = w & 3, wm = w >> 2;
+    const int wq = NQ == 4 ? (w & 3) : 0, wm = NQ == 4 ? (w >> 2) : w;
     const int col = 64 * wq + 16 * fg;
     const bool first = col < p.Nout, second = col + 8 < p.Nout;
     f32x4_t bz4[4];
@@ -207,21 +211,21 @@ template <int CIN, int MODE> __global__ __launch_bounds__(512, 4) void conv_firs
     // ---- 128 x 256 x 64 on the matrix cores: wave w owns pixels 64*(w/4) .. +63 x the tile quad w%4 = channels 64*(w%4) .. +63
     if (CF_DBG == 3) return;
     const int fsw = (fi >> 1) & 7;
-    f32x4_t acc[4][4];
+    f32x4_t acc[MT][4];
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt)
+    for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int h = 0; h < 4; ++h) acc[mt][h] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
         const int ch = ((4 * kk + fg) ^ fsw) * 16;
-        u32x4_t wv[4], av[4];
+        u32x4_t wv[4], av[MT];
 #pragma unroll
         for (int h = 0; h < 4; ++h) wv[h] = *(const u32x4_t*)(s_b + ((4 * wq + h) * 16 + fi) * 128 + ch);
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt) av[mt] = *(const u32x4_t*)(s_a + ((4 * wm + mt) * 16 + fi) * 128 + ch);
+        for (int mt = 0; mt < MT; ++mt) av[mt] = *(const u32x4_t*)(s_a + ((MT * wm + mt) * 16 + fi) * 128 + ch);
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt)
+        for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int h = 0; h < 4; ++h)
                 acc[mt][h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8_t*)&wv[h], *(const bf16x8_t*)&av[mt],
@@ -234,8 +238,8 @@ template <int CIN, int MODE> __global__ __launch_bounds__(512, 4) void conv_firs
 #pragma unroll
     for (int e = 0; e < 16; ++e) csum[e] = 0.f;
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt) {
-        const int r = (4 * wm + mt) * 16 + fi;
+    for (int mt = 0; mt < MT; ++mt) {
+        const int r = (MT * wm + mt) * 16 + fi;
         const int oh = oh0 + (r >> 4), ow = ow0 + (r & 15);
         if (oh >= p.OH || ow >= p.OW || !first) continue;
         const size_t orow = (size_t)(n * p.OH + oh) * p.OW + ow;
@@ -279,15 +283,21 @@ template <int CIN, int MODE> __global__ __launch_bounds__(512, 4) void conv_firs
     if constexpr (MODE == 1) {
         if (p.colsum_ws) {
             // bias gradient of the layer below: column sums of this block's stored values, pixels then wave halves
-            float* red = s_patch;                              // [2][256]; the patch is dead since the second barrier
+            float* red = s_patch;                              // [pixel groups][64 NQ]; the patch is dead since the second barrier
+            constexpr int RW = 64 * NQ, NGRP = NQ == 4 ? 2 : 8;
 #pragma unroll
             for (int e = 0; e < 16; ++e) csum[e] = cf_row_sum(csum[e]);
             if (fi == 0) {
 #pragma unroll
-                for (int e = 0; e < 16; ++e) red[wm * 256 + col + e] = csum[e];
+                for (int e = 0; e < 16; ++e) red[wm * RW + col + e] = csum[e];
             }
             __syncthreads();
-            if (tid < p.Nout) p.colsum_ws[(size_t)blockIdx.x * p.Nout + tid] = red[tid] + red[256 + tid];
+            if (tid < p.Nout) {
+                float t = red[tid];
+#pragma unroll
+                for (int g2 = 1; g2 < NGRP; ++g2) t += red[g2 * RW + tid];      // fixed order
+                p.colsum_ws[(size_t)blockIdx.x * p.Nout + tid] = t;
+            }
         }
     }
 }
@@ -298,14 +308,17 @@ static int cf_shape_ok(int dtype, int Cin, int IH, int IW, int Nout, int N) {
            IW >= 1 && (long)N * OH * OW * 256 < (1l << 31) && (long)N * Cin * IH * IW < (1l << 40);
 }
 
-template <int MODE> static void cf_launch(const CfArgs& a, hipStream_t st) {
+template <int MODE, int NQ> static void cf_launch_nq(const CfArgs& a, hipStream_t st) {
     const int blocks = a.N * cdiv(a.OH, CF_TA) * cdiv(a.OW, CF_TB);
     switch (a.Cin) {
-        case 1: hipLaunchKernelGGL((conv_first_fused_k<1, MODE>), dim3(blocks), dim3(512), 0, st, a); break;
-        case 2: hipLaunchKernelGGL((conv_first_fused_k<2, MODE>), dim3(blocks), dim3(512), 0, st, a); break;
-        case 3: hipLaunchKernelGGL((conv_first_fused_k<3, MODE>), dim3(blocks), dim3(512), 0, st, a); break;
-        default: hipLaunchKernelGGL((conv_first_fused_k<4, MODE>), dim3(blocks), dim3(512), 0, st, a); break;
+        case 1: hipLaunchKernelGGL((conv_first_fused_k<1, MODE, NQ>), dim3(blocks), dim3(512), 0, st, a); break;
+        case 2: hipLaunchKernelGGL((conv_first_fused_k<2, MODE, NQ>), dim3(blocks), dim3(512), 0, st, a); break;
+        case 3: hipLaunchKernelGGL((conv_first_fused_k<3, MODE, NQ>), dim3(blocks), dim3(512), 0, st, a); break;
+        default: hipLaunchKernelGGL((conv_first_fused_k<4, MODE, NQ>), dim3(blocks), dim3(512), 0, st, a); break;
     }
+}
+template <int MODE> static void cf_launch(const CfArgs& a, hipStream_t st) {
+    if (a.Nout <= 64) cf_launch_nq<MODE, 1>(a, st); else cf_launch_nq<MODE, 4>(a, st);
 }
 
 }  // namespace rbvae
