@@ -302,6 +302,61 @@ __global__ __launch_bounds__(256) void run_jobs_k(const Job* __restrict__ jobs) 
         const unsigned d1 = (unsigned)j.d1, d2 = (unsigned)j.d2;
         const long n = j.d0 * j.d1 * j.d2, base = j.src - c.w;
         const int t1 = (int)(j.dtype & 255), t2 = (int)((j.dtype >> 8) & 255);
+#ifndef JOBS_TILED_ADAM
+#define JOBS_TILED_ADAM 1
+#endif
+        if (JOBS_TILED_ADAM && j.type == 6 && n >= 65536) {
+            // A big tensor whose packed copies are PERMUTED (the fc weights: 56 320 x 32 in NHWC-flatten order and
+            // transposed): with one thread per master element every 2-byte store of a transposed copy went to its own
+            // 64-byte sector (30-40 us per fc weight).  Tiles of 8192 elements through LDS instead: the master side moves in
+            // runs along i2, each copy in runs along ITS contiguous index; the update arithmetic is adam_at's, element for
+            // element (bit-identical: only the order of the memory operations changes).
+            const long sA[3] = {j.s0, j.s1, j.s2}, sB[3] = {j.nslab, j.slab, j.accumulate};
+            const int fA = sA[0] == 1 ? 0 : (sA[1] == 1 ? 1 : 2);
+            const int fB = !j.dst2 ? fA : (sB[0] == 1 ? 0 : (sB[1] == 1 ? 1 : 2));
+            if (fA != 2 || fB != 2) {
+                unsigned T[3] = {1, 1, 1};
+                const int ndist = 1 + (fA != 2) + (fB != 2 && fB != fA);
+                if (ndist == 3) { T[2] = 16; T[fA] = 16; T[fB] = 32; }                // 16 x 16 x 32
+                else { T[2] = 32; T[fA] = 32; T[fB] = 32; T[3 - 2 - (fA != 2 ? fA : fB)] = 8; }   // 32 x 32 x 8 in some order
+                const unsigned dd[3] = {(unsigned)j.d0, d1, d2};
+#pragma unroll
+                for (int q = 0; q < 3; ++q) T[q] = min(T[q], dd[q]);
+                const unsigned nt0 = (dd[0] + T[0] - 1) / T[0], nt1 = (dd[1] + T[1] - 1) / T[1], nt2 = (dd[2] + T[2] - 1) / T[2];
+                const unsigned pitch = T[2] + 1, tel = T[0] * T[1] * T[2];
+                float* tile = (float*)lds_raw;                                           // [T0 * T1][T2 + 1]
+                for (unsigned t = blockIdx.x; t < nt0 * nt1 * nt2; t += gridDim.x) {
+                    const unsigned b2 = (t % nt2) * T[2], b1 = ((t / nt2) % nt1) * T[1], b0 = (t / (nt2 * nt1)) * T[0];
+                    for (unsigned e = threadIdx.x; e < tel; e += 256) {                  // master order: i2 fastest
+                        const unsigned l2 = e % T[2], l1 = (e / T[2]) % T[1], l0 = e / (T[2] * T[1]);
+                        if (b0 + l0 < dd[0] && b1 + l1 < dd[1] && b2 + l2 < dd[2]) {
+                            const long i = ((long)(b0 + l0) * d1 + (b1 + l1)) * d2 + (b2 + l2);
+                            tile[(l0 * T[1] + l1) * pitch + l2] = adam_at(c, base + i, step_size, bc2_sqrt);
+                        }
+                    }
+                    __syncthreads();
+                    for (int copy = 0; copy < (j.dst2 ? 2 : 1); ++copy) {
+                        const int f = copy ? fB : fA;                                    // this copy's contiguous index
+                        const int o1 = f == 0 ? 1 : 0, o2 = f == 2 ? 1 : 2;             // the other two, in order
+                        const long* st = copy ? sB : sA;
+                        void* dst = copy ? j.dst2 : j.dst;
+                        const int ty = copy ? t2 : t1;
+                        const unsigned bb[3] = {b0, b1, b2};
+                        for (unsigned e = threadIdx.x; e < tel; e += 256) {
+                            unsigned l[3];
+                            l[f] = e % T[f]; l[o2] = (e / T[f]) % T[o2]; l[o1] = e / (T[f] * T[o2]);
+                            if (bb[0] + l[0] < dd[0] && bb[1] + l[1] < dd[1] && bb[2] + l[2] < dd[2]) {
+                                const float w = tile[(l[0] * T[1] + l[1]) * pitch + l[2]];
+                                const size_t o = (bb[0] + l[0]) * (size_t)st[0] + (bb[1] + l[1]) * (size_t)st[1] + (bb[2] + l[2]) * (size_t)st[2];
+                                if (ty == RBVAE_F32) ((float*)dst)[o] = w; else ((bf16_t*)dst)[o] = f32_to_bf16(w);
+                            }
+                        }
+                    }
+                    __syncthreads();
+                }
+                return;
+            }
+        }
         for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
             const float w = adam_at(c, base + i, step_size, bc2_sqrt);
             if (j.type == 6) {

@@ -35,7 +35,7 @@ def time_tab(label, tab, n, jl):
         evs = []
         for ptr, cnt in calls:
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            a.record(); L.call("rbvae_run_jobs", ptr, cnt, 256); b.record()
+            a.record(); L.call("rbvae_run_jobs", ptr, cnt, int(os.environ.get("JOB_BLOCKS", "256"))); b.record()
             evs.append((a, b))
         torch.cuda.synchronize()
         return [a.elapsed_time(b) * 1e3 for a, b in evs]
