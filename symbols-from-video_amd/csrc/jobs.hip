@@ -305,49 +305,51 @@ __global__ __launch_bounds__(256) void run_jobs_k(const Job* __restrict__ jobs) 
 #ifndef JOBS_TILED_ADAM
 #define JOBS_TILED_ADAM 1
 #endif
-        if (JOBS_TILED_ADAM && j.type == 6 && n >= 65536) {
-            // A big tensor whose packed copies are PERMUTED (the fc weights: 56 320 x 32 in NHWC-flatten order and
-            // transposed): with one thread per master element every 2-byte store of a transposed copy went to its own
+        if (JOBS_TILED_ADAM && j.type == 6 && n >= (1l << 20)) {
+            // A big tensor (>= 1 M elements = 128 tiles: the 131 072-element fc weight of the bench shape would keep 16 workgroups
+            // busy for 40 us: 0.458 -> 0.49 ms per step) whose packed copies are PERMUTED (the fc weights: 56 320 x 32 in
+            // NHWC-flatten order and transposed): with one thread per master element every 2-byte store of a transposed copy went to its own
             // 64-byte sector (30-40 us per fc weight).  Tiles of 8192 elements through LDS instead: the master side moves in
             // runs along i2, each copy in runs along ITS contiguous index; the update arithmetic is adam_at's, element for
             // element (bit-identical: only the order of the memory operations changes).
-            const long sA[3] = {j.s0, j.s1, j.s2}, sB[3] = {j.nslab, j.slab, j.accumulate};
-            const int fA = sA[0] == 1 ? 0 : (sA[1] == 1 ? 1 : 2);
-            const int fB = !j.dst2 ? fA : (sB[0] == 1 ? 0 : (sB[1] == 1 ? 1 : 2));
+            // (scalars and selects, no indexed local arrays: those are promoted to LDS and cost every job of the launch a
+            // workgroup per CU -- 40 064 instead of 36 992 bytes: +5 us per bench step)
+            const long a0 = j.s0, a1 = j.s1, a2 = j.s2, c0 = j.nslab, c1 = j.slab, c2 = j.accumulate;
+            const int fA = a0 == 1 ? 0 : (a1 == 1 ? 1 : 2);
+            const int fB = !j.dst2 ? fA : (c0 == 1 ? 0 : (c1 == 1 ? 1 : 2));
             if (fA != 2 || fB != 2) {
-                unsigned T[3] = {1, 1, 1};
-                const int ndist = 1 + (fA != 2) + (fB != 2 && fB != fA);
-                if (ndist == 3) { T[2] = 16; T[fA] = 16; T[fB] = 32; }                // 16 x 16 x 32
-                else { T[2] = 32; T[fA] = 32; T[fB] = 32; T[3 - 2 - (fA != 2 ? fA : fB)] = 8; }   // 32 x 32 x 8 in some order
-                const unsigned dd[3] = {(unsigned)j.d0, d1, d2};
-#pragma unroll
-                for (int q = 0; q < 3; ++q) T[q] = min(T[q], dd[q]);
-                const unsigned nt0 = (dd[0] + T[0] - 1) / T[0], nt1 = (dd[1] + T[1] - 1) / T[1], nt2 = (dd[2] + T[2] - 1) / T[2];
-                const unsigned pitch = T[2] + 1, tel = T[0] * T[1] * T[2];
+                const unsigned D0 = (unsigned)j.d0;
+                unsigned T0, T1, T2;
+                if (fA != 2 && fB != 2 && fA != fB) { T2 = 16; T0 = fB == 0 ? 32 : 16; T1 = fB == 1 ? 32 : 16; }   // three contiguous indices
+                else { const int f = fA != 2 ? fA : fB; T2 = 32; T0 = f == 0 ? 32 : 8; T1 = f == 1 ? 32 : 8; }
+                T0 = min(T0, D0); T1 = min(T1, d1); T2 = min(T2, d2);
+                const unsigned nt0 = (D0 + T0 - 1) / T0, nt1 = (d1 + T1 - 1) / T1, nt2 = (d2 + T2 - 1) / T2;
+                const unsigned pitch = T2 + 1, tel = T0 * T1 * T2;
                 float* tile = (float*)lds_raw;                                           // [T0 * T1][T2 + 1]
                 for (unsigned t = blockIdx.x; t < nt0 * nt1 * nt2; t += gridDim.x) {
-                    const unsigned b2 = (t % nt2) * T[2], b1 = ((t / nt2) % nt1) * T[1], b0 = (t / (nt2 * nt1)) * T[0];
+                    const unsigned b2 = (t % nt2) * T2, b1 = ((t / nt2) % nt1) * T1, b0 = (t / (nt2 * nt1)) * T0;
                     for (unsigned e = threadIdx.x; e < tel; e += 256) {                  // master order: i2 fastest
-                        const unsigned l2 = e % T[2], l1 = (e / T[2]) % T[1], l0 = e / (T[2] * T[1]);
-                        if (b0 + l0 < dd[0] && b1 + l1 < dd[1] && b2 + l2 < dd[2]) {
+                        const unsigned l2 = e % T2, l1 = (e / T2) % T1, l0 = e / (T2 * T1);
+                        if (b0 + l0 < D0 && b1 + l1 < d1 && b2 + l2 < d2) {
                             const long i = ((long)(b0 + l0) * d1 + (b1 + l1)) * d2 + (b2 + l2);
-                            tile[(l0 * T[1] + l1) * pitch + l2] = adam_at(c, base + i, step_size, bc2_sqrt);
+                            tile[(l0 * T1 + l1) * pitch + l2] = adam_at(c, base + i, step_size, bc2_sqrt);
                         }
                     }
                     __syncthreads();
                     for (int copy = 0; copy < (j.dst2 ? 2 : 1); ++copy) {
                         const int f = copy ? fB : fA;                                    // this copy's contiguous index
-                        const int o1 = f == 0 ? 1 : 0, o2 = f == 2 ? 1 : 2;             // the other two, in order
-                        const long* st = copy ? sB : sA;
+                        const long q0 = copy ? c0 : a0, q1 = copy ? c1 : a1, q2 = copy ? c2 : a2;
                         void* dst = copy ? j.dst2 : j.dst;
                         const int ty = copy ? t2 : t1;
-                        const unsigned bb[3] = {b0, b1, b2};
+                        // e -> (fastest = index f, then the other two in order)
+                        const unsigned Tf = f == 0 ? T0 : (f == 1 ? T1 : T2);
+                        const unsigned Tm = f == 2 ? T1 : T2;                            // the faster of the other two
                         for (unsigned e = threadIdx.x; e < tel; e += 256) {
-                            unsigned l[3];
-                            l[f] = e % T[f]; l[o2] = (e / T[f]) % T[o2]; l[o1] = e / (T[f] * T[o2]);
-                            if (bb[0] + l[0] < dd[0] && bb[1] + l[1] < dd[1] && bb[2] + l[2] < dd[2]) {
-                                const float w = tile[(l[0] * T[1] + l[1]) * pitch + l[2]];
-                                const size_t o = (bb[0] + l[0]) * (size_t)st[0] + (bb[1] + l[1]) * (size_t)st[1] + (bb[2] + l[2]) * (size_t)st[2];
+                            const unsigned lf = e % Tf, lm = (e / Tf) % Tm, ls = e / (Tf * Tm);
+                            const unsigned l0 = f == 0 ? lf : ls, l1 = f == 1 ? lf : (f == 0 ? ls : lm), l2 = f == 2 ? lf : lm;
+                            if (b0 + l0 < D0 && b1 + l1 < d1 && b2 + l2 < d2) {
+                                const float w = tile[(l0 * T1 + l1) * pitch + l2];
+                                const size_t o = (b0 + l0) * (size_t)q0 + (b1 + l1) * (size_t)q1 + (b2 + l2) * (size_t)q2;
                                 if (ty == RBVAE_F32) ((float*)dst)[o] = w; else ((bf16_t*)dst)[o] = f32_to_bf16(w);
                             }
                         }

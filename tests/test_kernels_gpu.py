@@ -778,12 +778,12 @@ def test_reduce_rows_job_over_thousands_of_partial_rows(sfv, rows, C, acc):
 
 
 @pytest.mark.parametrize("variant,in_ch,dtype,Ld,hw", [("percep", 4, "bf16", 32, (16, 16)), ("percep", 4, "f32", 25, (16, 24)),
-                                                        ("contrastive", 3, "bf16", 50, (32, 16)), ("percep", 4, "bf16", 32, (32, 32)),
-                                                        ("contrastive", 3, "bf16", 25, (64, 48)), ("percep", 4, "f32", 32, (40, 24))])
+                                                        ("contrastive", 3, "bf16", 50, (32, 16)), ("percep", 4, "bf16", 32, (88, 160)),
+                                                        ("contrastive", 3, "bf16", 25, (256, 256)), ("percep", 4, "f32", 32, (96, 128))])
 def test_fused_update_jobs_equal_adam_plus_pack(sfv, variant, in_ch, dtype, Ld, hw):
     """Engine.update_jobs (optimiser step + weight repack as one batched job launch: kinds 3 / 6 / 7 with an Adam context)
     against rbvae_adam_step followed by Engine.pack: parameters, both moments and every packed copy bit for bit.  The last
-    three shapes have fc weights of >= 65536 elements: their permuted copies go through the job's LDS tiles."""
+    three shapes have fc weights of >= 1 M elements: their permuted copies go through the job's LDS tiles."""
     from importlib import import_module
     E = import_module("symbols-from-video_amd.engine")
     g = torch.Generator().manual_seed(95)
