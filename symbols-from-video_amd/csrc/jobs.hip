@@ -328,11 +328,28 @@ __global__ __launch_bounds__(256) void run_jobs_k(const Job* __restrict__ jobs) 
                 float* tile = (float*)lds_raw;                                           // [T0 * T1][T2 + 1]
                 for (unsigned t = blockIdx.x; t < nt0 * nt1 * nt2; t += gridDim.x) {
                     const unsigned b2 = (t % nt2) * T2, b1 = ((t / nt2) % nt1) * T1, b0 = (t / (nt2 * nt1)) * T0;
-                    for (unsigned e = threadIdx.x; e < tel; e += 256) {                  // master order: i2 fastest
-                        const unsigned l2 = e % T2, l1 = (e / T2) % T1, l0 = e / (T2 * T1);
-                        if (b0 + l0 < D0 && b1 + l1 < d1 && b2 + l2 < d2) {
-                            const long i = ((long)(b0 + l0) * d1 + (b1 + l1)) * d2 + (b2 + l2);
-                            tile[(l0 * T1 + l1) * pitch + l2] = adam_at(c, base + i, step_size, bc2_sqrt);
+                    // master order (i2 fastest), four elements per thread and round: their 16 loads are in flight together
+                    // (one element per round was 32 dependent round trips per tile: the stores of one may alias the loads of
+                    // the next as far as the compiler knows)
+                    for (unsigned e0 = threadIdx.x; e0 < tel; e0 += 1024) {
+                        long off[4]; unsigned li[4]; bool ok[4];
+                        float pw[4], pg[4], pm[4], pv[4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const unsigned e = e0 + 256 * u;
+                            const unsigned l2 = e % T2, l1 = (e / T2) % T1, l0 = e / (T2 * T1);
+                            ok[u] = e < tel && b0 + l0 < D0 && b1 + l1 < d1 && b2 + l2 < d2;
+                            off[u] = base + ((long)(b0 + l0) * d1 + (b1 + l1)) * d2 + (b2 + l2);
+                            li[u] = (l0 * T1 + l1) * pitch + l2;
+                            if (ok[u]) { pw[u] = c.w[off[u]]; pg[u] = c.g[off[u]]; pm[u] = c.m[off[u]]; pv[u] = c.v[off[u]]; }
+                        }
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            if (ok[u]) {
+                                const float w = adam_value(pw[u], pg[u], pm[u], pv[u], c, step_size, bc2_sqrt);
+                                c.m[off[u]] = pm[u]; c.v[off[u]] = pv[u]; c.w[off[u]] = w;
+                                tile[li[u]] = w;
+                            }
                         }
                     }
                     __syncthreads();
