@@ -173,10 +173,10 @@ def roofline_leg(trainer, steps, tname, overlap):
         with timers.setdefault(name, KernelTimer())(2.0 * rows * nout * kc * t_eff):
             return orig_gemm(*args, **kw)
 
-    def timed_wgrad(Dy, In, idx, P, Co, Ci, ldy, ldi, taps, out, dims, strides, tag=None):
+    def timed_wgrad(Dy, In, idx, P, Co, Ci, ldy, ldi, taps, out, dims, strides, tag=None, **kw):
         name = "wgrad_gemm_k<%s, %d, K-split>" % (tname, 2 if Ci > 64 else 1)
         with timers.setdefault(name, KernelTimer())(2.0 * P * Co * Ci * taps):
-            return orig_wgrad(Dy, In, idx, P, Co, Ci, ldy, ldi, taps, out, dims, strides, tag=tag)
+            return orig_wgrad(Dy, In, idx, P, Co, Ci, ldy, ldi, taps, out, dims, strides, tag=tag, **kw)
 
     calib = KernelTimer()                  # event pairs around nothing: the event records' own cost
 
