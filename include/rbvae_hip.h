@@ -237,7 +237,7 @@ int rbvae_run_jobs(const void* jobs_dev, int njobs, int blocks_per_job, void* st
 int rbvae_im2col(int dtype, const float* src, long sn, long sc, long sh, long sw, int N, int C, int IH, int IW,
                  int OH, int OW, int KH, int KW, int stride, int pad, int Kpad, void* col, void* stream);
 /* The first Conv2d(3x3, stride 2, pad 1; Cin <= 4 -> Nout <= 256) + bias + ReLU + Dropout (percep_RBVAE_model.py:51-53)
- * as ONE kernel, bf16: rbvae_im2col_frames (col [N*OH*OW][64] is still written: the weight gradient reads it) + the
+ * as ONE kernel, bf16: rbvae_im2col_frames (col [N*OH*OW][64] is written for rbvae_wgrad_gemm unless col == NULL) + the
  * single-slice rbvae_gather_gemm, with the patch gathered in LDS and results stored from the accumulators.  W is the
  * packed [Nout][64] im2col-order weight; x frames f32 [Cin][IH][IW] through the frame map (fd1 == 0: frame n at
  * n*fs2); drop_mode 0 / 1 with rbvae_gather_gemm's key and element indices. */
@@ -257,6 +257,19 @@ int rbvae_deconv_last_dgrad_blocks(int dtype, int Cout, int OH, int OW, int C1, 
 int rbvae_deconv_last_dgrad_fused(int dtype, const float* dpre, const void* W, const void* zero_page, void* col,
                                   const void* gate, void* out, int N, int Cout, int OH, int OW, int C1, int ldo, float scale,
                                   float* colsum_ws, void* stream);
+
+/* Weight gradient of those two layers WITHOUT the im2col rows: dW[ks][co][k] = sum over the K-slice's output pixels p of
+ * dY[p][co] * col(x)[p][k], k = (kh*3+kw)*Cin + ci zero padded to 64 -- rbvae_wgrad_gemm's sums over the [rows][64] im2col rows
+ * (one tap), in its slab layout [ksplit][Nout][64], with the rows rebuilt in LDS from the 3/4-channel image instead of read
+ * back (128 bytes per pixel for 12-16 bytes of image).  mode 0: x = the input frames through the frame map (as
+ * rbvae_conv_first_fused), dY = the gradient at the first Conv2d's output (percep_RBVAE_model.py:51, autograd as run by
+ * percep_RBVAE_train.py:552); mode 1: x = d(loss)/d(pre-sigmoid) [N][IH][IW][Cin] f32, dY = the stored activation in front of
+ * the last ConvTranspose2d (:82).  With it the two kernels above take col = NULL.  K-slices are runs of
+ * rbvae_wgrad_first_blocks(..) / ksplit blocks of 8 x 16 output pixels; grid = (Nout / 64) * ksplit workgroups. */
+int rbvae_wgrad_first_blocks(int dtype, int Cin, int IH, int IW, int Nout, int N);
+int rbvae_wgrad_first(int dtype, int mode, const float* x, int fd1, int fd2, long fs0, long fs1, long fs2, const void* dY,
+                      float* dW_slabs, const void* zero_page, int N, int Cin, int IH, int IW, int Nout, int ldy, int ksplit,
+                      void* stream);
 /* Last ConvTranspose2d + Sigmoid (percep_RBVAE_model.py:82-83) fused with recon_loss
  * (percep_RBVAE_train.py:32-33): Y[(n,a,b)][t*Cout+co] = per-tap products; gathers them (col2im),
  * adds bias, applies sigmoid, writes x_recon NCHW f32; with target: sse_mean[0] = mse and

@@ -203,7 +203,7 @@ template <int CIN, int MODE, int NQ> __global__ __launch_bounds__(512, NQ == 1 ?
         pk[2] = (unsigned)e[4] | ((unsigned)e[5] << 16); pk[3] = (unsigned)e[6] | ((unsigned)e[7] << 16);
         *(u32x4_t*)(s_a + r * 128 + ((c ^ ((r >> 1) & 7)) * 16)) = pk;
         const int oh = oh0 + oy, ow = ow0 + ox;
-        if (CF_DBG != 2 && oh < p.OH && ow < p.OW)
+        if (CF_DBG != 2 && p.col && oh < p.OH && ow < p.OW)     // col == null: the weight gradient rebuilds the rows (wgrad_first_k)
             *(u32x4_t*)(p.col + ((size_t)(n * p.OH + oh) * p.OW + ow) * 128 + c * 16) = pk;
     }
     __syncthreads();
@@ -302,6 +302,205 @@ template <int CIN, int MODE, int NQ> __global__ __launch_bounds__(512, NQ == 1 ?
     }
 }
 
+
+// ---- weight gradient of the two 3/4-channel ends WITHOUT the im2col rows in HBM -------------------------------------------
+//   dW[ks][co][k] = sum_{p in K-slice ks} dY[p][co] * col(x)[p][k],   k = (kh*3+kw)*CIN + ci  (zero padded to 64)
+// MODE 0: the first Conv2d's weight (x = the input frames; dY = the gradient at its output); MODE 1: the last
+// ConvTranspose2d's (x = d(loss)/d(pre-sigmoid) NHWC f32; dY = the stored activation in front of it) -- the sums
+// rbvae_wgrad_gemm forms from the [rows][64] im2col rows that conv_first_fused_k writes (128 bytes per pixel for 12-16 bytes
+// of image: on 256 x 256 frames 268 MB written and 268 MB re-read per weight).  Here a workgroup walks 8 x 16 blocks of
+// output pixels: the block's input patch is prefetched into registers one block ahead, the im2col rows are rebuilt in
+// LDS (pixel-major 128-byte rows: the reduction index is the row), the [128 px][64 co] tile of dY arrives by LDS-DMA one
+// block ahead, fragments by ds_read_b64_tr_b16.  Tile 64 co x 64 k, 2 sub-tiles per wave; two workgroups per CU.
+struct WfArgs {
+    const float* x; CfFrameMap fm;
+    const unsigned char* dY;     // [N*OH*OW][ldy] bf16
+    const unsigned char* zero;
+    float* dW;                   // [ksplit][Nout][64] f32
+    int N, Cin, IH, IW, OH, OW, Nout, ldy, ksplit, per, nblk;
+};
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+__device__ __forceinline__ int wf_swz(int row) { return (((row >> 1) & 1) | (((row >> 3) & 1) << 1)) << 1; }   // tr_swz<128> (wgrad_gemm.hip)
+__device__ __forceinline__ void wf_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+template <int CIN, int MODE> __global__ __launch_bounds__(512, 4) void wgrad_first_k(const WfArgs p) {
+    __shared__ __attribute__((aligned(16))) unsigned char s_col[128 * 128];       // im2col rows [px][64 k], tr-swizzled
+    __shared__ __attribute__((aligned(16))) unsigned char s_dy[2][128 * 128];     // dY tile [px][64 co], tr-swizzled, double-buffered
+    __shared__ float s_patch[4 * CF_PA * CF_PP];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nco = p.Nout >> 6;
+    const int cot = blockIdx.x % nco, ks = blockIdx.x / nco;
+    const int co0 = cot * 64;
+    const int tb_n = (p.OW + CF_TB - 1) / CF_TB, ta_n = (p.OH + CF_TA - 1) / CF_TA;
+    const int blk0 = ks * p.per, blk1 = min(blk0 + p.per, p.nblk);
+    static constexpr CfOff<CIN, MODE> otab{};
+    int koff[8];
+#pragma unroll
+    for (int k8 = 0; k8 < 8; ++k8) koff[k8] = otab.v[(tid & 7) * 8 + k8];
+
+    // patch of block blk -> registers (the loads of conv_first_fused_k)
+    constexpr int R0 = CIN * CF_PA, PIT0 = ((R0 + 1) / 2 + 7) / 8;
+    constexpr int RUN = CF_PB * CIN, PN = CF_PA * RUN, PIT1 = (PN + 511) / 512;
+    constexpr int PIT = MODE == 0 ? PIT0 : PIT1;
+    float pv[PIT], hv = 0.f;
+    auto load_patch = [&](int blk) {
+        unsigned b = blk;
+        const int tbi = b % (unsigned)tb_n; b /= (unsigned)tb_n;
+        const int tai = b % (unsigned)ta_n;
+        const int n = b / (unsigned)ta_n;
+        const int ih0 = 2 * tai * CF_TA - 1, iw0 = 2 * tbi * CF_TB - 1;
+        if constexpr (MODE == 0) {
+            const float* xf = p.x + cf_frame_off(p.fm, n);
+#pragma unroll
+            for (int it = 0; it < PIT; ++it) {
+                const int row = 2 * (w + 8 * it) + (lane >> 5);
+                const int c = row / CF_PA, r = row - c * CF_PA;
+                const int ih = ih0 + r, iw = iw0 + 1 + (lane & 31);
+                pv[it] = 0.f;
+                if (row < R0 && ih >= 0 && ih < p.IH && iw < p.IW) pv[it] = xf[((size_t)c * p.IH + ih) * p.IW + iw];
+            }
+            hv = 0.f;
+            if (tid < R0) {
+                const int c = tid / CF_PA, r = tid - c * CF_PA;
+                const int ih = ih0 + r;
+                if (ih >= 0 && ih < p.IH && iw0 >= 0) hv = xf[((size_t)c * p.IH + ih) * p.IW + iw0];
+            }
+        } else {
+            const float* xf = p.x + (size_t)n * p.IH * p.IW * CIN;
+#pragma unroll
+            for (int it = 0; it < PIT; ++it) {
+                const int i = it * 512 + tid;
+                const int r = i / RUN, j = i - r * RUN;
+                const int ih = ih0 + r, iw = iw0 + j / CIN;
+                pv[it] = 0.f;
+                if (i < PN && ih >= 0 && ih < p.IH && iw >= 0 && iw < p.IW) pv[it] = xf[((long)ih * p.IW + iw0) * CIN + j];
+            }
+        }
+    };
+    auto store_patch = [&]() {
+        if constexpr (MODE == 0) {
+#pragma unroll
+            for (int it = 0; it < PIT; ++it) {
+                const int row = 2 * (w + 8 * it) + (lane >> 5);
+                if (row < R0) s_patch[row * CF_PP + 1 + (lane & 31)] = pv[it];
+            }
+            if (tid < R0) s_patch[tid * CF_PP] = hv;
+        } else {
+#pragma unroll
+            for (int it = 0; it < PIT; ++it) {
+                const int i = it * 512 + tid;
+                const int r = i / RUN, j = i - r * RUN;
+                if (i < PN) s_patch[r * (CF_PP * CIN) + j] = pv[it];
+            }
+        }
+    };
+    // dY tile of block blk -> s_dy[buf]: 16 LDS-DMA instructions of 8 rows, two per wave
+    auto stage_dy = [&](int blk, int buf) {
+        unsigned b = blk;
+        const int tbi = b % (unsigned)tb_n; b /= (unsigned)tb_n;
+        const int tai = b % (unsigned)ta_n;
+        const int n = b / (unsigned)ta_n;
+#pragma unroll
+        for (int i2 = 0; i2 < 2; ++i2) {
+            const int r = (2 * w + i2) * 8 + (lane >> 3);
+            const int oh = tai * CF_TA + (r >> 4), ow = tbi * CF_TB + (r & 15);
+            const bool v = oh < p.OH && ow < p.OW;
+            const unsigned char* src = p.dY + ((size_t)(n * p.OH + oh) * p.OW + ow) * ((size_t)p.ldy * 2) + co0 * 2 +
+                                       (((lane & 7) ^ wf_swz(r)) * 16);
+            cf_glds16(v ? src : p.zero, s_dy[buf] + (2 * w + i2) * 1024);
+        }
+    };
+
+    // consumer: wave w = co sub-tile w & 3 x the k sub-tiles 2 (w >> 2), 2 (w >> 2) + 1
+    const int fi = lane & 15, fg = lane >> 4;
+    const int q = fi >> 2, pp = fi & 3;
+    const int mt = w & 3, nt0 = (w >> 2) * 2;
+    const int row0 = 8 * fg + q;
+    const int offA = row0 * 128 + (((mt * 2 + (pp >> 1)) ^ wf_swz(row0)) * 16) + (pp & 1) * 8;
+    const int offB0 = row0 * 128 + (((nt0 * 2 + (pp >> 1)) ^ wf_swz(row0)) * 16) + (pp & 1) * 8;
+    const int offB1 = row0 * 128 + ((((nt0 + 1) * 2 + (pp >> 1)) ^ wf_swz(row0)) * 16) + (pp & 1) * 8;
+    f32x4_t acc0 = f32x4_t{0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
+    const unsigned l_col = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)s_col;
+    const unsigned l_dy = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)s_dy[0];
+
+    if (blk0 < blk1) {
+        load_patch(blk0);
+        stage_dy(blk0, 0);
+    }
+    int buf = 0;
+    for (int blk = blk0; blk < blk1; ++blk) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // this block's patch registers and dY tile (issued a block ago)
+#pragma unroll
+        for (int it = 0; it < PIT; ++it) asm volatile("" : "+v"(pv[it]));
+        asm volatile("" : "+v"(hv));
+        store_patch();
+        if (blk + 1 < blk1) load_patch(blk + 1);                         // lands under this block's work
+        wf_lds_barrier();
+        // im2col rows: 128 rows x 8 chunks of 8 columns
+#pragma unroll
+        for (int i0 = 0; i0 < 128 * 8; i0 += 512) {
+            const int i = i0 + tid;
+            const int r = i >> 3, c = i & 7;
+            const int oy = r >> 4, ox = r & 15;
+            const int corner = (2 * oy * CF_PP + 2 * ox) * (MODE == 0 ? 1 : CIN);
+            unsigned short e[8];
+#pragma unroll
+            for (int k8 = 0; k8 < 8; ++k8) {
+                const float v = koff[k8] >= 0 ? s_patch[corner + max(koff[k8], 0)] : 0.f;
+                e[k8] = f32_to_bf16(v);
+            }
+            u32x4_t pk;
+            pk[0] = (unsigned)e[0] | ((unsigned)e[1] << 16); pk[1] = (unsigned)e[2] | ((unsigned)e[3] << 16);
+            pk[2] = (unsigned)e[4] | ((unsigned)e[5] << 16); pk[3] = (unsigned)e[6] | ((unsigned)e[7] << 16);
+            *(u32x4_t*)(s_col + r * 128 + ((c ^ wf_swz(r)) * 16)) = pk;
+        }
+        wf_lds_barrier();
+        // the next block's dY tile: issued HERE, behind the last compiler-visible LDS access of the block (in front of one
+        // the compiler drains every LDS-DMA); the fragment reads below are asm
+        if (blk + 1 < blk1) stage_dy(blk + 1, buf ^ 1);
+        const unsigned la = l_dy + buf * (128 * 128);
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) {
+            s16x4_t al, ah, b0l, b0h, b1l, b1h;
+            const unsigned ada = la + offA + kb * (32 * 128), adb0 = l_col + offB0 + kb * (32 * 128), adb1 = l_col + offB1 + kb * (32 * 128);
+            asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(al) : "v"(ada));
+            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:512" : "=v"(ah) : "v"(ada));
+            asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(b0l) : "v"(adb0));
+            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:512" : "=v"(b0h) : "v"(adb0));
+            asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(b1l) : "v"(adb1));
+            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:512" : "=v"(b1h) : "v"(adb1));
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(al), "+v"(ah), "+v"(b0l), "+v"(b0h), "+v"(b1l), "+v"(b1h));
+            const bf16x8_t fa = bf16x8_t{al[0], al[1], al[2], al[3], ah[0], ah[1], ah[2], ah[3]};
+            const bf16x8_t fb0 = bf16x8_t{b0l[0], b0l[1], b0l[2], b0l[3], b0h[0], b0h[1], b0h[2], b0h[3]};
+            const bf16x8_t fb1 = bf16x8_t{b1l[0], b1l[1], b1l[2], b1l[3], b1h[0], b1h[1], b1h[2], b1h[3]};
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb0, fa, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb1, fa, acc1, 0, 0, 0);
+        }
+        wf_lds_barrier();                                                // everyone is done with s_patch / s_col / s_dy[buf]
+        buf ^= 1;
+    }
+    // D[row = k 4 fg + r][col = co fi]: a lane owns 4 consecutive k of one co
+    float* slab = p.dW + ((size_t)ks * p.Nout + co0 + mt * 16 + fi) * 64 + 4 * fg;
+    *(f32x4_t*)(slab + nt0 * 16) = acc0;
+    *(f32x4_t*)(slab + (nt0 + 1) * 16) = acc1;
+}
+
+static int wf_shape_ok(int dtype, int Cin, int IH, int IW, int Nout, int N) {
+    const int OH = (IH + 2 - 3) / 2 + 1, OW = (IW + 2 - 3) / 2 + 1;
+    return dtype == RBVAE_BF16 && Cin >= 1 && Cin <= 4 && Nout >= 64 && Nout % 64 == 0 && N >= 1 && IH >= 1 && IW >= 1 &&
+           (long)N * OH * OW * 256 < (1l << 31) && (long)N * Cin * IH * IW < (1l << 40);
+}
+template <int MODE> static void wf_launch(const WfArgs& a, hipStream_t st) {
+    const int blocks = (a.Nout / 64) * a.ksplit;
+    switch (a.Cin) {
+        case 1: hipLaunchKernelGGL((wgrad_first_k<1, MODE>), dim3(blocks), dim3(512), 0, st, a); break;
+        case 2: hipLaunchKernelGGL((wgrad_first_k<2, MODE>), dim3(blocks), dim3(512), 0, st, a); break;
+        case 3: hipLaunchKernelGGL((wgrad_first_k<3, MODE>), dim3(blocks), dim3(512), 0, st, a); break;
+        default: hipLaunchKernelGGL((wgrad_first_k<4, MODE>), dim3(blocks), dim3(512), 0, st, a); break;
+    }
+}
+
 static int cf_shape_ok(int dtype, int Cin, int IH, int IW, int Nout, int N) {
     const int OH = (IH + 2 - 3) / 2 + 1, OW = (IW + 2 - 3) / 2 + 1;
     return dtype == RBVAE_BF16 && Cin >= 1 && Cin <= 4 && Nout >= 8 && Nout <= 256 && Nout % 8 == 0 && N >= 1 && IH >= 1 &&
@@ -334,7 +533,7 @@ extern "C" int rbvae_conv_first_fused(int dtype, const float* x, int fd1, int fd
                                       const float* bias, const void* zero_page, void* col, void* out, int N, int Cin, int IH,
                                       int IW, int Nout, int ldo, int relu, int drop_mode, float drop_p, float scale,
                                       unsigned long long seed, const unsigned long long* seed_dev, void* stream) {
-    RBVAE_CHECK_ARG(x && W && zero_page && col && out, "conv_first_fused: null pointer");
+    RBVAE_CHECK_ARG(x && W && zero_page && out, "conv_first_fused: null pointer");
     RBVAE_CHECK_ARG(cf_shape_ok(dtype, Cin, IH, IW, Nout, N), "conv_first_fused: shape outside the fused kernel "
                     "(bf16, Cin <= 4, Nout <= 256): Cin=%d %dx%d Nout=%d", Cin, IH, IW, Nout);
     RBVAE_CHECK_ARG(ldo >= Nout && ldo % 8 == 0, "conv_first_fused: ldo=%d", ldo);
@@ -362,7 +561,7 @@ extern "C" int rbvae_deconv_last_dgrad_blocks(int dtype, int Cout, int OH, int O
 extern "C" int rbvae_deconv_last_dgrad_fused(int dtype, const float* dpre, const void* W, const void* zero_page, void* col,
                                              const void* gate, void* out, int N, int Cout, int OH, int OW, int C1, int ldo,
                                              float scale, float* colsum_ws, void* stream) {
-    RBVAE_CHECK_ARG(dpre && W && zero_page && col && gate && out, "deconv_last_dgrad_fused: null pointer");
+    RBVAE_CHECK_ARG(dpre && W && zero_page && gate && out, "deconv_last_dgrad_fused: null pointer");
     RBVAE_CHECK_ARG(cf_shape_ok(dtype, Cout, OH, OW, C1, N), "deconv_last_dgrad_fused: shape outside the fused kernel "
                     "(bf16, Cout <= 4, C1 <= 256): Cout=%d %dx%d C1=%d", Cout, OH, OW, C1);
     RBVAE_CHECK_ARG(ldo >= C1 && ldo % 8 == 0, "deconv_last_dgrad_fused: ldo=%d", ldo);
@@ -376,5 +575,34 @@ extern "C" int rbvae_deconv_last_dgrad_fused(int dtype, const float* dpre, const
     a.Nout = C1; a.ldo = ldo; a.relu = 0; a.drop_mode = 0; a.scale = scale; a.drop_thresh = 0; a.seed = 0; a.seed_dev = nullptr;
     cf_launch<1>(a, (hipStream_t)stream);
     RBVAE_CHECK_LAUNCH("deconv_last_dgrad_fused");
+    return RBVAE_OK;
+}
+
+/* 8 x 16 output-pixel blocks rbvae_wgrad_first walks (the caller sizes ksplit against it); 0 when the shape is not covered
+ * (bf16, Cin <= 4, Nout a multiple of 64) */
+extern "C" int rbvae_wgrad_first_blocks(int dtype, int Cin, int IH, int IW, int Nout, int N) {
+    if (!wf_shape_ok(dtype, Cin, IH, IW, Nout, N)) return 0;
+    return N * cdiv((IH + 2 - 3) / 2 + 1, CF_TA) * cdiv((IW + 2 - 3) / 2 + 1, CF_TB);
+}
+
+extern "C" int rbvae_wgrad_first(int dtype, int mode, const float* x, int fd1, int fd2, long fs0, long fs1, long fs2, const void* dY,
+                                 float* dW_slabs, const void* zero_page, int N, int Cin, int IH, int IW, int Nout, int ldy,
+                                 int ksplit, void* stream) {
+    RBVAE_CHECK_ARG(x && dY && dW_slabs && zero_page, "wgrad_first: null pointer");
+    RBVAE_CHECK_ARG(mode == 0 || mode == 1, "wgrad_first: mode %d (0 = frames through the frame map, 1 = NHWC f32)", mode);
+    RBVAE_CHECK_ARG(wf_shape_ok(dtype, Cin, IH, IW, Nout, N), "wgrad_first: shape not covered (bf16, Cin <= 4, Nout %% 64 == 0): "
+                    "Cin=%d %dx%d Nout=%d", Cin, IH, IW, Nout);
+    RBVAE_CHECK_ARG(ldy >= Nout && ldy % 8 == 0, "wgrad_first: ldy=%d", ldy);
+    RBVAE_CHECK_ARG(((uintptr_t)dY | (uintptr_t)dW_slabs | (uintptr_t)zero_page) % 16 == 0, "wgrad_first: pointers must be 16-byte aligned");
+    WfArgs a;
+    a.x = x; a.fm = mode == 0 ? CfFrameMap{fd1, fd2, fs0, fs1, fs2} : CfFrameMap{0, 0, 0, 0, 0};
+    a.dY = (const unsigned char*)dY; a.zero = (const unsigned char*)zero_page; a.dW = dW_slabs;
+    a.N = N; a.Cin = Cin; a.IH = IH; a.IW = IW; a.OH = (IH + 2 - 3) / 2 + 1; a.OW = (IW + 2 - 3) / 2 + 1;
+    a.Nout = Nout; a.ldy = ldy;
+    a.nblk = N * cdiv(a.OH, CF_TA) * cdiv(a.OW, CF_TB);
+    RBVAE_CHECK_ARG(ksplit >= 1 && ksplit <= a.nblk, "wgrad_first: ksplit=%d (1 .. %d blocks)", ksplit, a.nblk);
+    a.ksplit = ksplit; a.per = cdiv(a.nblk, ksplit);
+    if (mode == 0) wf_launch<0>(a, (hipStream_t)stream); else wf_launch<1>(a, (hipStream_t)stream);
+    RBVAE_CHECK_LAUNCH("wgrad_first");
     return RBVAE_OK;
 }

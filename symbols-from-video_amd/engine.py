@@ -191,7 +191,7 @@ class JobList:
 
 class Saved:
     """Activations one forward call keeps for its backward."""
-    __slots__ = ("N", "S", "T", "hw", "train", "tau", "tau_dev", "hard", "col1", "a1", "a2", "a3", "e", "hs_enc", "hp_enc",
+    __slots__ = ("N", "S", "T", "hw", "train", "tau", "tau_dev", "hard", "col1", "x_in", "fm_in", "a1", "a2", "a3", "e", "hs_enc", "hp_enc",
                  "acts_enc", "cs_enc", "y", "z", "hs_dec", "hp_dec", "acts_dec", "cs_dec", "ds_pad", "f", "d1", "d2",
                  "xr", "gate_scale", "dpre3", "b3_parts")
 
@@ -266,6 +266,10 @@ class Engine:
         self.wgrad_halo = True
         self._wh_min_steps = 8
         self._wh_max_tiles = 2
+        # weight gradients of the two 3/4-channel ends from the image itself instead of from im2col rows in HBM
+        # (rbvae_wgrad_first, csrc/conv_first.hip) when every workgroup gets at least this many 8 x 16 pixel blocks
+        self.wgrad_first = True
+        self._wf_min_steps = 8
         self.lstm_pair_bwd = True   # both stacks' BPTT in one launch
         self.keep_dz = False                # also store the codes' gradient
         self._wg_nt4_slab = 8     # cap on a weight's f32 slabs, M floats
@@ -583,6 +587,22 @@ class Engine:
         self._conv_idx(N, h1, w1, h2, w2)
         self._conv_idx(N, h2, w2, h3, w3)
 
+    def _wf_ksplit(self, N, Cin, IH, IW, Nout):
+        """K-slices of rbvae_wgrad_first for this layer, or 0 when the im2col-row path stays (f32, a shape outside the
+        kernel, or too few pixel blocks per workgroup: the bench shape keeps its rows -- 8 MB, 4 blocks per workgroup)."""
+        if not (self.wgrad_first and self.dt == BF16 and self.k == 3):
+            return 0
+        nblk = L.query("rbvae_wgrad_first_blocks", self.dt, Cin, IH, IW, Nout, N)
+        if nblk == 0:
+            return 0
+        ks = max(1, min(512 // (Nout // 64), nblk))            # two workgroups per CU
+        return ks if nblk // ks >= self._wf_min_steps else 0
+
+    def _wgrad_first(self, mode, x, fm, Dy, N, Cin, IH, IW, Nout, ldy, ks, out, dims, strides, tag=None):
+        slabs = self._buf(("slabs", tag), ks * Nout * 64)
+        L.call("rbvae_wgrad_first", self.dt, mode, x, *fm, Dy, slabs, self.zero, N, Cin, IH, IW, Nout, ldy, ks)
+        self._wgrad_reduce(slabs, out, Nout, 64, 1, ks, dims, strides)
+
     def _wgrad(self, Dy, In, idx, P, Co, Ci, ldy, ldi, taps, out, dims, strides, tag=None, geom=None):
         """wgrad GEMM into K-slice slabs; their fixed-order reduction into the torch layout is a job.
         geom = (Nimg, OH, OW, IH, IW) of a 3x3 stride-2 layer (Dy rows at OH x OW, In rows at IH x IW): with the nine taps
@@ -737,12 +757,16 @@ class Engine:
         # encoder CNN
         if repack:
             self.pack_begin(flat)
-        sv.col1 = self._E(N * h1 * w1, self.K1)
         sv.a1 = self._E(N * h1 * w1, c1)
         m, mk = dm(0)
         fm = frame_map if frame_map is not None else (0, 0, 0, 0, C * H * W)
-        if (self.conv_first_fused and k == 3 and self.K1 == 64 and m != 2
-                and L.query("rbvae_conv_first_fused_ok", self.dt, C, H, W, c1, N)):
+        fused1 = bool(self.conv_first_fused and k == 3 and self.K1 == 64 and m != 2
+                      and L.query("rbvae_conv_first_fused_ok", self.dt, C, H, W, c1, N))
+        # the im2col rows are written for the weight gradient unless it rebuilds them from the frames (rbvae_wgrad_first)
+        keep_col = not (fused1 and train and self._wf_ksplit(N, C, H, W, c1))
+        sv.col1 = self._E(N * h1 * w1, self.K1) if keep_col else None
+        sv.x_in, sv.fm_in = x, fm
+        if fused1:
             # im2col + GEMM + bias/ReLU/dropout of the first conv in one kernel (csrc/conv_first.hip)
             L.call("rbvae_conv_first_fused", self.dt, x, *fm, self.W1p, P(f"encoder_cnn.conv.{i0}.bias"), self.zero,
                    sv.col1, sv.a1, N, C, H, W, c1, c1, 1, m, float(drop), float(dscale), int(seed * 8 + 1), self.seed_dev)
@@ -986,10 +1010,11 @@ class Engine:
             dpre3 = sv.dpre3
             if dpre3 is None:
                 raise RuntimeError("backward without g_xr needs forward(target=..., need_grad=True)")
-        col3 = tmp("col3", P1, self.K3)
         dd2 = tmp("dd2", P1, c1)
         nb = (L.query("rbvae_deconv_last_dgrad_blocks", self.dt, oc, H, W, c1, N)
               if self.conv_first_fused and k == 3 and self.K3 == 64 else 0)
+        wf3 = self._wf_ksplit(N, oc, H, W, c1) if nb else 0      # the last deconv's weight gradient from dpre3 itself
+        col3 = None if wf3 else tmp("col3", P1, self.K3)
         if nb:
             # im2col + GEMM + gate + bias-gradient partial sums in one kernel (csrc/conv_first.hip, MODE 1)
             ws = self._buf((N, "colsum_dd2f"), nb * c1)
@@ -1025,8 +1050,12 @@ class Engine:
                                slab=4)
             else:
                 self._colsum(F32, dpre3, N * H * W, oc, oc, G(f"decoder_cnn.deconv.{i2}.bias"), tag=(N, "b3"))
-            self._wgrad(sv.d2, col3, None, P1, c1, self.K3, c1, self.K3, 1, G(f"decoder_cnn.deconv.{i2}.weight"),
-                        (c1, oc, kk), (self.K3, 1, oc), tag=(N, "V3"))
+            if wf3:
+                self._wgrad_first(1, dpre3, (0, 0, 0, 0, 0), sv.d2, N, oc, H, W, c1, c1, wf3,
+                                  G(f"decoder_cnn.deconv.{i2}.weight"), (c1, oc, kk), (self.K3, 1, oc), tag=(N, "V3"))
+            else:
+                self._wgrad(sv.d2, col3, None, P1, c1, self.K3, c1, self.K3, 1, G(f"decoder_cnn.deconv.{i2}.weight"),
+                            (c1, oc, kk), (self.K3, 1, oc), tag=(N, "V3"))
             self._wgrad(sv.d1, dd2, self._conv_idx(N, h1, w1, h2, w2), P2, c2, c1, c2, c1, kk,
                         G(f"decoder_cnn.deconv.{i1}.weight"), (c2, c1, kk), (kk * c1, 1, c1), tag=(N, "V2"),
                         geom=(N, h2, w2, h1, w1))
@@ -1279,9 +1308,15 @@ class Engine:
         self._gemm(da2, self.W2d, da1, None, sv.a1, None, N, h2, w2, h2, w2, 1, h1, w1, 2, c2, c1, c2, c1, kk, "dgrad",
                    scale=gs, bias_grad=G(f"encoder_cnn.conv.{i0}.bias"), tag=(N, "da1"))
         # --- conv1 (1-tap GEMM over the saved im2col columns)
-        on_tail(4, lambda: self._wgrad(da1, sv.col1, None, P1, c1, self.K1, c1, self.K1, 1,
-                                       G(f"encoder_cnn.conv.{i0}.weight"), (c1, self.in_ch, kk),
-                                       (self.K1, 1, self.in_ch), tag=(N, "W1")))
+        if sv.col1 is None:
+            wf1 = self._wf_ksplit(N, self.in_ch, H, W, c1)
+            on_tail(4, lambda: self._wgrad_first(0, sv.x_in, sv.fm_in, da1, N, self.in_ch, H, W, c1, c1, wf1,
+                                                 G(f"encoder_cnn.conv.{i0}.weight"), (c1, self.in_ch, kk),
+                                                 (self.K1, 1, self.in_ch), tag=(N, "W1")))
+        else:
+            on_tail(4, lambda: self._wgrad(da1, sv.col1, None, P1, c1, self.K1, c1, self.K1, 1,
+                                           G(f"encoder_cnn.conv.{i0}.weight"), (c1, self.in_ch, kk),
+                                           (self.K1, 1, self.in_ch), tag=(N, "W1")))
         if defer_side:
             issue_decoder_side()
         # every slab / partial-sum reduction of this pass in one launch, once the side stream has caught up

@@ -716,6 +716,82 @@ def test_deconv_last_dgrad_fused(sfv, N, Cout, OH, OW, C1):
     assert torch.equal(out_c.view(torch.int16), out_b.view(torch.int16))
 
 
+@pytest.mark.parametrize("N,Cin,IH,IW,Nout,ks", [(3, 4, 32, 32, 256, 2), (2, 3, 21, 40, 64, 3), (4, 3, 64, 64, 64, 7),
+                                                  (2, 4, 7, 70, 128, 1), (5, 1, 16, 16, 64, 5)])
+def test_wgrad_first_rebuilds_the_im2col_rows(sfv, N, Cin, IH, IW, Nout, ks):
+    """rbvae_wgrad_first (csrc/conv_first.hip): the weight gradients of the first Conv2d (mode 0: frames, also through a
+    frame map) and of the last ConvTranspose2d (mode 1: NHWC f32 image) from the 3/4-channel image itself, against
+    rbvae_wgrad_gemm over the [rows][64] im2col rows the fused forward kernels write -- the same bf16 products, f32 sums
+    in another order -- and against autograd of F.conv2d.  With it the forward kernels take col = NULL and store the same
+    outputs."""
+    L = sfv._lib
+    g = torch.Generator().manual_seed(170 + IH + Nout)
+    OH, OW = (IH - 1) // 2 + 1, (IW - 1) // 2 + 1
+    P = N * OH * OW
+    zero = torch.zeros(256, dtype=torch.uint8, device="cuda")
+    nblk = L.query("rbvae_wgrad_first_blocks", 1, Cin, IH, IW, Nout, N)
+    assert nblk == N * -(-OH // 8) * -(-OW // 16)
+    assert L.query("rbvae_wgrad_first_blocks", 0, Cin, IH, IW, Nout, N) == 0
+    assert L.query("rbvae_wgrad_first_blocks", 1, Cin, IH, IW, Nout + 8, N) == 0
+    ks = min(ks, nblk)
+    dy = (torch.randn(P, Nout, generator=g) / 8).bfloat16().cuda()
+    Wp = torch.zeros(Nout, 64, dtype=torch.bfloat16, device="cuda")
+    b = torch.zeros(Nout, device="cuda")
+
+    def via_col(col):
+        k2 = max(1, -(-P // 4096))
+        slabs = torch.empty(k2, Nout, 64, device="cuda")
+        L.call("rbvae_wgrad_gemm", 1, dy, col, slabs, None, zero, P, P, Nout, 64, Nout, 64, 1, k2)
+        return slabs.sum(0)
+
+    # mode 0: frames
+    x = torch.randn(N, Cin, IH, IW, generator=g).cuda()
+    col = torch.empty(P, 64, dtype=torch.bfloat16, device="cuda")
+    out_a = torch.empty(P, Nout, dtype=torch.bfloat16, device="cuda")
+    L.call("rbvae_conv_first_fused", 1, x, 0, 0, 0, 0, Cin * IH * IW, Wp, b, zero, col, out_a, N, Cin, IH, IW, Nout, Nout, 1, 0,
+           0.0, 1.0, 0, None)
+    out_b = torch.full_like(out_a, float("nan"))
+    L.call("rbvae_conv_first_fused", 1, x, 0, 0, 0, 0, Cin * IH * IW, Wp, b, zero, None, out_b, N, Cin, IH, IW, Nout, Nout, 1, 0,
+           0.0, 1.0, 0, None)
+    assert torch.equal(out_a.view(torch.int16), out_b.view(torch.int16))
+    want = via_col(col)
+    slabs = torch.full((ks, Nout, 64), float("nan"), device="cuda")
+    L.call("rbvae_wgrad_first", 1, 0, x, 0, 0, 0, 0, Cin * IH * IW, dy, slabs, zero, N, Cin, IH, IW, Nout, Nout, ks)
+    got = slabs.sum(0)
+    assert torch.isfinite(got).all()
+    assert float((got - want).abs().max()) <= 2e-5 * float(want.abs().max()) + 1e-6
+    assert float(got[:, 9 * Cin:].abs().max()) == 0.0                       # the padding columns
+    w = torch.zeros(Nout, Cin, 3, 3, requires_grad=True)
+    F.conv2d(x.cpu().bfloat16().float(), w, None, stride=2, padding=1).backward(
+        dy.float().cpu().view(N, OH, OW, Nout).permute(0, 3, 1, 2))
+    ref = w.grad.permute(0, 2, 3, 1).reshape(Nout, 9 * Cin)                # column = (kh*3+kw)*Cin + ci
+    assert float((got[:, :9 * Cin].cpu() - ref).norm() / ref.norm()) < 3e-3
+    # frame-mapped frames: frame n = (s, t) of an item buffer [S][2][T] taken at view 1
+    S, T = 1, N
+    buf = torch.randn(S, 2, T, Cin, IH, IW, generator=g).cuda()
+    buf[:, 1] = x.view(S, T, Cin, IH, IW)
+    fsz = Cin * IH * IW
+    slabs_m = torch.empty_like(slabs)
+    L.call("rbvae_wgrad_first", 1, 0, buf[:, 1], T, T, 2 * T * fsz, 0, fsz, dy, slabs_m, zero, N, Cin, IH, IW, Nout, Nout, ks)
+    assert torch.equal(slabs_m, slabs)
+    # mode 1: NHWC f32 image (d(loss)/d(pre-sigmoid) of the last ConvTranspose2d)
+    dpre = (torch.randn(N, IH, IW, Cin, generator=g) * 0.1).cuda()
+    gate = torch.ones(P, Nout, dtype=torch.bfloat16, device="cuda")
+    col3 = torch.empty(P, 64, dtype=torch.bfloat16, device="cuda")
+    o3 = torch.empty(P, Nout, dtype=torch.bfloat16, device="cuda")
+    L.call("rbvae_deconv_last_dgrad_fused", 1, dpre, Wp, zero, col3, gate, o3, N, Cin, IH, IW, Nout, Nout, 1.0, None)
+    o4 = torch.full_like(o3, float("nan"))
+    L.call("rbvae_deconv_last_dgrad_fused", 1, dpre, Wp, zero, None, gate, o4, N, Cin, IH, IW, Nout, Nout, 1.0, None)
+    assert torch.equal(o3.view(torch.int16), o4.view(torch.int16))
+    want3 = via_col(col3)
+    slabs3 = torch.full((ks, Nout, 64), float("nan"), device="cuda")
+    L.call("rbvae_wgrad_first", 1, 1, dpre, 0, 0, 0, 0, 0, dy, slabs3, zero, N, Cin, IH, IW, Nout, Nout, ks)
+    got3 = slabs3.sum(0)
+    assert float((got3 - want3).abs().max()) <= 2e-5 * float(want3.abs().max()) + 1e-6
+    with pytest.raises(ValueError):
+        L.call("rbvae_wgrad_first", 1, 0, x, 0, 0, 0, 0, fsz, dy, slabs, zero, N, Cin, IH, IW, Nout, Nout, nblk + 1)
+
+
 def _job_row(kind, src, dst, d0, d1, d2, nslab=1, slab=0, dtype=0, accumulate=0, scale=1.0, dst2=None):
     import struct
     bits = struct.unpack("<I", struct.pack("<f", float(scale)))[0]
