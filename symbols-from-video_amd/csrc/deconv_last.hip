@@ -67,9 +67,11 @@ __global__ __launch_bounds__(256, (DL_SL == 1 ? 3 : 2)) void deconv_last_fused_k
     // gather phase (with all of C1 resident it was one workgroup per CU, every phase exposed, and slower than the
     // two-kernel path).
     constexpr int SL = DL_SL;
-    unsigned char* s_pix = smem;                                     // [SL][DL_MROWS][128]
-    unsigned char* s_wts = s_pix + (size_t)SL * DL_MROWS * 128;      // [SL][DL_WROWS][128]
-    float* s_y = (float*)(s_wts + (size_t)SL * DL_WROWS * 128);      // [DL_MROWS][DL_YP]
+    // a 64-channel layer (cfg 3) has ONE slice: one buffer, 50 KB, three workgroups per CU instead of two
+    const int NBUF = KS > 1 ? SL : 1;
+    unsigned char* s_pix = smem;                                     // [NBUF][DL_MROWS][128]
+    unsigned char* s_wts = s_pix + (size_t)NBUF * DL_MROWS * 128;    // [NBUF][DL_WROWS][128]
+    float* s_y = (float*)(s_wts + (size_t)NBUF * DL_WROWS * 128);    // [DL_MROWS][DL_YP]
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int OH = 2 * p.IH, OW = 2 * p.IW;
     const int tb_n = (p.IW + DL_TB - 1) / DL_TB, ta_n = (p.IH + DL_TA - 1) / DL_TA;
@@ -321,7 +323,7 @@ __global__ __launch_bounds__(256, (DL_SL == 1 ? 3 : 2)) void deconv_last_fused_k
 }
 
 static int dl_blocks(int N, int IH, int IW) { return N * cdiv(IH, DL_TA) * cdiv(IW, DL_TB); }
-static size_t dl_lds(int C1) { (void)C1; return (size_t)DL_SL * (DL_MROWS + DL_WROWS) * 128 + (size_t)DL_MROWS * DL_YP * 4; }
+static size_t dl_lds(int C1) { return (size_t)(C1 > 64 ? DL_SL : 1) * (DL_MROWS + DL_WROWS) * 128 + (size_t)DL_MROWS * DL_YP * 4; }
 
 }  // namespace rbvae
 
