@@ -484,7 +484,17 @@ size_t rbvae_conv3x3_halo_stats_floats(int Nimg, int OH, int OW, int Nout, int c
  * optional), or from the mean / rstd of rbvae_groupnorm_swish_ws's statistics kernels (gn_affine). */
 int rbvae_gn_finish_tiles(const float* stats_part, const float* gamma, const float* beta, float* scale, float* shift,
                           float* mean_out, float* rstd_out, int Nimg, int OH, int OW, int C, int groups, float eps,
-                          void* stream);
+                          int tile_h, int tile_w, void* stream);   /* tile: 16 x 16 (rbvae_conv3x3_halo), 8 x 16 (rbvae_conv_in) */
+/* The LDM encoder's conv_in, Conv2d(Cin <= 4 -> Nout <= 256, 3x3, stride 1, pad 1) on f32 NCHW frames (model.py:385-389,
+ * :436), as ONE kernel in bf16 storage -- rbvae_im2col + the one-tap rbvae_gather_gemm, the same 64-deep MFMA chain per
+ * output -- with the GroupNorm partial statistics of its output out of the epilogue: stats_part (may be NULL;
+ * rbvae_conv_in_stats_floats floats) receives per 8 x 16 pixel tile and group of cg (4, 8 or 16) channels the (mean, sum of
+ * squared deviations) of the stored values, merged by rbvae_gn_finish_tiles(.., 8, 16).  W [Nout][64] bf16, column
+ * (kh*3+kw)*Cin + ci zero padded; out [N*H*W][ldo] bf16. */
+int rbvae_conv_in_ok(int dtype, int Cin, int H, int W, int Nout, int N, int cg);
+size_t rbvae_conv_in_stats_floats(int N, int H, int W, int Nout, int cg);
+int rbvae_conv_in(int dtype, const float* x, const void* W, const float* bias, const void* zero_page, void* out, float* stats_part,
+                  int cg, int N, int Cin, int H, int Wd, int Nout, int ldo, void* stream);
 int rbvae_gn_affine(const float* mean, const float* rstd, const float* gamma, const float* beta, float* scale,
                     float* shift, int N, int C, int groups, void* stream);
 

@@ -567,7 +567,7 @@ __global__ __launch_bounds__(512) void conv_halo_k(const ChArgs p) {
 // Merge the per-tile (mean, M2) of rbvae_conv3x3_halo into per-(image, group) mean / rstd, and expand them with the
 // affine parameters into the per-(image, channel) scale / shift the consuming convolution applies while it stages its
 // input: y = x * scale + shift = (x - mean) * rstd * gamma + beta  (model.py:38-39).
-__global__ __launch_bounds__(64) void gn_finish_tiles_k(const float2* __restrict__ part, int tiles_r, int tiles_c, int OH,
+__global__ __launch_bounds__(64) void gn_finish_tiles_k(const float2* __restrict__ part, int TH, int TW, int tiles_r, int tiles_c, int OH,
                                                         int OW, int cg, int G, float eps, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, float* __restrict__ scale,
                                                         float* __restrict__ shift, float* __restrict__ mean_out,
@@ -577,7 +577,7 @@ __global__ __launch_bounds__(64) void gn_finish_tiles_k(const float2* __restrict
     const float2* pp = part + (size_t)n * nb * G + g;
     auto count = [&](int b) {
         const int tr = b / tiles_c, tc = b - tr * tiles_c;
-        return (float)(min(CH_T, OH - tr * CH_T) * min(CH_T, OW - tc * CH_T) * cg);
+        return (float)(min(TH, OH - tr * TH) * min(TW, OW - tc * TW) * cg);
     };
     const float total = (float)OH * (float)OW * (float)cg;
     float a = 0.f;
@@ -680,13 +680,14 @@ extern "C" size_t rbvae_conv3x3_halo_stats_floats(int Nimg, int OH, int OW, int 
 
 extern "C" int rbvae_gn_finish_tiles(const float* stats_part, const float* gamma, const float* beta, float* scale,
                                      float* shift, float* mean_out, float* rstd_out, int Nimg, int OH, int OW, int C,
-                                     int groups, float eps, void* stream) {
+                                     int groups, float eps, int tile_h, int tile_w, void* stream) {
     RBVAE_CHECK_ARG(stats_part && gamma && beta && scale && shift, "gn_finish_tiles: null pointer");
     RBVAE_CHECK_ARG(groups > 0 && C % groups == 0 && C / groups <= 64, "gn_finish_tiles: C=%d groups=%d", C, groups);
     RBVAE_CHECK_ARG((mean_out == nullptr) == (rstd_out == nullptr), "gn_finish_tiles: mean_out and rstd_out go together");
+    RBVAE_CHECK_ARG(tile_h > 0 && tile_w > 0, "gn_finish_tiles: tile %d x %d (16 x 16: rbvae_conv3x3_halo, 8 x 16: rbvae_conv_in)", tile_h, tile_w);
     hipLaunchKernelGGL(gn_finish_tiles_k, dim3(Nimg * groups), dim3(64), 0, (hipStream_t)stream, (const float2*)stats_part,
-                       cdiv(OH, CH_T), cdiv(OW, CH_T), OH, OW, C / groups, groups, eps, gamma, beta, scale, shift, mean_out,
-                       rstd_out);
+                       tile_h, tile_w, cdiv(OH, tile_h), cdiv(OW, tile_w), OH, OW, C / groups, groups, eps, gamma, beta, scale, shift,
+                       mean_out, rstd_out);
     RBVAE_CHECK_LAUNCH("gn_finish_tiles");
     return RBVAE_OK;
 }

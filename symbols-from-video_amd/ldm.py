@@ -225,7 +225,7 @@ class LDMEncoder(nn.Module):
         else from the statistics kernels"""
         dev = x.device
         if xst is not None:
-            return xst
+            return xst                 # ("tiles", partials, tile_h, tile_w)
         dt = self._packed[1]
         nws = L.query("rbvae_groupnorm_ws_floats", dt, N, H * W, C, 32)
         ws = torch.empty(nws, dtype=torch.float32, device=dev)
@@ -246,18 +246,19 @@ class LDMEncoder(nn.Module):
         if fused:
             sc = torch.empty(N, cin, dtype=torch.float32, device=dev)
             sh = torch.empty(N, cin, dtype=torch.float32, device=dev)
-            if isinstance(st, tuple):
+            if st[0] == "ms":
                 L.call("rbvae_gn_affine", st[1], st[1][N * 32:], gamma, beta, sc, sh, N, cin, 32)
             else:
-                L.call("rbvae_gn_finish_tiles", st, gamma, beta, sc, sh, None, None, N, H, W, cin, 32, 1e-6)
+                L.call("rbvae_gn_finish_tiles", st[1], gamma, beta, sc, sh, None, None, N, H, W, cin, 32, 1e-6, st[2], st[3])
         else:
-            if isinstance(st, tuple):
+            if st[0] == "ms":
                 mean, rstd = st[1], st[1][N * 32:]
             else:
                 ms = torch.empty(2 * N * 32, dtype=torch.float32, device=dev)
                 sc0 = torch.empty(2, N, cin, dtype=torch.float32, device=dev)
                 mean, rstd = ms, ms[N * 32:]
-                L.call("rbvae_gn_finish_tiles", st, gamma, beta, sc0[0], sc0[1], mean, rstd, N, H, W, cin, 32, 1e-6)
+                L.call("rbvae_gn_finish_tiles", st[1], gamma, beta, sc0[0], sc0[1], mean, rstd, N, H, W, cin, 32, 1e-6, st[2],
+                       st[3])
             y = torch.empty_like(x)
             L.call("rbvae_groupnorm_apply", dt, x, y, mean, rstd, gamma, beta, N, H * W, cin, x.shape[1], y.shape[1], 32, 1)
             x = y
@@ -265,7 +266,7 @@ class LDMEncoder(nn.Module):
         ost = torch.empty(L.query("rbvae_conv3x3_halo_stats_floats", N, H, W, cout, cout // 32), dtype=torch.float32, device=dev)
         L.call("rbvae_conv3x3_halo", dt, x, pk[f"{conv}.weight"], out, self._p(f"{conv}.bias"), addend, self._zero, sc, sh, 1,
                ost, cout // 32, N, H, W, H, W, 1, 1, cin, cout, x.shape[1], cout)
-        return out, ost
+        return out, ("tiles", ost, 16, 16)
 
     def _halo_ok(self, N, H, W, cin, cout):
         dt = self._packed[1]
@@ -366,6 +367,16 @@ class LDMEncoder(nn.Module):
         x = x.float().contiguous()
         h, hst = None, None          # activation rows and (when a halo convolution produced them) their GroupNorm partials
         for prefix, kind, cin, cout in self.plan:
+            if kind == "conv_in" and self.conv_impl == "halo" and cout % 32 == 0 and \
+                    L.query("rbvae_conv_in_ok", dt, C, H, W, cout, N, cout // 32) and pk[f"{prefix}.weight"].shape[1] == 64:
+                # one kernel: patch -> im2col rows in LDS -> MFMA -> bias -> store, and the first GroupNorm's partial
+                # statistics out of the epilogue (csrc/conv_in.hip)
+                h = torch.empty(N * H * W, cout, dtype=tdt, device=dev)
+                ost = torch.empty(L.query("rbvae_conv_in_stats_floats", N, H, W, cout, cout // 32), dtype=torch.float32, device=dev)
+                L.call("rbvae_conv_in", dt, x, pk[f"{prefix}.weight"], self._p(f"{prefix}.bias"), self._zero, h, ost, cout // 32,
+                       N, C, H, W, cout, cout)
+                hst = ("tiles", ost, 8, 16)
+                continue
             if kind == "conv_in":
                 K = pk[f"{prefix}.weight"].shape[1]
                 col = torch.empty(N * H * W, K, dtype=tdt, device=dev)

@@ -114,7 +114,7 @@ def test_fused_groupnorm_input_and_output_statistics(sfv, dtype, N, C, Co, H, W,
     g2, b2 = torch.randn(Co, generator=g), torch.randn(Co, generator=g)
     sc2, sh2 = torch.empty(N, Co, device="cuda"), torch.empty(N, Co, device="cuda")
     mean, rstd = torch.empty(N * 32, device="cuda"), torch.empty(N * 32, device="cuda")
-    lib.call("rbvae_gn_finish_tiles", stats, g2.cuda(), b2.cuda(), sc2, sh2, mean, rstd, N, H, W, Co, 32, 1e-6)
+    lib.call("rbvae_gn_finish_tiles", stats, g2.cuda(), b2.cuda(), sc2, sh2, mean, rstd, N, H, W, Co, 32, 1e-6, 16, 16)
     grp = got.reshape(N, 32, -1)
     m_ref, v_ref = grp.mean(-1), grp.var(-1, unbiased=False)
     np.testing.assert_allclose(mean.cpu().reshape(N, 32).numpy(), m_ref.numpy(), rtol=2e-5, atol=2e-5)

@@ -156,3 +156,56 @@ def test_captured_encode_equals_eager_and_follows_new_weights():
         assert torch.equal(g.encode(xs[3], sample=False), e.encode(xs[3], sample=False))
     with pytest.raises(ValueError):
         g.encode(torch.zeros(1, 3, 60, 64, device="cuda"))
+
+
+@pytest.mark.parametrize("N,Cin,H,W,Nout,cg", [(2, 3, 64, 64, 128, 4), (1, 3, 21, 40, 128, 4), (3, 4, 16, 48, 64, 8), (2, 3, 24, 17, 256, 16),
+                                               (1, 1, 8, 16, 32, 4)])
+def test_conv_in_matches_conv2d_and_its_groupnorm_statistics(N, Cin, H, W, Nout, cg):
+    """rbvae_conv_in (csrc/conv_in.hip): the encoder's conv_in (model.py:385-389) as one kernel against F.conv2d on the
+    bf16-rounded operands, bit-identical to rbvae_im2col + the one-tap rbvae_gather_gemm it replaces, and the per-tile
+    GroupNorm partials of its epilogue merged by rbvae_gn_finish_tiles(.., 8, 16) against the mean / variance of the stored
+    output per (image, group) -- blocks that hang over the image, 1..4 input channels, 32..256 output channels."""
+    import ctypes
+    import sfv_amd as sfv
+    import torch.nn.functional as F
+    L = sfv._lib
+    g = torch.Generator().manual_seed(300 + H + Nout)
+    x = (torch.rand(N, Cin, H, W, generator=g) * 2 - 1).cuda()
+    Wt = torch.randn(Nout, Cin, 3, 3, generator=g) * 0.2
+    b = torch.randn(Nout, generator=g).cuda()
+    Wp = torch.zeros(Nout, 64, dtype=torch.bfloat16)
+    Wp[:, :9 * Cin] = Wt.permute(0, 2, 3, 1).reshape(Nout, 9 * Cin).bfloat16()
+    Wp = Wp.cuda()
+    zero = torch.zeros(256, dtype=torch.uint8, device="cuda")
+    G = Nout // cg
+    assert L.query("rbvae_conv_in_ok", 1, Cin, H, W, Nout, N, cg) == 1
+    assert L.query("rbvae_conv_in_ok", 0, Cin, H, W, Nout, N, cg) == 0
+    out = torch.full((N * H * W, Nout), float("nan"), dtype=torch.bfloat16, device="cuda")
+    st = torch.full((L.query("rbvae_conv_in_stats_floats", N, H, W, Nout, cg),), float("nan"), device="cuda")
+    L.call("rbvae_conv_in", 1, x, Wp, b, zero, out, st, cg, N, Cin, H, W, Nout, Nout)
+    got = out.float().cpu().view(N, H, W, Nout).permute(0, 3, 1, 2)
+    ref = F.conv2d(x.cpu().bfloat16().float(), Wt.bfloat16().float(), b.cpu(), stride=1, padding=1)
+    assert torch.isfinite(got).all()
+    np.testing.assert_allclose(got.numpy(), ref.numpy(), rtol=1e-2, atol=1e-2)
+    # the two-kernel path it replaces
+    col = torch.empty(N * H * W, 64, dtype=torch.bfloat16, device="cuda")
+    L.call("rbvae_im2col", 1, x, Cin * H * W, H * W, W, 1, N, Cin, H, W, H, W, 3, 3, 1, 1, 64, col)
+    out2 = torch.empty_like(out)
+    d_one = (ctypes.c_int * 6)(1, 0, 0, 0, 0, 0)
+    L.call("rbvae_gather_gemm", 1, col, Wp, out2, b, None, None, None, zero, N * H * W, 1, 1, 1, 1, 1, 1, 1, 1, 64, Nout, 64,
+           Nout, 1, 1, ctypes.addressof(d_one), 0, 0, 0.0, 1.0, 0, None, None)
+    assert torch.equal(out.view(torch.int16), out2.view(torch.int16))
+    # statistics of the stored values
+    gamma, beta = torch.ones(Nout, device="cuda"), torch.zeros(Nout, device="cuda")
+    sc, sh = torch.empty(N, Nout, device="cuda"), torch.empty(N, Nout, device="cuda")
+    mean, rstd = torch.empty(N * G, device="cuda"), torch.empty(N * G, device="cuda")
+    L.call("rbvae_gn_finish_tiles", st, gamma, beta, sc, sh, mean, rstd, N, H, W, Nout, G, 1e-6, 8, 16)
+    v = got.double().view(N, G, cg, H * W)
+    m_ref = v.mean((2, 3)).reshape(-1)
+    var_ref = v.var((2, 3), unbiased=False).reshape(-1)
+    np.testing.assert_allclose(mean.cpu().double().numpy(), m_ref.numpy(), rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(rstd.cpu().double().numpy(), (var_ref + 1e-6).rsqrt().numpy(), rtol=1e-4)
+    # without statistics
+    out3 = torch.empty_like(out)
+    L.call("rbvae_conv_in", 1, x, Wp, b, zero, out3, None, 0, N, Cin, H, W, Nout, Nout)
+    assert torch.equal(out3.view(torch.int16), out.view(torch.int16))
