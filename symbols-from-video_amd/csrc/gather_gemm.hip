@@ -337,8 +337,13 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void gather_gemm_k(const GgArgs p)
     // wait until at most YOUNGER LDS reads are outstanding (in-order return): the guarded fragments landed
     auto landed = [&](auto younger_tag, u32x4_t (&fa)[MT], u32x4_t (&fb)[NTW]) {
         constexpr int YOUNGER = decltype(younger_tag)::value;
-        static_assert((MT == 4 && (NTW == 1 || NTW == 2 || NTW == 4)) || (MT == 2 && NTW == 2), "operand list below");
-        if constexpr (MT == 2)
+        static_assert((MT == 4 && (NTW == 1 || NTW == 2 || NTW == 4)) || (MT == 2 && NTW == 2) || (MT == 8 && NTW == 2), "operand list below");
+        if constexpr (MT == 8)
+            asm volatile("s_waitcnt lgkmcnt(%10)"
+                         : "+v"(fa[0]), "+v"(fa[1 % MT]), "+v"(fa[2 % MT]), "+v"(fa[3 % MT]), "+v"(fa[4 % MT]), "+v"(fa[5 % MT]),
+                           "+v"(fa[6 % MT]), "+v"(fa[7 % MT]), "+v"(fb[0]), "+v"(fb[1 % NTW])
+                         : "n"(YOUNGER));
+        else if constexpr (MT == 2)
             asm volatile("s_waitcnt lgkmcnt(%4)"
                          : "+v"(fa[0]), "+v"(fa[MT - 1]), "+v"(fb[0]), "+v"(fb[NTW - 1])
                          : "n"(YOUNGER));
@@ -627,6 +632,9 @@ static int dispatch_gg(const GgArgs& a, hipStream_t st, int max_steps) {
     // (128 x 256 tiles -- <8, 8, 2>, the gathered rows read once instead of twice -- measured 37.2 us against 34.6 us for
     // the 1024-workgroup parity-class launches: one 8-wave workgroup per CU and two uneven rounds cost more than the
     // 25 % smaller ingest gains)
+    // (256 x 128 tiles -- <4, 8, 2, 1, 256>, 64 accumulators per lane, one workgroup per CU -- for the launches of many
+    // rounds: native 4x88x160 step 2.26-2.28 ms against 2.22, same GPU, alternating: two 128-row workgroups per CU hide each
+    // other's barriers and epilogues better than the 25 % smaller ingest of the tall tile gains)
     if (ns == 2) return launch_gg<T, 4, 8, 2>(a, st);
     if (dbg == 4) return launch_gg<T, 4, 4, 3>(a, st);       // 4 waves, 64x64 wave tiles (less LDS traffic)
     if (ns >= 4) return launch_gg<T, 4, 8, 4>(a, st);
