@@ -792,6 +792,38 @@ def test_wgrad_first_rebuilds_the_im2col_rows(sfv, N, Cin, IH, IW, Nout, ks):
         L.call("rbvae_wgrad_first", 1, 0, x, 0, 0, 0, 0, fsz, dy, slabs, zero, N, Cin, IH, IW, Nout, Nout, nblk + 1)
 
 
+def test_wgrad_first_at_the_cfg3_frame_size(sfv):
+    """BASELINE configs[2] size: 128 frames of 3 x 256 x 256 -> 2 097 152 output pixels, 64 channels, the engine's K-split
+    of 512: rbvae_wgrad_first against rbvae_wgrad_gemm over the im2col rows rbvae_conv_first_fused writes (same bf16
+    products), and zero padding columns."""
+    L = sfv._lib
+    N, Cin, IH, IW, Nout = 128, 3, 256, 256, 64
+    OH, OW = IH // 2, IW // 2
+    P = N * OH * OW
+    g = torch.Generator(device="cuda").manual_seed(17)
+    x = torch.rand(N, Cin, IH, IW, device="cuda", generator=g)
+    dy = (torch.randn(P, Nout, device="cuda", generator=g) / 8).bfloat16()
+    Wp = torch.zeros(Nout, 64, dtype=torch.bfloat16, device="cuda")
+    b = torch.zeros(Nout, device="cuda")
+    zero = torch.zeros(256, dtype=torch.uint8, device="cuda")
+    col = torch.empty(P, 64, dtype=torch.bfloat16, device="cuda")
+    out = torch.empty(P, Nout, dtype=torch.bfloat16, device="cuda")
+    L.call("rbvae_conv_first_fused", 1, x, 0, 0, 0, 0, Cin * IH * IW, Wp, b, zero, col, out, N, Cin, IH, IW, Nout, Nout, 1, 0, 0.0,
+           1.0, 0, None)
+    k2 = P // 4096
+    slabs2 = torch.empty(k2, Nout, 64, device="cuda")
+    L.call("rbvae_wgrad_gemm", 1, dy, col, slabs2, None, zero, P, P, Nout, 64, Nout, 64, 1, k2)
+    ref = slabs2.double().sum(0)
+    nblk = L.query("rbvae_wgrad_first_blocks", 1, Cin, IH, IW, Nout, N)
+    assert nblk == N * 16 * 8
+    slabs = torch.full((512, Nout, 64), float("nan"), device="cuda")
+    L.call("rbvae_wgrad_first", 1, 0, x, 0, 0, 0, 0, Cin * IH * IW, dy, slabs, zero, N, Cin, IH, IW, Nout, Nout, 512)
+    got = slabs.double().sum(0)
+    assert torch.isfinite(got).all()
+    assert float((got - ref).norm() / ref.norm()) < 1e-5
+    assert float(got[:, 27:].abs().max()) == 0.0
+
+
 def _job_row(kind, src, dst, d0, d1, d2, nslab=1, slab=0, dtype=0, accumulate=0, scale=1.0, dst2=None):
     import struct
     bits = struct.unpack("<I", struct.pack("<f", float(scale)))[0]

@@ -79,3 +79,40 @@ def test_wgrad_halo_padded_rows_and_rejections(sfv):
         lib.call("rbvae_wgrad3x3s2_halo", 1, S, G, slabs, zero, N, OH, OW, 32, Cb, 192, 128, 2)
     with pytest.raises(ValueError):
         lib.call("rbvae_wgrad3x3s2_halo", 1, S, G, slabs, zero, N, OH, OW, Ca, Cb, 192, 128, 10 ** 6)
+
+
+def test_wgrad_halo_at_the_cfg3_layer_sizes(sfv):
+    """BASELINE configs[2] sizes (128 frames of 256 x 256: conv2 / deconv2 = 64 x 64 pixels, 64 channels, 524 288 pixels; the
+    engine's K-split of 256): the nine-tap kernel against rbvae_wgrad_gemm on the same operands, and linearity in S
+    (dW(S1 + S2) = dW(S1) + dW(S2) up to f32 summation order) as a size-independent property."""
+    lib = sfv._lib
+    N, OH, OW, Ca, Cb = 128, 64, 64, 64, 64
+    P = N * OH * OW
+    g = torch.Generator(device="cuda").manual_seed(5)
+    S1 = (torch.randn(P, Ca, device="cuda", generator=g) / 8).bfloat16()
+    G = torch.randn(4 * P, Cb, device="cuda", generator=g).bfloat16()
+    zero = torch.zeros(256, dtype=torch.uint8, device="cuda")
+    nblk = lib.query("rbvae_wgrad3x3s2_halo_blocks", N, OH, OW)
+    assert nblk == N * 16 * 8
+    ks = 256
+
+    def halo(S):
+        slabs = torch.empty(ks, Ca, 9, Cb, device="cuda")
+        lib.call("rbvae_wgrad3x3s2_halo", 1, S, G, slabs, zero, N, OH, OW, Ca, Cb, Ca, Cb, ks)
+        return slabs.double().sum(0)
+
+    d1 = halo(S1)
+    idx = torch.empty(9 * P, dtype=torch.int32, device="cuda")
+    lib.call("rbvae_conv_gather_index", idx, N, 2 * OH, 2 * OW, OH, OW, 3, 3, 2, 1)
+    k2 = P // 4096
+    slabs2 = torch.empty(k2, Ca, 9, Cb, device="cuda")
+    lib.call("rbvae_wgrad_gemm", 1, S1, G, slabs2, idx, zero, P, 4 * P, Ca, Cb, Ca, Cb, 9, k2)
+    ref = slabs2.double().sum(0)
+    assert float((d1 - ref).norm() / ref.norm()) < 1e-5
+    # linearity: operands whose sum is exact in bf16 (S2 = 3 S1 -> S1 + S2 = 4 S1)
+    S2 = (S1.float() * 3).bfloat16()
+    S12 = (S1.float() * 4).bfloat16()
+    assert torch.equal(S12.float(), S1.float() * 4)
+    lhs, rhs = halo(S12), d1 + halo(S2)
+    exact3 = torch.equal(S2.float(), S1.float() * 3)          # 3 x a bf16 value may round: then compare loosely
+    assert float((lhs - rhs).norm() / lhs.norm()) < (1e-6 if exact3 else 5e-3)
