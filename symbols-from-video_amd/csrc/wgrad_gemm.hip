@@ -96,12 +96,15 @@ template <int N> __device__ __forceinline__ void wg_wait_barrier() {
 // Workgroup order: the grid is one-dimensional; with xcd_order (the default when ksplit > 1) every XCD's workgroups
 // work on one or two pixel slices, so all taps and channel tiles of a slice re-read its Dy / In rows from that XCD's
 // own L2 instead of from the Infinity Cache; otherwise the K-slice index is the fastest digit of the workgroup id.
-template <typename T, int NT, int WG_NS>
+// BM = co per workgroup: 128, or 64 (f32 only) for layers of <= 64 output channels -- with the 128-row tile half of the
+// waves multiplied zero rows, and the exact-f32 kernel is bound by its matrix-core time (cfg 3, 64 channels: 45 % of the f32 step)
+template <typename T, int NT, int WG_NS, int BM = WG_BM>
 __global__ __launch_bounds__(512, WG_NS == 2 ? 2 : 1) void wgrad_gemm_k(const WgArgs p) {
     constexpr int ES = sizeof(T);
     constexpr int WG_BK = (ES == 2) ? 64 : 32;            // pixels per K step (one or two 32-pixel MFMA steps)
-    constexpr int MT = 4;
-    constexpr int BM = WG_BM, BN = 64 * NT;
+    constexpr int MT = BM / 32;
+    static_assert(BM == 128 || (BM == 64 && ES == 4), "64-row tiles: the f32 path only (the bf16 fragment guards list MT = 4 operands)");
+    constexpr int BN = 64 * NT;
     constexpr int RBA = BM * ES, RBB = BN * ES;           // image row bytes
     constexpr int A_BYTES = WG_BK * RBA, B_BYTES = WG_BK * RBB;
     constexpr int STAGE = A_BYTES + B_BYTES;
@@ -543,38 +546,38 @@ __global__ void conv_gather_index_k(int* __restrict__ idx, int Nimg, int IH, int
     idx[i] = (ih >= 0 && ih < IH && iw >= 0 && iw < IW) ? (n * IH + ih) * IW + iw : -1;
 }
 
-template <typename T, int NT, int NS>
+template <typename T, int NT, int NS, int BM = WG_BM>
 static int launch_wg_ns(const WgArgs& a, hipStream_t st) {
     constexpr int ES = sizeof(T);
     constexpr int BK = (ES == 2) ? 64 : 32;
-    constexpr size_t ring = (size_t)NS * BK * (WG_BM + 64 * NT) * ES;
+    constexpr size_t ring = (size_t)NS * BK * (BM + 64 * NT) * ES;
     const size_t lds = ring + (size_t)a.Pper * sizeof(int);            // + this launch's index table
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute((const void*)wgrad_gemm_k<T, NT, NS>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)(ring + (NT == 4 ? 2048 : WG_MAXP) * sizeof(int)));
+        (void)hipFuncSetAttribute((const void*)wgrad_gemm_k<T, NT, NS, BM>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)(ring + (NT == 4 ? 2048 : WG_MAXP) * sizeof(int)));
         attr_set = true;
     }
-    long blocks = (long)cdiv(a.Co, WG_BM) * cdiv(a.Ci, 64 * NT) * a.taps * a.ksplit;
+    long blocks = (long)cdiv(a.Co, BM) * cdiv(a.Ci, 64 * NT) * a.taps * a.ksplit;
     if (a.xcd_order) blocks = 8 * ((blocks + 7) / 8);
-    hipLaunchKernelGGL((wgrad_gemm_k<T, NT, NS>), dim3((unsigned)blocks), dim3(512), lds, st, a);
+    hipLaunchKernelGGL((wgrad_gemm_k<T, NT, NS, BM>), dim3((unsigned)blocks), dim3(512), lds, st, a);
     RBVAE_CHECK_LAUNCH("wgrad_gemm");
     return RBVAE_OK;
 }
 
-template <typename T, int NT>
+template <typename T, int NT, int BM = WG_BM>
 static int launch_wg(const WgArgs& a, hipStream_t st) {
     constexpr int ES = sizeof(T);
     constexpr int BK = (ES == 2) ? 64 : 32;
     // more workgroups than CUs: two per CU (double buffer) when two rings + index tables fit the 160 KB LDS
-    const long blocks = (long)cdiv(a.Co, WG_BM) * cdiv(a.Ci, 64 * NT) * a.taps * a.ksplit;
-    const size_t lds2 = (size_t)2 * BK * (WG_BM + 64 * NT) * ES + (size_t)a.Pper * sizeof(int);
+    const long blocks = (long)cdiv(a.Co, BM) * cdiv(a.Ci, 64 * NT) * a.taps * a.ksplit;
+    const size_t lds2 = (size_t)2 * BK * (BM + 64 * NT) * ES + (size_t)a.Pper * sizeof(int);
     constexpr int force = 0;
     const bool two = force ? force == 2 : (blocks > 256 && 2 * lds2 <= 160 * 1024);
     if constexpr (ES == 2) {
         if (force == 4 && a.Pper <= 2560) return launch_wg_ns<T, NT, 4>(a, st);
     }
-    return two ? launch_wg_ns<T, NT, 2>(a, st) : launch_wg_ns<T, NT, 3>(a, st);
+    return two ? launch_wg_ns<T, NT, 2, BM>(a, st) : launch_wg_ns<T, NT, 3, BM>(a, st);
 }
 
 }  // namespace rbvae
@@ -634,6 +637,7 @@ int rbvae_wgrad_gemm(int dtype, const void* Dy, const void* In, float* dW_slabs,
                     WG_MAXP, cdiv(P, WG_MAXP));
     hipStream_t st = (hipStream_t)stream;
     const bool wide = Ci > 64;
+    if (dtype == RBVAE_F32 && Co <= 64) return wide ? launch_wg<float, 2, 64>(a, st) : launch_wg<float, 1, 64>(a, st);
     if (dtype == RBVAE_F32) return wide ? launch_wg<float, 2>(a, st) : launch_wg<float, 1>(a, st);
     // 128 x 256 tiles (RBVAE_WG_NT4=1): 48 KB of operands per 4.2 MFLOP K step instead of 32 KB per 2.1 MFLOP
     static const int nt4 = getenv("RBVAE_WG_NT4") ? atoi(getenv("RBVAE_WG_NT4")) : 0;
