@@ -288,7 +288,9 @@ class Engine:
         # 4x the workgroups, and the LSTM kernels sum the slabs while staging their input (RBVAE_FC_SPLIT=1: one
         # group, 32 CUs busy at 256 frames).  Needs the wavefront LSTM kernels (latent <= 32).
         ks_unit = 32 if dtype == "bf16" else 16
-        want = 4
+        # (16 groups for the large fc layers: at F3 = 56 320 / 65 536 four groups were 64 workgroups streaming 21-42 MB:
+        # 31-36 us per launch at 0.6 TB/s)
+        want = 16 if self.F3 >= 16384 else 4
         wave_ok = latent <= 32 and self.v.lstm_layers * _ru(4 * latent, 64) <= 1024 and not self.v.simple_order
         self.fc_split = want if (want > 1 and wave_ok and self.F3 % (want * ks_unit) == 0 and self.F3 >= 2048) else 1
         # ... and write the bf16 / padded copy of their output that the next GEMM reads (rbvae_cast_pad otherwise)
