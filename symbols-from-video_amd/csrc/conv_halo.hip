@@ -567,29 +567,40 @@ __global__ __launch_bounds__(512) void conv_halo_k(const ChArgs p) {
 // Merge the per-tile (mean, M2) of rbvae_conv3x3_halo into per-(image, group) mean / rstd, and expand them with the
 // affine parameters into the per-(image, channel) scale / shift the consuming convolution applies while it stages its
 // input: y = x * scale + shift = (x - mean) * rstd * gamma + beta  (model.py:38-39).
-__global__ __launch_bounds__(64) void gn_finish_tiles_k(const float2* __restrict__ part, int TH, int TW, int tiles_r, int tiles_c, int OH,
-                                                        int OW, int cg, int G, float eps, const float* __restrict__ gamma,
-                                                        const float* __restrict__ beta, float* __restrict__ scale,
-                                                        float* __restrict__ shift, float* __restrict__ mean_out,
-                                                        float* __restrict__ rstd_out) {
+__global__ __launch_bounds__(256) void gn_finish_tiles_k(const float2* __restrict__ part, int TH, int TW, int tiles_r, int tiles_c, int OH,
+                                                         int OW, int cg, int G, float eps, const float* __restrict__ gamma,
+                                                         const float* __restrict__ beta, float* __restrict__ scale,
+                                                         float* __restrict__ shift, float* __restrict__ mean_out,
+                                                         float* __restrict__ rstd_out) {
+    // one workgroup of four waves per (image, group): 1024-2048 tiles per image at 512 x 512 were 16-32 dependent rounds for
+    // one wave (12-26 us per launch); the waves' partial sums merge in wave order (fixed: reproducible)
+    __shared__ float s_part[4];
     const int n = blockIdx.x / G, g = blockIdx.x - n * G;
     const int nb = tiles_r * tiles_c;
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const float2* pp = part + (size_t)n * nb * G + g;
     auto count = [&](int b) {
         const int tr = b / tiles_c, tc = b - tr * tiles_c;
         return (float)(min(TH, OH - tr * TH) * min(TW, OW - tc * TW) * cg);
     };
+    auto block_sum = [&](float v) {
+        v = wave_sum(v);
+        __syncthreads();                               // s_part free (second use)
+        if (lane == 0) s_part[w] = v;
+        __syncthreads();
+        return ((s_part[0] + s_part[1]) + s_part[2]) + s_part[3];
+    };
     const float total = (float)OH * (float)OW * (float)cg;
     float a = 0.f;
-    for (int b = threadIdx.x; b < nb; b += 64) a += count(b) * pp[(size_t)b * G].x;
-    const float m = wave_sum(a) / total;
+    for (int b = threadIdx.x; b < nb; b += 256) a += count(b) * pp[(size_t)b * G].x;
+    const float m = block_sum(a) / total;
     float q = 0.f;
-    for (int b = threadIdx.x; b < nb; b += 64) {
+    for (int b = threadIdx.x; b < nb; b += 256) {
         const float2 pb = pp[(size_t)b * G];
         const float d = pb.x - m;
         q += pb.y + count(b) * d * d;
     }
-    const float var = wave_sum(q) / total;
+    const float var = block_sum(q) / total;
     const float rs = rsqrtf(var + eps);
     if (threadIdx.x == 0 && mean_out) { mean_out[blockIdx.x] = m; rstd_out[blockIdx.x] = rs; }
     if ((int)threadIdx.x < cg) {
@@ -685,7 +696,7 @@ extern "C" int rbvae_gn_finish_tiles(const float* stats_part, const float* gamma
     RBVAE_CHECK_ARG(groups > 0 && C % groups == 0 && C / groups <= 64, "gn_finish_tiles: C=%d groups=%d", C, groups);
     RBVAE_CHECK_ARG((mean_out == nullptr) == (rstd_out == nullptr), "gn_finish_tiles: mean_out and rstd_out go together");
     RBVAE_CHECK_ARG(tile_h > 0 && tile_w > 0, "gn_finish_tiles: tile %d x %d (16 x 16: rbvae_conv3x3_halo, 8 x 16: rbvae_conv_in)", tile_h, tile_w);
-    hipLaunchKernelGGL(gn_finish_tiles_k, dim3(Nimg * groups), dim3(64), 0, (hipStream_t)stream, (const float2*)stats_part,
+    hipLaunchKernelGGL(gn_finish_tiles_k, dim3(Nimg * groups), dim3(256), 0, (hipStream_t)stream, (const float2*)stats_part,
                        tile_h, tile_w, cdiv(OH, tile_h), cdiv(OW, tile_w), OH, OW, C / groups, groups, eps, gamma, beta, scale, shift,
                        mean_out, rstd_out);
     RBVAE_CHECK_LAUNCH("gn_finish_tiles");
