@@ -79,41 +79,39 @@ class GradReducer:
     def head(self) -> torch.Tensor:
         return self.gflat[:self.cut]
 
+    def _sum(self, part: torch.Tensor, async_op: bool = False):
+        """all-reduce (sum) of one view of the gradient buffer; None in a one-rank job"""
+        if self.world <= 1:
+            return None
+        return dist.all_reduce(part, op=dist.ReduceOp.SUM, group=self.group, async_op=async_op)
+
+    # synchronous forms: on return the CURRENT stream is ordered behind the collective (what the 2-graph schedule issues
+    # between its graphs and what an in-graph schedule captures on its communication stream)
     def reduce_all(self):
-        if self.world > 1:
-            dist.all_reduce(self.gflat, op=dist.ReduceOp.SUM, group=self.group)
+        self._sum(self.gflat)
 
     def reduce_tail(self):
-        """Tail bucket, synchronous form: on return the CURRENT stream is ordered behind the collective (what an
-        in-graph schedule captures on its communication stream)."""
-        if self.world > 1:
-            dist.all_reduce(self.tail, op=dist.ReduceOp.SUM, group=self.group)
+        self._sum(self.tail)
 
     def reduce_head(self):
-        if self.world > 1:
-            dist.all_reduce(self.head, op=dist.ReduceOp.SUM, group=self.group)
+        self._sum(self.head)
 
+    # asynchronous forms: RCCL runs the collective on its own stream; wait() orders the current stream behind it (no host block)
     def start_tail(self):
-        if self.world > 1:
-            return dist.all_reduce(self.tail, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-        return None
+        return self._sum(self.tail, async_op=True)
 
     def start_head(self):
-        if self.world > 1:
-            return dist.all_reduce(self.head, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-        return None
+        return self._sum(self.head, async_op=True)
 
     @staticmethod
     def wait(work):
-        """Make the current stream wait for an asynchronous all-reduce (no host block with RCCL)."""
         if work is not None:
             work.wait()
 
     def finish(self, work):
-        if self.world > 1:
-            dist.all_reduce(self.head, op=dist.ReduceOp.SUM, group=self.group)
-            if work is not None:
-                work.wait()
+        """head bucket now, then the current stream waits for the tail's asynchronous all-reduce"""
+        self._sum(self.head)
+        self.wait(work)
 
 
 def broadcast_(flat: torch.Tensor, src=0, group=None):
