@@ -486,3 +486,48 @@ def test_load_state_dict_drops_captured_graphs_and_reprimes():
     tr2.load_state_dict(sd["optimizer_state_dict"])
     tr2.step(item, 0.8, U=U)
     assert torch.equal(m._flat, m2._flat)
+
+
+@pytest.mark.parametrize("variant,in_ch,hw,item_shape", [("contrastive", 3, (64, 64), (2, 2, 4)), ("percep", 4, (32, 48), (2, 2, 4))])
+def test_large_frame_weight_gradient_kernels_equal_the_gemm_path(variant, in_ch, hw, item_shape):
+    """The engine switches three weight-gradient kernels in by size (rbvae_wgrad3x3s2_halo for the 3x3 layers of <= 2 channel
+    tiles, rbvae_wgrad_first for the two 3/4-channel ends with the forward kernels' col = NULL): forced on at a small shape
+    (thresholds lowered to one pixel block per workgroup) they must leave the gradients of the rbvae_wgrad_gemm path --
+    the same bf16 products, f32 sums in another order -- and the same losses, from the same weights, batch, noise and
+    dropout keys."""
+    import sfv_amd as sfv
+    from importlib import import_module
+    FusedTrainer = import_module("symbols-from-video_amd.trainer").FusedTrainer
+    B, V, T = item_shape
+    g = torch.Generator().manual_seed(41)
+    item = torch.rand(B, V, T, in_ch, *hw, generator=g).cuda()
+    res = []
+    for forced in (True, False):
+        torch.manual_seed(40)
+        m = sfv.Seq2SeqBinaryVAE(in_ch, in_ch, 32, 32, variant=variant, input_hw=hw, compute_dtype="bf16").cuda().train()
+        tr = FusedTrainer(m, lr=1e-3, alpha=1.0, beta_kl=1.0, bernoulli_p=0.1, noise_ratio=0.1, device_noise=True, use_graph=False,
+                          seed=77)
+        eng = tr.eng = m._engine_for(item)            # the trainer adopts the model's engine at its first step
+        eng.seed_dev = tr.step_dev
+        if forced:
+            eng._wf_min_steps = 1
+            eng._wh_min_steps = 1
+        else:
+            eng.wgrad_first = False
+            eng.wgrad_halo = False
+        L = sfv._lib
+        names, orig = [], L.call
+        L.call = lambda name, *a: (names.append(name), orig(name, *a))[1]
+        try:
+            losses = tr.step(item, 0.7).cpu()
+        finally:
+            L.call = orig
+        res.append((losses, tr.gflat.clone(), eng, names))
+    (la, ga, ea, na), (lb, gb, eb, nb) = res
+    assert na.count("rbvae_wgrad_first") == 2 and "rbvae_wgrad_first" not in nb
+    assert ("rbvae_wgrad3x3s2_halo" in na) == (variant == "contrastive") and "rbvae_wgrad3x3s2_halo" not in nb
+    assert torch.allclose(la, lb, rtol=1e-6, atol=1e-6), (la, lb)
+    lay = ea.layout
+    for k in lay.names:
+        a, b = lay.view(ga, k).double().reshape(-1), lay.view(gb, k).double().reshape(-1)
+        assert float((a - b).norm()) <= 2e-5 * max(float(b.norm()), 1e-9), k
