@@ -531,3 +531,32 @@ def test_large_frame_weight_gradient_kernels_equal_the_gemm_path(variant, in_ch,
     for k in lay.names:
         a, b = lay.view(ga, k).double().reshape(-1), lay.view(gb, k).double().reshape(-1)
         assert float((a - b).norm()) <= 2e-5 * max(float(b.norm()), 1e-9), k
+
+
+def test_sixteen_fc_groups_equal_four():
+    """The fc products on either side of the LSTM stacks run K-split over 4 workgroup groups, over 16 from 16 384 fc inputs up
+    (native 4x88x160: 56 320, cfg 3: 65 536); the LSTM kernels sum the groups' slabs in order.  Sixteen groups forced at the
+    bench shape (4096 inputs) leave the losses of four and its gradients up to the f32 summation order of the fc products and
+    the bf16 roundings of the activations behind them that an f32 ulp flips (the first conv's weight gradient, a sum of
+    millions of cancelling terms, moves by 1.6e-4 relative; gate 2e-3)."""
+    import sfv_amd as sfv
+    from importlib import import_module
+    FusedTrainer = import_module("symbols-from-video_amd.trainer").FusedTrainer
+    g = torch.Generator().manual_seed(43)
+    item = torch.randn(4, 2, 8, 4, 32, 32, generator=g).cuda()
+    res = []
+    for groups in (16, 4):
+        torch.manual_seed(42)
+        m = sfv.Seq2SeqBinaryVAE(4, 4, 32, 32, variant="percep", input_hw=(32, 32), compute_dtype="bf16").cuda().train()
+        tr = FusedTrainer(m, lr=1e-3, alpha=1.0, beta_kl=1.0, bernoulli_p=0.1, noise_ratio=0.1, device_noise=True, use_graph=False,
+                          seed=78)
+        eng = tr.eng = m._engine_for(item)
+        eng.seed_dev = tr.step_dev
+        assert eng.fc_split == 4 and eng.F3 == 4096
+        eng.fc_split = groups
+        res.append((tr.step(item, 0.7).cpu(), tr.gflat.clone(), eng.layout))
+    (la, ga, lay), (lb, gb, _) = res
+    assert torch.allclose(la, lb, rtol=2e-6, atol=2e-6), (la, lb)
+    for k in lay.names:
+        a, b = lay.view(ga, k).double().reshape(-1), lay.view(gb, k).double().reshape(-1)
+        assert float((a - b).norm()) <= 2e-3 * max(float(b.norm()), 1e-9), k
