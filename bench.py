@@ -136,7 +136,8 @@ def roofline_leg(trainer, steps, tname, overlap):
       gather_gemm_k<T,2,4,3,64-row tile>  64x64 tiles, deep K, 4096 rows: conv3 forward, first deconv's input gradient
       gather_gemm_k<T,4,8,3>  128x128 row-gather GEMM, deep K, 129..256 workgroups: conv2 forward, first deconv
                               forward (4 parity classes) and their two input-gradient twins
-      wgrad_gemm_k<T,2,3>     128x128 weight-gradient GEMM with K split over workgroups: the five 256-channel ones
+      wgrad_row_k             3x3 stride-2 weight gradient, the three taps of a kernel row per workgroup (csrc/wgrad_row.hip)
+      wgrad_gemm_k<T,2,3>     128x128 weight-gradient GEMM with K split over workgroups: the other 256-channel ones
     Algorithmic FLOPs: 2 * output rows * Nout * Kc * taps for the gather GEMM (the 4 parity classes of a
     transposed convolution share its k*k taps: taps/4 per output pixel), 2 * P * Co * Ci * taps for wgrad."""
     import torch
@@ -174,9 +175,19 @@ def roofline_leg(trainer, steps, tname, overlap):
             return orig_gemm(*args, **kw)
 
     def timed_wgrad(Dy, In, idx, P, Co, Ci, ldy, ldi, taps, out, dims, strides, tag=None, **kw):
-        name = "wgrad_gemm_k<%s, %d, K-split>" % (tname, 2 if Ci > 64 else 1)
-        with timers.setdefault(name, KernelTimer())(2.0 * P * Co * Ci * taps):
-            return orig_wgrad(Dy, In, idx, P, Co, Ci, ldy, ldi, taps, out, dims, strides, tag=tag, **kw)
+        # the engine picks the kernel (three-taps-per-workgroup rows / nine-tap halo / per-tap GEMM) and says which
+        st = torch.cuda.current_stream()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(st)
+        r = orig_wgrad(Dy, In, idx, P, Co, Ci, ldy, ldi, taps, out, dims, strides, tag=tag, **kw)
+        b.record(st)
+        fam = eng.last_wgrad_kernel or "wgrad_gemm_k"
+        name = {"wgrad_row_k": "wgrad_row_k<3 taps per workgroup, K-split>", "wgrad_halo_k": "wgrad_halo_k<9 taps per workgroup, K-split>"}.get(
+            fam, "wgrad_gemm_k<%s, %d, K-split>" % (tname, 2 if Ci > 64 else 1))
+        t = timers.setdefault(name, KernelTimer())
+        t.pairs.append((a, b))
+        t.flops += 2.0 * P * Co * Ci * taps
+        return r
 
     calib = KernelTimer()                  # event pairs around nothing: the event records' own cost
 

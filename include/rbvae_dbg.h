@@ -14,6 +14,9 @@ int rbvae_dbg_glds(const void* src, const int* lane_src_chunk, void* out, void* 
 /* stamped builds of librbvae_hip only: every later rbvae_gather_gemm launch writes 8 phase time stamps (100 MHz) per workgroup into buf (NULL = off) */
 int rbvae_dbg_gg_stamps(unsigned long long* buf, void* stream);
 int rbvae_dbg_wg_stamps(unsigned long long* buf, void* stream);   /* same for rbvae_wgrad_gemm (-DWG_STAMPS=1 builds) */
+/* rbvae_wgrad3x3s2_row (-DWR_STAMPS=1 builds): per workgroup start, loop start, loop end, end (100 MHz), cycles waited at
+ * the stage barriers, cycles of the loop, K steps */
+int rbvae_dbg_wr_stamps(unsigned long long* buf, void* stream);
 int rbvae_dbg_tr16(const void* img, const int* rowsel, const int* colsel, void* out, void* stream);
 
 #ifdef __cplusplus

@@ -194,6 +194,20 @@ int rbvae_wgrad3x3s2_halo_blocks(int Nimg, int OH, int OW);
 int rbvae_wgrad3x3s2_halo(int dtype, const void* S, const void* G, float* dW_slabs, const void* zero_page, int Nimg, int OH,
                           int OW, int Ca, int Cb, int lds, int ldg, int ksplit, void* stream);
 
+/* ---- the same sum for wide layers (Ca, Cb multiples of 128, bf16): the three taps of ONE kernel row per workgroup ------
+ * A workgroup owns a 128 (a) x 128 (b) tile of the taps kw = 0, 1, 2 of one kh; per block of 64 low-resolution pixels the
+ * [64][128] tile of S arrives once and of G the rows 2r + kh - 1 with their 2W + 1 columns (kw = 0 and kw = 2 share the odd
+ * columns): 50 KB per 6.3 MFLOP instead of rbvae_wgrad_gemm's 96 KB (three taps, three workgroups).  Replaces
+ * rbvae_wgrad_gemm for the 256-channel Conv2d(.., 3, 2, 1) / ConvTranspose2d(.., 3, 2, 1, 1) weights of
+ * percep_RBVAE_model.py:54-57,76-81 (autograd as run by percep_RBVAE_train.py:552); same operands, same slab layout
+ * [ksplit][Ca][9][Cb] and the same reduction jobs as rbvae_wgrad3x3s2_halo.  K-slices are balanced runs of the
+ * rbvae_wgrad3x3s2_row_blocks(..) pixel blocks; grid = (Ca/128) * (Cb/128) * 3 * ksplit workgroups (rounded up to a multiple
+ * of 8: every XCD takes a contiguous eighth of the (K-slice, tile) items). */
+int rbvae_wgrad3x3s2_row_ok(int dtype, int Nimg, int OH, int OW, int Ca, int Cb);
+int rbvae_wgrad3x3s2_row_blocks(int Nimg, int OH, int OW);
+int rbvae_wgrad3x3s2_row(int dtype, const void* S, const void* G, float* dW_slabs, const void* zero_page, int Nimg, int OH,
+                         int OW, int Ca, int Cb, int lds, int ldg, int ksplit, void* stream);
+
 /* ---- layout helpers --------------------------------------------------------------
  * pack3:          out[i0*s0+i1*s1+i2*s2] = (T) in[i0][i1][i2]        (torch f32 weight -> packed T)
  * permute_reduce: out[i0][i1][i2] (+)= scale * sum_k in[k*slab+i0*s0+i1*s1+i2*s2]  (slabs -> torch grad)

@@ -239,6 +239,7 @@ class Engine:
         self._bwd_tab: Dict = {}       # uploaded reduce-job tables, keyed by their signature
         self._jobs: Optional[JobList] = None
         self._wg_cus = 256
+        self.last_wgrad_kernel = None  # kernel family the last _wgrad() call launched (bench.py's roofline leg keys its timers by it)
         self.first_launch_jobs = None  # extra job rows for the repack launch at the start of a forward(repack=True)
         self._job_blocks = 256      # workgroups per job of a batched job launch
         self._sides: List[Optional[torch.cuda.Stream]] = [None, None]
@@ -266,6 +267,17 @@ class Engine:
         self.wgrad_halo = True
         self._wh_min_steps = 8
         self._wh_max_tiles = 2
+        # three-taps-per-workgroup weight gradient of the wide (multiples of 128 channels) 3x3 stride-2 layers
+        # (csrc/wgrad_row.hip): K-slices of at least _wr_min_steps 64-pixel blocks, at most _wr_slab_mb MB of f32 slabs
+        self.wgrad_row = True
+        self._wr_min_steps = 4
+        self._wr_slab_mb = 64
+        # K-slices ~ sqrt(coef * blocks): a K-slice more costs its f32 slab (2.4 MB written, read again by the reduction job:
+        # ~1.2 us of memory time at 256 x 256 channels), a K-slice less lengthens every workgroup's loop by blocks / ks^2 steps
+        # of ~1.1 us.  Bench shape (256 blocks), same box, ms per step: 7 slices 0.4447, 10 0.4392, 14 0.4549, 21 0.4689
+        # (rbvae_wgrad_gemm: 0.4451); native 4 x 88 x 160 (1 760 blocks) wants every CU: 21 slices 2.00 (gemm 2.14)
+        self._wr_ks_coef = 0.4
+        self._wr_min_blocks = 128      # fewer 64-pixel blocks than this (the bench shape's 4 x 4 layers: 64): rbvae_wgrad_gemm
         # weight gradients of the two 3/4-channel ends from the image itself instead of from im2col rows in HBM
         # (rbvae_wgrad_first, csrc/conv_first.hip) when every workgroup gets at least this many 8 x 16 pixel blocks
         self.wgrad_first = True
@@ -623,9 +635,28 @@ class Engine:
             # together 245 against rbvae_wgrad_gemm's 172 -- narrow layers only
             if nblk // ks >= self._wh_min_steps and ntile <= self._wh_max_tiles:
                 slabs = self._buf(("slabs", tag), ks * Co * taps * Ci)
+                self.last_wgrad_kernel = "wgrad_halo_k"
                 L.call("rbvae_wgrad3x3s2_halo", self.dt, Dy, In, slabs, self.zero, nimg, oh, ow, Co, Ci, ldy, ldi, ks)
                 self._wgrad_reduce(slabs, out, Co, Ci, taps, ks, dims, strides)
                 return
+        if (geom is not None and self.wgrad_row and self.dt == BF16 and self.k == 3 and taps == 9 and idx is not None
+                and geom[3] == 2 * geom[1] and geom[4] == 2 * geom[2]
+                and L.query("rbvae_wgrad3x3s2_row_ok", self.dt, geom[0], geom[1], geom[2], Co, Ci)
+                and L.query("rbvae_wgrad3x3s2_row_blocks", geom[0], geom[1], geom[2]) >= self._wr_min_blocks):
+            # wide layers: the three taps of one kernel row per workgroup (csrc/wgrad_row.hip) -- 50 KB of operands per
+            # 6.3 MFLOP instead of rbvae_wgrad_gemm's 96, LDS-DMA issued by waves of their own
+            nimg, oh, ow = geom[:3]
+            nblk = L.query("rbvae_wgrad3x3s2_row_blocks", nimg, oh, ow)
+            ntile = (Co // 128) * (Ci // 128) * 3
+            # K-slices: one round of workgroups on the CUs this launch can count on, every workgroup >= _wr_min_steps
+            # blocks, at most ~_wr_slab_mb of f32 slabs
+            ks = max(1, min(self._wg_cus // ntile, nblk // self._wr_min_steps, (self._wr_slab_mb << 20) // (Co * taps * Ci * 4),
+                            int(round(math.sqrt(self._wr_ks_coef * nblk)))))
+            slabs = self._buf(("slabs", tag), ks * Co * taps * Ci)
+            self.last_wgrad_kernel = "wgrad_row_k"
+            L.call("rbvae_wgrad3x3s2_row", self.dt, Dy, In, slabs, self.zero, nimg, oh, ow, Co, Ci, ldy, ldi, ks)
+            self._wgrad_reduce(slabs, out, Co, Ci, taps, ks, dims, strides)
+            return
         nt4 = self._wg_nt4 and self.dt == BF16 and Ci % 256 == 0        # 128 x 256 tiles (wgrad_gemm.hip)
         blocks = -(-Co // 128) * -(-Ci // (256 if nt4 else 128 if Ci > 64 else 64)) * taps
         # K-slices: one round of workgroups on the 256 CUs, each with >= 256 pixels, and at most ~16 MB of f32
@@ -646,6 +677,7 @@ class Engine:
             ks = min(ks, self._ks_narrow)       # RBVAE_WG_KS_NARROW: the 64-column weight gradients (first conv, last deconv)
         ks = max(ks, -(-P // (2048 if nt4 else 4096)))   # the kernel keeps a K-slice's gather indices in LDS
         slabs = self._buf(("slabs", tag), ks * Co * taps * Ci)
+        self.last_wgrad_kernel = "wgrad_gemm_k<%d>" % (2 if Ci > 64 else 1)
         L.call("rbvae_wgrad_gemm", self.dt, Dy, In, slabs, idx, self.zero, P, In.numel() // ldi, Co, Ci, ldy, ldi, taps, ks)
         self._wgrad_reduce(slabs, out, Co, Ci, taps, ks, dims, strides)
 
