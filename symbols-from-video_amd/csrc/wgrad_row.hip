@@ -20,7 +20,7 @@
 //   S tile   row k = W rr + cc; 16-byte chunks XOR-swizzled by tr_swz<256> (wgrad_gemm.hip).
 //   G patch  block row rr holds 2W + 1 slots: j = 0..W the odd columns 2 (c0 + j) - 1, j = W + 1..2W the even columns
 //            2 (c0 + j - W - 1); tap kw of pixel (rr, cc) is slot j = cc | W + 1 + cc | cc + 1: consecutive pixels are
-//            consecutive slots although the convolution strides by two.  Chunk pairs XORed by (j + W/2 rr) & 7: the eight
+//            consecutive slots although the convolution strides by two.  Chunk pairs XORed by wr_swz_g(rr, j): the eight
 //            pixel rows a 32-lane half of a transposing read touches fall on eight distinct 32-byte bank groups.
 // Blocks tile the flattened rows (n, r) -> n OH + r (a block may span images: every block row looks up its own image),
 // W = 8 or 4 columns (whichever pads the image width less), strips of W columns.
@@ -37,7 +37,7 @@
 #include "common.h"
 #include <type_traits>
 
-#ifndef WR_ABL          // timing ablations (results wrong on purpose; RBVAE_ABLATION builds only): 1 no LDS-DMA, 2 no fragment reads / MFMAs, 3 / 4 see piece()
+#ifndef WR_ABL          // timing ablations (results wrong on purpose; RBVAE_ABLATION builds only): 1 no LDS-DMA, 2 no fragment reads / MFMAs, 3 see stage(), 5 no fragment reads, 6 one MFMA wave per SIMD
 #define WR_ABL 0
 #endif
 #if WR_ABL && !defined(RBVAE_ABLATION)
@@ -74,6 +74,10 @@ __device__ __forceinline__ void wr_glds16(const void* g, void* lds) {
                                      (__attribute__((address_space(3))) void*)lds, 16, 0, 0);
 }
 __device__ __forceinline__ int wr_swz_a(int row) { return ((row & 3) | (((row >> 3) & 1) << 2)) << 1; }   // tr_swz<256>
+// chunk-pair swizzle of patch slot (block row rr, slot jj): the eight pixel rows a 32-lane half of a transposing read touches
+// (four consecutive slots of two block rows: rr, rr + 1 for W = 8; rr, rr + 2 for W = 4) get eight distinct values, and the
+// pixels k + 4 / k + 32 of a lane get the SAME value as pixel k (their reads are immediate offsets of one address)
+template <int W> __device__ __forceinline__ int wr_swz_g(int rr, int jj) { return (jj & 3) | ((((W == 8) ? rr : rr >> 1) & 1) << 2); }
 
 template <int N> __device__ __forceinline__ void wr_wait_barrier() {
     asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(N) : "memory");
@@ -85,6 +89,7 @@ __global__ __launch_bounds__(768, 1) void wgrad_row_k(const WrArgs p) {
     constexpr int G_BYTES = NSLOT * 256, STAGE = WR_A_BYTES + G_BYTES;
     constexpr int TOT = 16 + NSLOT / 4;                               // LDS-DMA instructions per stage: 50 (W = 8) / 52 (W = 4)
     constexpr int KSUB = (32 / W) * SPR * 256;                        // second 32-pixel half of a block: 32 / W block rows on
+    constexpr int HOFF = (W == 8 ? 4 : SPR) * 256;                    // pixel k + 4: four slots on (W = 8) / the next block row (W = 4)
     static_assert(NSLOT % 4 == 0 && TOT <= 4 * WR_MAXP && TOT > 4 * (WR_MAXP - 1), "instruction split");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -135,7 +140,7 @@ __global__ __launch_bounds__(768, 1) void wgrad_row_k(const WrArgs p) {
                 const int rr = s / SPR, jj = s - rr * SPR;
                 const int dcol = jj <= W ? 2 * jj - 1 : 2 * (jj - W - 1);
                 d_rr[j] = rr; d_c[j] = dcol; d_rm[j] = rr % p.OH;
-                d_off[j] = ((2 * rr + kh) * IW + dcol + 1) * ldg_b + (((lane & 15) ^ (((jj + (W / 2) * rr) & 7) << 1)) * 16) + b0 * 2;
+                d_off[j] = ((2 * rr + kh) * IW + dcol + 1) * ldg_b + (((lane & 15) ^ (wr_swz_g<W>(rr, jj) << 1)) * 16) + b0 * 2;
             }
         }
         const auto rsrcS = __builtin_amdgcn_make_buffer_rsrc((void*)p.S, 0, p.rows * p.OW * lds_b, 0x00020000);
@@ -203,18 +208,15 @@ __global__ __launch_bounds__(768, 1) void wgrad_row_k(const WrArgs p) {
         const int chunk = ((wr * 4) * 2 + (pp >> 1)) ^ wr_swz_a(row);
         offA = row * 256 + chunk * 16 + (pp & 1) * 8;
     }
-    int offB[3][2];                                      // [kw][h]: pixel k = 8 fg + 4 h + q of the first half, b sub-tile 2 wc
-#pragma unroll                                           // (sub-tile 2 wc + 1: chunk index ^ 2 = byte address ^ 32, stage bases are multiples of 1 KiB)
-    for (int kw = 0; kw < 3; ++kw)
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int k = 8 * fg + 4 * h + q;
-            const int rr = k / W, cc = k % W;
-            const int jj = kw == 0 ? cc : (kw == 1 ? W + 1 + cc : cc + 1);
-            const int s = rr * SPR + jj, g = (jj + (W / 2) * rr) & 7;
-            const int chunk = ((wc * 2) * 2 + (pp >> 1)) ^ (g << 1);
-            offB[kw][h] = WR_A_BYTES + s * 256 + chunk * 16 + (pp & 1) * 8;
-        }
+    int offB[3];                                         // [kw]: pixel k = 8 fg + q of the first half, b sub-tile 2 wc
+#pragma unroll                                           // (sub-tile 2 wc + 1: chunk index ^ 2 = byte address ^ 32; pixel k + 4 and the second
+    for (int kw = 0; kw < 3; ++kw) {                     //  half: the same swizzle value, i.e. immediate offsets HOFF and KSUB)
+        const int k = 8 * fg + q;
+        const int rr = k / W, cc = k % W;
+        const int jj = kw == 0 ? cc : (kw == 1 ? W + 1 + cc : cc + 1);
+        const int chunk = ((wc * 2) * 2 + (pp >> 1)) ^ (wr_swz_g<W>(rr, jj) << 1);
+        offB[kw] = WR_A_BYTES + (rr * SPR + jj) * 256 + chunk * 16 + (pp & 1) * 8;
+    }
 
     wr_f32x4_t acc[3][4][2];
 #pragma unroll
@@ -228,10 +230,14 @@ __global__ __launch_bounds__(768, 1) void wgrad_row_k(const WrArgs p) {
     // Fragment reads are inline asm (invisible to the compiler's wait-count pass); every group is followed by a counted
     // s_waitcnt lgkmcnt tied ("+v") to the registers it guards, and isa_check proves on the listing that nothing touches a
     // register before its wait.
-    auto read_a = [&](unsigned lb, auto ksub_tag, wr_s16x4_t (&al)[4], wr_s16x4_t (&ah)[4]) {
-        constexpr int KS_ = decltype(ksub_tag)::value;
+    // reads of the S fragments of a sub-tiles m0, m0 + 1 (4 reads) / of one tap's G fragments (4 reads)
+    auto read_a2 = [&](unsigned lb, auto ksub_tag, auto m0_tag, wr_s16x4_t (&al)[4], wr_s16x4_t (&ah)[4]) {
+        constexpr int KS_ = decltype(ksub_tag)::value, M0 = decltype(m0_tag)::value;
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt) {
+        for (int mt = M0; mt < M0 + 2; ++mt) {
+#if WR_ABL == 5
+            continue;
+#endif
             const unsigned ad = (lb + offA) ^ (mt * 32);
             asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(al[mt]) : "v"(ad), "n"(KS_ * 32 * 256));
             asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(ah[mt]) : "v"(ad), "n"(KS_ * 32 * 256 + 4 * 256));
@@ -241,58 +247,66 @@ __global__ __launch_bounds__(768, 1) void wgrad_row_k(const WrArgs p) {
         constexpr int KS_ = decltype(ksub_tag)::value;
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) {
-            const unsigned adl = (lb + offB[kw][0]) ^ (nt * 32), adh = (lb + offB[kw][1]) ^ (nt * 32);
-            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(bl[nt]) : "v"(adl), "n"(KS_ * KSUB));
-            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(bh[nt]) : "v"(adh), "n"(KS_ * KSUB));
+#if WR_ABL == 5
+            continue;
+#endif
+            const unsigned ad = (lb + offB[kw]) ^ (nt * 32);
+            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(bl[nt]) : "v"(ad), "n"(KS_ * KSUB));
+            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(bh[nt]) : "v"(ad), "n"(KS_ * KSUB + HOFF));
         }
     };
-    auto landed_b = [&](auto younger_tag, wr_s16x4_t (&bl)[2], wr_s16x4_t (&bh)[2], wr_bf16x8_t (&fb)[2]) {
-        constexpr int Y = decltype(younger_tag)::value;
+    // counted waits tied to the registers they guard: at most Y younger reads stay outstanding
+    auto wait_b = [&](auto y_tag, wr_s16x4_t (&bl)[2], wr_s16x4_t (&bh)[2]) {
+        constexpr int Y = decltype(y_tag)::value;
         asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(bl[0]), "+v"(bh[0]), "+v"(bl[1]), "+v"(bh[1]) : "n"(Y));
-#pragma unroll
-        for (int nt = 0; nt < 2; ++nt)
-            fb[nt] = wr_bf16x8_t{bl[nt][0], bl[nt][1], bl[nt][2], bl[nt][3], bh[nt][0], bh[nt][1], bh[nt][2], bh[nt][3]};
     };
-    auto landed_ab = [&](auto younger_tag, wr_s16x4_t (&al)[4], wr_s16x4_t (&ah)[4], wr_s16x4_t (&bl)[2], wr_s16x4_t (&bh)[2],
-                         wr_bf16x8_t (&fa)[4], wr_bf16x8_t (&fb)[2]) {
-        constexpr int Y = decltype(younger_tag)::value;
-        asm volatile("s_waitcnt lgkmcnt(%12)"
-                     : "+v"(al[0]), "+v"(ah[0]), "+v"(al[1]), "+v"(ah[1]), "+v"(al[2]), "+v"(ah[2]), "+v"(al[3]), "+v"(ah[3]),
-                       "+v"(bl[0]), "+v"(bh[0]), "+v"(bl[1]), "+v"(bh[1])
+    auto wait_a2 = [&](auto y_tag, auto m0_tag, wr_s16x4_t (&al)[4], wr_s16x4_t (&ah)[4]) {
+        constexpr int Y = decltype(y_tag)::value, M0 = decltype(m0_tag)::value;
+        asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(al[M0]), "+v"(ah[M0]), "+v"(al[M0 + 1]), "+v"(ah[M0 + 1]) : "n"(Y));
+    };
+    auto wait_a2b = [&](auto y_tag, auto m0_tag, wr_s16x4_t (&al)[4], wr_s16x4_t (&ah)[4], wr_s16x4_t (&bl)[2], wr_s16x4_t (&bh)[2]) {
+        constexpr int Y = decltype(y_tag)::value, M0 = decltype(m0_tag)::value;
+        asm volatile("s_waitcnt lgkmcnt(%8)"
+                     : "+v"(al[M0]), "+v"(ah[M0]), "+v"(al[M0 + 1]), "+v"(ah[M0 + 1]), "+v"(bl[0]), "+v"(bh[0]), "+v"(bl[1]), "+v"(bh[1])
                      : "n"(Y));
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt)
-            fa[mt] = wr_bf16x8_t{al[mt][0], al[mt][1], al[mt][2], al[mt][3], ah[mt][0], ah[mt][1], ah[mt][2], ah[mt][3]};
-#pragma unroll
-        for (int nt = 0; nt < 2; ++nt)
-            fb[nt] = wr_bf16x8_t{bl[nt][0], bl[nt][1], bl[nt][2], bl[nt][3], bh[nt][0], bh[nt][1], bh[nt][2], bh[nt][3]};
     };
-    auto mma = [&](int kw, const wr_bf16x8_t (&fa)[4], const wr_bf16x8_t (&fb)[2]) {
+    // the MFMAs of tap kw on a sub-tiles m0 .. m0 + NM - 1 (fragments that have passed their wait)
+    auto mma = [&](int kw, auto m0_tag, auto nm_tag, const wr_s16x4_t (&al)[4], const wr_s16x4_t (&ah)[4], const wr_s16x4_t (&bl)[2],
+                   const wr_s16x4_t (&bh)[2]) {
+        constexpr int M0 = decltype(m0_tag)::value, NM = decltype(nm_tag)::value;
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt)
+        for (int nt = 0; nt < 2; ++nt) {
+            const wr_bf16x8_t fb = {bl[nt][0], bl[nt][1], bl[nt][2], bl[nt][3], bh[nt][0], bh[nt][1], bh[nt][2], bh[nt][3]};
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt)
-                acc[kw][mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[nt], fa[mt], acc[kw][mt][nt], 0, 0, 0);
+            for (int mt = M0; mt < M0 + NM; ++mt) {
+                const wr_bf16x8_t fa = {al[mt][0], al[mt][1], al[mt][2], al[mt][3], ah[mt][0], ah[mt][1], ah[mt][2], ah[mt][3]};
+                acc[kw][mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb, fa, acc[kw][mt][nt], 0, 0, 0);
+            }
+        }
     };
     using H0 = std::integral_constant<int, 0>;
     using H1 = std::integral_constant<int, 1>;
+    using M0 = std::integral_constant<int, 0>;
+    using M2 = std::integral_constant<int, 2>;
+    using N2 = std::integral_constant<int, 2>;
+    using N4 = std::integral_constant<int, 4>;
     using Y0 = std::integral_constant<int, 0>;
     using Y4 = std::integral_constant<int, 4>;
-    using Y8 = std::integral_constant<int, 8>;
 
 #define WR_SB() __builtin_amdgcn_sched_barrier(0)
     if (nsteps > 0) {
-        wr_s16x4_t a0l[4], a0h[4], a1l[4], a1h[4], xbl[2], xbh[2], ybl[2], ybh[2];
-        wr_bf16x8_t fa[4], fb[2];
+        wr_s16x4_t a0l[4], a0h[4], a1l[4], a1h[4], xbl[2], xbh[2], ybl[2], ybh[2], zbl[2], zbh[2];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) fa[i] = wr_bf16x8_t{0, 0, 0, 0, 0, 0, 0, 0};
+        for (int i = 0; i < 4; ++i) a1l[i] = a1h[i] = wr_s16x4_t{0, 0, 0, 0};
 #pragma unroll
-        for (int i = 0; i < 2; ++i) fb[i] = wr_bf16x8_t{0, 0, 0, 0, 0, 0, 0, 0};
+        for (int i = 0; i < 2; ++i) zbl[i] = zbh[i] = wr_s16x4_t{0, 0, 0, 0};
         unsigned lb = lds0;
         // Block s: barrier (stage s landed: the producer waves waited for their pieces in front of it).  Six (half, tap) units
-        // of 8 MFMAs; the reads of unit u + 1 are issued before the MFMAs of unit u, and the last unit's MFMAs run at the top
-        // of the next block behind its first reads (zero fragments at s = 0).  Nothing asynchronous crosses the loop's back
-        // edge: fa / fb carry landed fragments.
+        // of 8 MFMAs: u0..u2 = taps 0..2 on the first 32 pixels (S fragments a0), u3..u5 on the second (a1); G fragments
+        // rotate through three sets (x, y, z).  Reads are issued 8-16 MFMAs ahead of their use -- with one unit of cover the
+        // wave that loses the matrix-pipe arbitration to its SIMD partner ran its last third alone at 37 % of the pipe --
+        // never more than 12 outstanding (lgkmcnt is a 4-bit counter), and the last unit's MFMAs run at the top of the next
+        // block behind its first reads (zero fragments at s = 0).  Nothing asynchronous crosses the loop's back edge.
 #if WR_STAMPS
         st_loop0 = wall_clock64(); st_c0 = __builtin_amdgcn_s_memtime();
 #endif
@@ -304,33 +318,41 @@ __global__ __launch_bounds__(768, 1) void wgrad_row_k(const WrArgs p) {
 #else
             asm volatile("s_barrier" ::: "memory");
 #endif
+#if WR_ABL == 6
+            if (w >= 4) continue;
+#endif
 #if WR_ABL != 2
-            // (never more than 12 reads outstanding: lgkmcnt is a 4-bit counter)
             read_b(lb, H0{}, 0, xbl, xbh);
-            read_a(lb, H0{}, a0l, a0h);
-            WR_SB(); mma(2, fa, fb); WR_SB();                     // last unit of block s - 1
-            landed_ab(Y0{}, a0l, a0h, xbl, xbh, fa, fb);          // half 0: S fragments + tap 0
+            read_a2(lb, H0{}, M0{}, a0l, a0h);
+            read_a2(lb, H0{}, M2{}, a0l, a0h);
+            WR_SB(); mma(2, M0{}, N4{}, a1l, a1h, zbl, zbh); WR_SB();          // u5 of block s - 1
+            wait_a2b(Y4{}, M0{}, a0l, a0h, xbl, xbh);                         // x, a0[0:2]  (a0[2:4] in flight)
             read_b(lb, H0{}, 1, ybl, ybh);
-            WR_SB(); mma(0, fa, fb); WR_SB();
-            read_b(lb, H0{}, 2, xbl, xbh);
-            landed_b(Y4{}, ybl, ybh, fb);                         // tap 1
-            read_a(lb, H1{}, a1l, a1h);
-            WR_SB(); mma(1, fa, fb); WR_SB();
-            landed_b(Y8{}, xbl, xbh, fb);                         // tap 2 (the second half's S fragments stay in flight)
-            read_b(lb, H1{}, 0, ybl, ybh);
-            WR_SB(); mma(2, fa, fb); WR_SB();
-            landed_ab(Y0{}, a1l, a1h, ybl, ybh, fa, fb);          // half 1: S fragments + tap 0
-            read_b(lb, H1{}, 1, xbl, xbh);
-            WR_SB(); mma(0, fa, fb); WR_SB();
-            read_b(lb, H1{}, 2, ybl, ybh);
-            landed_b(Y4{}, xbl, xbh, fb);                         // tap 1
-            WR_SB(); mma(1, fa, fb); WR_SB();
-            landed_b(Y0{}, ybl, ybh, fb);                         // tap 2: the stage is in registers
+            WR_SB(); mma(0, M0{}, N2{}, a0l, a0h, xbl, xbh); WR_SB();          // u0, first half
+            wait_a2(Y4{}, M2{}, a0l, a0h);                                    // a0[2:4]  (y in flight)
+            read_b(lb, H0{}, 2, zbl, zbh);
+            WR_SB(); mma(0, M2{}, N2{}, a0l, a0h, xbl, xbh); WR_SB();          // u0, second half
+            wait_b(Y4{}, ybl, ybh);                                           // y  (z in flight)
+            read_a2(lb, H1{}, M0{}, a1l, a1h);
+            WR_SB(); mma(1, M0{}, N4{}, a0l, a0h, ybl, ybh); WR_SB();          // u1
+            wait_b(Y4{}, zbl, zbh);                                           // z  (a1[0:2] in flight)
+            read_b(lb, H1{}, 0, xbl, xbh);
+            read_a2(lb, H1{}, M2{}, a1l, a1h);
+            WR_SB(); mma(2, M0{}, N4{}, a0l, a0h, zbl, zbh); WR_SB();          // u2
+            wait_a2b(Y4{}, M0{}, a1l, a1h, xbl, xbh);                         // a1[0:2], x  (a1[2:4] in flight)
+            read_b(lb, H1{}, 1, ybl, ybh);
+            WR_SB(); mma(0, M0{}, N2{}, a1l, a1h, xbl, xbh); WR_SB();          // u3, first half
+            wait_a2(Y4{}, M2{}, a1l, a1h);                                    // a1[2:4]  (y in flight)
+            read_b(lb, H1{}, 2, zbl, zbh);
+            WR_SB(); mma(0, M2{}, N2{}, a1l, a1h, xbl, xbh); WR_SB();          // u3, second half
+            wait_b(Y4{}, ybl, ybh);                                           // y  (z in flight)
+            WR_SB(); mma(1, M0{}, N4{}, a1l, a1h, ybl, ybh); WR_SB();          // u4
+            wait_b(Y0{}, zbl, zbh);                                           // z: the stage is in registers
 #endif
             lb = lb + STAGE == lds0 + WR_RING * STAGE ? lds0 : lb + STAGE;
         }
 #if WR_ABL != 2
-        mma(2, fa, fb);
+        mma(2, M0{}, N4{}, a1l, a1h, zbl, zbh);
 #endif
 #if WR_STAMPS
         st_loop1 = wall_clock64(); st_c1 = __builtin_amdgcn_s_memtime();
