@@ -71,6 +71,55 @@ __global__ __launch_bounds__(256) void colsum_partial_k(const T* __restrict__ X,
         ws[(long)blockIdx.x * C + c] = t;
     }
 }
+// The same partial sums for wide tensors (C a multiple of 16 / sizeof(T), 16-byte aligned rows): a thread owns one 16-byte
+// chunk of columns and walks the block's rows with 16-byte loads, four in flight.  The one-element-per-thread form above
+// moved the decoder fc's 128 x 56 320 bf16 gradient (14 MB, native 4x88x160) in 89 us; the sums are the same f32 additions
+// in the same row order.
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_partial_vec_k(const T* __restrict__ X, int P, int C, int ld, int rpb,
+                                                            float* __restrict__ ws) {
+    constexpr int EC = 16 / sizeof(T);
+    typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+    const int r0 = blockIdx.x * rpb, r1 = min(P, r0 + rpb);
+    const int c = (blockIdx.y * 256 + threadIdx.x) * EC;
+    if (c >= C) return;
+    float acc[EC];
+#pragma unroll
+    for (int e = 0; e < EC; ++e) acc[e] = 0.f;
+    const T* px = X + (long)r0 * ld + c;
+    int r = r0;
+    for (; r + 4 <= r1; r += 4) {
+        u32x4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = *(const u32x4*)(px + (long)u * ld);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const T* ev = (const T*)&v[u];
+#pragma unroll
+            for (int e = 0; e < EC; ++e) acc[e] += Elem<T>::load(ev + e);
+        }
+        px += 4l * ld;
+    }
+    for (; r < r1; ++r) {
+        const u32x4 v = *(const u32x4*)px;
+        const T* ev = (const T*)&v;
+#pragma unroll
+        for (int e = 0; e < EC; ++e) acc[e] += Elem<T>::load(ev + e);
+        px += ld;
+    }
+    float* o = ws + (long)blockIdx.x * C + c;
+#pragma unroll
+    for (int e = 0; e < EC; e += 4) *(float4*)(o + e) = make_float4(acc[e], acc[e + 1], acc[e + 2], acc[e + 3]);
+}
+template <typename T>
+static void launch_colsum_partial(const T* X, int P, int C, int ld, int rpb, float* ws, hipStream_t st) {
+    constexpr int EC = 16 / sizeof(T);
+    if (C >= 2048 && C % EC == 0 && ld % EC == 0 && (uintptr_t)X % 16 == 0 && (uintptr_t)ws % 16 == 0) {
+        hipLaunchKernelGGL(colsum_partial_vec_k<T>, dim3(cdiv(P, rpb), cdiv(C, 256 * EC)), dim3(256), 0, st, X, P, C, ld, rpb, ws);
+    } else {
+        hipLaunchKernelGGL(colsum_partial_k<T>, dim3(cdiv(P, rpb), cdiv(C, 256)), dim3(256), 0, st, X, P, C, ld, rpb, ws);
+    }
+}
 // out[c] (+)= scale * sum_b ws[b][c]: 64 columns per block, 4 row lanes, fixed order
 __global__ __launch_bounds__(256) void colsum_final_k(const float* __restrict__ ws, int nblk, int C,
                                                       float* __restrict__ out, float scale, int accumulate) {
@@ -550,13 +599,10 @@ int rbvae_colsum(int dtype, const void* X, int P, int C, int ld, float* out, flo
     RBVAE_CHECK_ARG(X && out && ws && P > 0 && C > 0 && ld >= C, "colsum: bad arguments");
     const int rpb = colsum_rpb(P);
     const int nblk = cdiv(P, rpb);
-    const dim3 grid(nblk, cdiv(C, 256));
     if (dtype == RBVAE_F32)
-        hipLaunchKernelGGL(colsum_partial_k<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)X,
-                           P, C, ld, rpb, ws);
+        launch_colsum_partial<float>((const float*)X, P, C, ld, rpb, ws, (hipStream_t)stream);
     else if (dtype == RBVAE_BF16)
-        hipLaunchKernelGGL(colsum_partial_k<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream,
-                           (const bf16_t*)X, P, C, ld, rpb, ws);
+        launch_colsum_partial<bf16_t>((const bf16_t*)X, P, C, ld, rpb, ws, (hipStream_t)stream);
     else
         return fail(RBVAE_E_INVALID, "colsum: dtype %d", dtype);
     hipLaunchKernelGGL(colsum_final_k, dim3(cdiv(C, 64)), dim3(256), 0, (hipStream_t)stream, ws, nblk, C, out, scale,
@@ -568,13 +614,10 @@ int rbvae_colsum(int dtype, const void* X, int P, int C, int ld, float* out, flo
 int rbvae_colsum_partial(int dtype, const void* X, int P, int C, int ld, float* ws, void* stream) {
     RBVAE_CHECK_ARG(X && ws && P > 0 && C > 0 && ld >= C, "colsum_partial: bad arguments");
     const int rpb = colsum_rpb(P);
-    const dim3 grid(cdiv(P, rpb), cdiv(C, 256));
     if (dtype == RBVAE_F32)
-        hipLaunchKernelGGL(colsum_partial_k<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)X, P, C, ld,
-                           rpb, ws);
+        launch_colsum_partial<float>((const float*)X, P, C, ld, rpb, ws, (hipStream_t)stream);
     else if (dtype == RBVAE_BF16)
-        hipLaunchKernelGGL(colsum_partial_k<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)X, P, C,
-                           ld, rpb, ws);
+        launch_colsum_partial<bf16_t>((const bf16_t*)X, P, C, ld, rpb, ws, (hipStream_t)stream);
     else
         return fail(RBVAE_E_INVALID, "colsum_partial: dtype %d", dtype);
     RBVAE_CHECK_LAUNCH("colsum_partial");

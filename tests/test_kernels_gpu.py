@@ -243,7 +243,9 @@ def test_skinny_linear_and_colsum(sfv, dtype):
         out = torch.empty(M, Nc, device="cuda")
         sfv._lib.call("rbvae_skinny_linear", dt, A.cuda(), B.cuda(), b.cuda(), out, M, Nc, K, K, K, Nc)
         assert rel(out.cpu(), A.float() @ B.float().t() + b) < tol
-    for (P, C) in ((1000, 256), (77, 3), (513, 4096), (300, 25)):
+    # (513, 4096), (130, 2056), (128, 56320): the 16-byte-per-thread form (wide tensors; ragged last column group, rows not a multiple
+    # of four, the native 4x88x160 decoder fc gradient)
+    for (P, C) in ((1000, 256), (77, 3), (513, 4096), (300, 25), (130, 2056), (128, 56320)):
         X = torch.randn(P, C, generator=g).to(tdt)
         out = torch.empty(C, device="cuda")
         ws = torch.empty(sfv._lib.query("rbvae_colsum_ws_floats", P, C), device="cuda")
