@@ -92,6 +92,9 @@ template <typename T, int RING> constexpr int ch_lds_main() {
 #ifndef CH_ABL
 #define CH_ABL 0
 #endif
+#if CH_ABL && !defined(RBVAE_ABLATION)
+#error "CH_ABL builds give wrong results: define RBVAE_ABLATION to confirm"
+#endif
 
 template <int I, int N, typename F> __device__ __forceinline__ void ch_static_for(F&& f) {
     if constexpr (I < N) {

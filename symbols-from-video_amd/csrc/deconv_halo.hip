@@ -413,6 +413,9 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? 2 : 1) void deconv_halo_k(
 #ifndef DH_ABL
 #define DH_ABL 0          // timing-only builds (tools/ab_variants.sh): 1 no epilogue, 2 no main loop, 4 no tables / prologue work
 #endif
+#if DH_ABL && !defined(RBVAE_ABLATION)
+#error "DH_ABL builds give wrong results: define RBVAE_ABLATION to confirm"
+#endif
 #if !(DH_ABL & 2)
     for (int kcl = 0; kcl + 1 < nkc; ++kcl) {
         int kc = kcl;

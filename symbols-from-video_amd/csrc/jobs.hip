@@ -190,6 +190,9 @@ __device__ __forceinline__ void conv_pack_rows(const Job& j, unsigned char* lds_
 // change order through LDS and leave as 16-byte stores of the contiguous [ci][t] row.
 constexpr int CRD_CI = 256, CRD_MAXKK = 16, CRD_ACC = CRD_CI * CRD_MAXKK / 4 / 256;      // float4 accumulators per thread
 __device__ __forceinline__ void conv_reduce_rows(const Job& j, float* tile) {
+#if defined(JOBS_ABL_ONE_SLAB) && !defined(RBVAE_ABLATION)
+#error "JOBS_ABL_ONE_SLAB gives wrong sums (timing ablation): define RBVAE_ABLATION to confirm"
+#endif
 #ifdef JOBS_ABL_ONE_SLAB
     const unsigned Co = (unsigned)j.d0, Ci = (unsigned)j.d1, kk = (unsigned)j.d2, ns = 1;      // ablation partner of WG_ABL=5
 #else

@@ -32,6 +32,9 @@
 #ifndef WH_ABL          // timing ablations (results wrong on purpose): 1 no LDS-DMA, 2 no fragment reads / MFMAs
 #define WH_ABL 0
 #endif
+#if WH_ABL && !defined(RBVAE_ABLATION)
+#error "WH_ABL builds give wrong results: define RBVAE_ABLATION to confirm"
+#endif
 
 namespace rbvae {
 

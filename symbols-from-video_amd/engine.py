@@ -240,24 +240,17 @@ class Engine:
         self._jobs: Optional[JobList] = None
         self._wg_cus = 256
         self.last_wgrad_kernel = None  # kernel family the last _wgrad() call launched (bench.py's roofline leg keys its timers by it)
-        self.first_launch_jobs = None  # extra job rows for the repack launch at the start of a forward(repack=True)
         self._job_blocks = 256      # workgroups per job of a batched job launch
-        self._sides: List[Optional[torch.cuda.Stream]] = [None, None]
-        # weight-gradient work of the decoder runs on a side stream beside the LSTM backward chain (RBVAE_OVERLAP=0:
-        # everything in issue order on one stream)
+        self._side: Optional[torch.cuda.Stream] = None
+        # Side stream (graph capture turns the fork / join into graph edges; `overlap = False`: everything in issue order on
+        # one stream -- bench.py's `isolated` leg).  What rides it was settled by same-GPU sweeps in rounds 1-2 (ms/step):
+        # pair term + decoder weight gradients + their reductions 0.547; also the loss bookkeeping / the LSTM weight
+        # gradients as forks of their own / the final reductions 0.553-0.568; nothing 0.591.  Full-chip side kernels beside
+        # full-chip main kernels only contend.  Program order at a fork: the main stream's continuation is issued BEFORE the
+        # side work (graph capture hands the forking node's queue to the branch created first; created second, the main
+        # chain paid a cross-queue hand-off of ~10 us at every fork).
         self.overlap = True
-        self.pack_late_split = False or bool(14 & 128)
-        # default 14 = pair term + decoder weight gradients + their reductions (same-GPU sweep, ms/step: 14 0.547,
-        # 12 0.553, 6 0.554, 30 0.556, 4 0.556, 63 0.568, 0 0.591: the weight repack, the loss bookkeeping and the
-        # LSTM weight gradients are better left on the main stream)
-        self.side_mask = 14
-        # Program order at a fork: the main stream's continuation is issued BEFORE the side work (the side stream
-        # already waits on the fork point).  Graph capture hands the forking node's queue to the branch created
-        # first; created second, the main chain paid the cross-queue hand-off (~10 us idle at every fork).
-        self.main_first = True
-        self._ks_force = 0
         self._ks_small = 3
-        self._wg_nt4 = os.environ.get("RBVAE_WG_NT4", "0") == "1"     # the library reads the same switch (wgrad_gemm.hip)
         self.fc_gemm = True               # dedicated kernel for the K = 64 fc products
         # halo-resident kernel for the transposed 3x3 / stride-2 launches (csrc/deconv_halo.hip) from this many workgroups up
         self.deconv_halo = True
@@ -284,32 +277,24 @@ class Engine:
         self._wf_min_steps = 8
         self.lstm_pair_bwd = True   # both stacks' BPTT in one launch
         self.keep_dz = False                # also store the codes' gradient
-        self._wg_nt4_slab = 8     # cap on a weight's f32 slabs, M floats
-        self._ks_narrow = 0
-        self.book_with_dec = True
-        self.wfc_side = True
-        self.lstm_wgrad_tail = True
-        self.tail_wgrads = 0
-        self.side_wg_cap = True
-        self.mid_reduce = False
-        # RBVAE_WFC_SWAP=1: the encoder fc's weight gradient with rows / columns swapped (full 128-row tiles on the 64-column
-        # kernel instance).  Same box, 2 x 2 runs: 0.4696 (swapped) vs 0.4666 ms/step -- the launch rides the side tail
-        # either way -- so the plain form stays.
-        self.wfc_swap = False
         # The fc products on either side of the LSTM stacks (M = frames, 32 outputs, K = thousands) run K-split over
-        # 4x the workgroups, and the LSTM kernels sum the slabs while staging their input (RBVAE_FC_SPLIT=1: one
-        # group, 32 CUs busy at 256 frames).  Needs the wavefront LSTM kernels (latent <= 32).
+        # several workgroup groups, and the LSTM kernels sum the slabs while staging their input (one group: 32 CUs busy at
+        # 256 frames).  Needs the wavefront LSTM kernels (latent <= 32).  16 groups for the large fc layers (at F3 = 56 320 /
+        # 65 536 four groups were 64 workgroups streaming 21-42 MB: 31-36 us per launch at 0.6 TB/s), else the largest of
+        # 16 / 8 / 4 that divides F3 into whole K units
         ks_unit = 32 if dtype == "bf16" else 16
-        # (16 groups for the large fc layers: at F3 = 56 320 / 65 536 four groups were 64 workgroups streaming 21-42 MB:
-        # 31-36 us per launch at 0.6 TB/s)
-        want = 16 if self.F3 >= 16384 else 4
         wave_ok = latent <= 32 and self.v.lstm_layers * _ru(4 * latent, 64) <= 1024 and not self.v.simple_order
-        self.fc_split = want if (want > 1 and wave_ok and self.F3 % (want * ks_unit) == 0 and self.F3 >= 2048) else 1
+        self.fc_split = 1
+        if wave_ok and self.F3 >= 2048:
+            for want in ((16, 8, 4) if self.F3 >= 16384 else (4,)):
+                if self.F3 % (want * ks_unit) == 0:
+                    self.fc_split = want
+                    break
         # ... and write the bf16 / padded copy of their output that the next GEMM reads (rbvae_cast_pad otherwise)
-        self.lstm_cast = wave_ok and True
+        self.lstm_cast = wave_ok
         # ... and, in forward passes that run both stacks, go as one launch with the binarisation between them
-        self.lstm_pair = wave_ok and True
-        self.bin_bwd_fused = wave_ok and True
+        self.lstm_pair = wave_ok
+        self.bin_bwd_fused = wave_ok
         self.deconv_fused = True
         self.conv_first_fused = True
         self._alloc_packed()
@@ -335,63 +320,15 @@ class Engine:
         self.wT_enc = torch.zeros(nl, 2, Ld, 4 * Ld, dtype=torch.float32, device=self.device)   # [k][gate row]
         self.wT_dec = torch.zeros(nl, 2, Ld, 4 * Ld, dtype=torch.float32, device=self.device)
 
-    def pack(self, flat: torch.Tensor, extra_rows=None):
-        """f32 parameters (reference layouts) -> the packed T copies the GEMMs read (one launch).
-        extra_rows: further job rows for the same launch (the fused trainer's batch gather, JOB_GATHER)."""
-        key = (flat.data_ptr(), tuple(map(tuple, extra_rows)) if extra_rows else None)
+    def pack(self, flat: torch.Tensor):
+        """f32 parameters (reference layouts) -> the packed T copies the GEMMs read (one launch)."""
+        key = flat.data_ptr()
         tab = self._pack_tab.get(key)
         if tab is None:
             jl = self._pack_jobs(flat)
-            if extra_rows:
-                jl.rows = [list(r) for r in extra_rows] + jl.rows       # first: its blocks start first
             tab = (jl.upload(self.device), len(jl.rows), jl)
             self._pack_tab[key] = tab
         L.call("rbvae_run_jobs", tab[0], tab[1], self._job_blocks)
-
-    def _pack_split(self, flat: torch.Tensor):
-        """pack() cut by when the copies are first read in a fused step: `first` (the first conv, current
-        stream), `early` (rest of the encoder + both LSTM stacks: beside im2col / conv1), `late` (decoder and
-        backward-only copies: beside the fc / LSTM chain, where most of the chip is idle)."""
-        key = ("split", flat.data_ptr())
-        tab = self._pack_tab.get(key)
-        if tab is None:
-            jl = self._pack_jobs(flat)
-            late_dst = {t.data_ptr() for t in (self.V1f, self.V1d, self.V2f, self.V2d, self.V3p, self.V3f, self.Wdfc,
-                                                self.WdfcT, self.bdfc, self.WfcT)}
-            parts = [JobList(), JobList(), JobList()]
-            for i, row in enumerate(jl.rows):
-                which = 0 if i == 0 else (2 if row[2] in late_dst and self.pack_late_split else 1)
-                parts[which].rows.append(row)
-            tab = tuple((p.upload(self.device), len(p.rows)) for p in parts) + (jl,)
-            self._pack_tab[key] = tab
-        return tab
-
-    def pack_group(self, flat: torch.Tensor, group: str):
-        """The packed copies of one optimiser-update group (FusedTrainer's early updates): "dec" = decoder CNN + both LSTM
-        stacks, "mid" = conv3 + encoder fc, "fin" = conv1 + conv2.  The three groups together are pack()."""
-        key = ("group", flat.data_ptr())
-        tab = self._pack_tab.get(key)
-        if tab is None:
-            jl = self._pack_jobs(flat)
-
-            def inside(ptr, t):
-                return t.data_ptr() <= ptr < t.data_ptr() + t.numel() * t.element_size()
-
-            dec = (self.V1f, self.V2f, self.V3p, self.V3f, self.Wdfc, self.WdfcT, self.bdfc, self.wT_enc, self.wT_dec)
-            mid = (self.W3f, self.Wfc, self.WfcT)
-            fin = (self.W1p, self.W2f)
-            parts = {"dec": JobList(), "mid": JobList(), "fin": JobList()}
-            for row in jl.rows:
-                g = next((n for n, ts in (("dec", dec), ("mid", mid), ("fin", fin)) if any(inside(row[2], t) for t in ts)), None)
-                if g is None:
-                    raise RuntimeError("pack job outside every update group")
-                parts[g].rows.append(row)
-            tab = {n: (p.upload(self.device), len(p.rows)) for n, p in parts.items()}
-            tab["_keep"] = jl
-            self._pack_tab[key] = tab
-        t, n = tab[group]
-        if n:
-            L.call("rbvae_run_jobs", t, n, self._job_blocks)
 
     def update_jobs(self, flat, gflat, m, v, hyper, betas, eps, gscale, extra_rows=None, part=None):
         """Optimiser step + weight repack of a training step as ONE batched job launch: every parameter tensor is a job
@@ -450,33 +387,6 @@ class Engine:
         t = torch.tensor(rows, dtype=torch.int64).to(self.device)
         self._pack_tab[key] = (t, len(rows), ctx, jl)
         return t, len(rows)
-
-    def _pack_one_launch(self) -> bool:
-        return not self._side_on(self.SIDE_PACK) and not self.pack_late_split
-
-    def pack_begin(self, flat: torch.Tensor):
-        if not self._side_on(self.SIDE_PACK) and not self.pack_late_split:
-            self.pack(flat, self.first_launch_jobs)     # nothing leaves the main stream: one launch for every copy
-            return
-        if self.first_launch_jobs:
-            raise RuntimeError("extra first-launch jobs need the one-launch repack (RBVAE_SIDE bit 1 / RBVAE_PACK_LATE off)")
-        first, early, _, _ = self._pack_split(flat)
-        self._fork(1, self.SIDE_PACK)
-        with self._on_side(1, self.SIDE_PACK):
-            L.call("rbvae_run_jobs", early[0], early[1], self._job_blocks)
-        L.call("rbvae_run_jobs", first[0], first[1], self._job_blocks)
-
-    def pack_late(self, flat: torch.Tensor):
-        late = self._pack_split(flat)[2]
-        if late[1] == 0:
-            return
-        bit = self.SIDE_PACK_LATE if (self.side_mask & self.SIDE_PACK_LATE) else self.SIDE_PACK
-        self._fork(1, bit)
-        with self._on_side(1, bit):
-            L.call("rbvae_run_jobs", late[0], late[1], self._job_blocks)
-
-    def pack_end(self):
-        self._join(1)
 
     def _pack_jobs(self, flat: torch.Tensor) -> JobList:
         lay, dt = self.layout, self.dt
@@ -657,25 +567,20 @@ class Engine:
             L.call("rbvae_wgrad3x3s2_row", self.dt, Dy, In, slabs, self.zero, nimg, oh, ow, Co, Ci, ldy, ldi, ks)
             self._wgrad_reduce(slabs, out, Co, Ci, taps, ks, dims, strides)
             return
-        nt4 = self._wg_nt4 and self.dt == BF16 and Ci % 256 == 0        # 128 x 256 tiles (wgrad_gemm.hip)
-        blocks = -(-Co // 128) * -(-Ci // (256 if nt4 else 128 if Ci > 64 else 64)) * taps
+        blocks = -(-Co // 128) * -(-Ci // (128 if Ci > 64 else 64)) * taps
         # K-slices: one round of workgroups on the 256 CUs, each with >= 256 pixels, and at most ~16 MB of f32
         # slabs to reduce afterwards
         # (self._wg_cus: the CUs this launch can count on -- beside the LSTM backward kernels, which hold one CU per
         # sequence and whose registers leave no room for a second workgroup there, a 252-workgroup grid ran in two
         # rounds: 31 -> 43 us)
         ks = max(1, min(self._wg_cus // max(blocks, 1), P // 256 if P >= 256 else 1,
-                        max(1, ((self._wg_nt4_slab if nt4 else 4) << 20) // (Co * taps * Ci))))
-        if self._ks_force and blocks >= 8:
-            ks = self._ks_force                 # RBVAE_WG_KS: experiment switch (K-slices of the multi-tile weight gradients)
+                        max(1, (4 << 20) // (Co * taps * Ci))))
         if self._ks_small and blocks >= 8 and P <= 4096:
             # the 4096-pixel layers (conv3 / first deconv at the bench shape): 3 K-slices of 22 steps instead of 7 of 9
             # -- 7 MB of slabs per weight instead of 16.5 MB; same GPU, 2 runs each: 0.4738 (7) / 0.4665 (4) /
             # 0.4659 (3) / 0.472 (2) ms per step
             ks = min(ks, self._ks_small)
-        if self._ks_narrow and blocks < 8:
-            ks = min(ks, self._ks_narrow)       # RBVAE_WG_KS_NARROW: the 64-column weight gradients (first conv, last deconv)
-        ks = max(ks, -(-P // (2048 if nt4 else 4096)))   # the kernel keeps a K-slice's gather indices in LDS
+        ks = max(ks, -(-P // 4096))   # the kernel keeps a K-slice's gather indices in LDS
         slabs = self._buf(("slabs", tag), ks * Co * taps * Ci)
         self.last_wgrad_kernel = "wgrad_gemm_k<%d>" % (2 if Ci > 64 else 1)
         L.call("rbvae_wgrad_gemm", self.dt, Dy, In, slabs, idx, self.zero, P, In.numel() // ldi, Co, Ci, ldy, ldi, taps, ks)
@@ -700,36 +605,22 @@ class Engine:
     # ---- side stream ------------------------------------------------------------------
     # The LSTM chains occupy 2B workgroups for ~25 us per stack; weight-gradient GEMMs that do not feed them are
     # issued on a side stream over exactly those windows (graph capture turns the fork/join into graph edges).
-    # Which pieces of side work actually leave the main stream is a bit mask (RBVAE_SIDE, default below): every piece
-    # was A/B'd on one GPU -- full-chip side kernels beside full-chip main kernels only contend.
-    SIDE_PACK, SIDE_PAIR, SIDE_DEC_WGRAD, SIDE_DEC_REDUCE, SIDE_LSTM_WGRAD, SIDE_BOOK, SIDE_ENC_REDUCE = 1, 2, 4, 8, 16, 32, 64
-    SIDE_PACK_LATE = 128     # decoder / backward-only weight copies repacked beside the fc / LSTM chain of the forward pass
-
-    def _side_on(self, bit: int) -> bool:
-        return self.overlap and (bit == 0 or bool(self.side_mask & bit))
-
-    def _fork(self, which: int = 0, bit: int = 0):
-        """Side stream `which` picks up after everything queued so far on the current stream."""
-        if not self._side_on(bit):
+    def _fork(self):
+        """The side stream picks up after everything queued so far on the current stream."""
+        if not self.overlap:
             return False
-        if self._sides[which] is None:
-            self._sides[which] = torch.cuda.Stream(device=self.device)
-        self._sides[which].wait_stream(torch.cuda.current_stream())
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=self.device)
+        self._side.wait_stream(torch.cuda.current_stream())
         return True
 
-    def _on_side(self, which: int = 0, bit: int = 0):
+    def _on_side(self):
         import contextlib
-        return torch.cuda.stream(self._sides[which]) if self._side_on(bit) else contextlib.nullcontext()
+        return torch.cuda.stream(self._side) if self.overlap else contextlib.nullcontext()
 
-    def _side_wait_main(self, which: int = 0, bit: int = 0):
-        if self._side_on(bit):
-            if self._sides[which] is None:
-                self._sides[which] = torch.cuda.Stream(device=self.device)
-            self._sides[which].wait_stream(torch.cuda.current_stream())
-
-    def _join(self, which: int = 0):
-        if self.overlap and self._sides[which] is not None:
-            torch.cuda.current_stream().wait_stream(self._sides[which])
+    def _join(self):
+        if self.overlap and self._side is not None:
+            torch.cuda.current_stream().wait_stream(self._side)
 
     def _run_jobs(self):
         jl, self._jobs = self._jobs, None
@@ -748,7 +639,7 @@ class Engine:
                 noise_ratio: float, train: bool, masks: Optional[Sequence[torch.Tensor]] = None,
                 seed: int = 0, need_grad: bool = True, encode_only: bool = False,
                 target: Optional[torch.Tensor] = None, recon_gscale: float = 0.0, kl_p: Optional[float] = None,
-                after_hs=None, defer_losses: bool = False, repack: bool = False,
+                after_hs=None, defer_losses: bool = False,
                 frame_map: Optional[Tuple[int, int, int, int, int]] = None, tau_dev: Optional[torch.Tensor] = None):
         """x: [S,T,C,H,W] f32 NCHW frames; U: [S*T, L] uniform noise.
         tau_dev: optional device float the kernels read the temperature from instead of `tau` (graph-replayed
@@ -759,7 +650,6 @@ class Engine:
         "kl": (parts, nparts, 1/rows)) for rbvae_combine_losses to finish.
         frame_map: (d1, d2, s0, s1, s2) -- frame n of x (and of target) starts at element
         (n // d1) * s0 + ((n % d1) // d2) * s1 + (n % d2) * s2 of the buffer x points at (rbvae_im2col_frames).
-        repack: refresh the packed weight copies from `flat` first (all but the first conv's on the side stream).
         after_hs: optional callable(h_seq) issued on the side stream as soon as the encoder LSTM is done (the
         trainer's pairwise term runs there, beside the decoder); backward() joins it.
         Returns dict(xr, hs, z, e, kl, mse, saved)."""
@@ -789,8 +679,6 @@ class Engine:
         sv.tau_dev = tau_dev
         sv.gate_scale = dscale
         # encoder CNN
-        if repack:
-            self.pack_begin(flat)
         sv.a1 = self._E(N * h1 * w1, c1)
         m, mk = dm(0)
         fm = frame_map if frame_map is not None else (0, 0, 0, 0, C * H * W)
@@ -809,8 +697,6 @@ class Engine:
             self._gemm(sv.col1, self.W1p, sv.a1, P(f"encoder_cnn.conv.{i0}.bias"), None, mk, N * h1 * w1, 1, 1, 1, 1, 1,
                        1, 1, 1, self.K1, c1, self.K1, c1, 1, "one", relu=1, drop_mode=m, drop_p=drop, scale=dscale,
                        seed=seed * 8 + 1)
-        if repack:
-            self.pack_end()
         sv.a2 = self._E(N * h2 * w2, c2)
         m, mk = dm(1)
         self._gemm(sv.a1, self.W2f, sv.a2, P(f"encoder_cnn.conv.{i1}.bias"), None, mk, N, h1, w1, h2, w2, 2, h2, w2,
@@ -818,8 +704,6 @@ class Engine:
         sv.a3 = self._E(N * h3 * w3, c3)
         self._gemm(sv.a2, self.W3f, sv.a3, P(f"encoder_cnn.conv.{i2}.bias"), None, None, N, h2, w2, h3, w3, 2, h3,
                    w3, 1, c2, c3, c2, c3, kk, "conv", relu=1 if v.simple_order else 0)
-        if repack:
-            self.pack_late(flat)
         # fc -> logits e [N][L]
         nl = v.lstm_layers
         sv.hs_enc = self._E(nl + 1, S, T, Ld, dtype=torch.float32)
@@ -865,12 +749,8 @@ class Engine:
             if kl_p is not None and not defer_losses:
                 kl = (parts.sum() * (1.0 / N)).reshape(1)
             if after_hs is not None:
-                self._fork(0, self.SIDE_PAIR)
-                if self.main_first and self._side_on(self.SIDE_PAIR):
-                    pending_hs = hs
-                else:
-                    with self._on_side(0, self.SIDE_PAIR):
-                        after_hs(hs)
+                self._fork()
+                pending_hs = hs                 # issued behind the main stream's continuation (end of forward())
         elif not v.simple_order:
             if e_parts is not None:
                 L.call("rbvae_lstm_fwd_ex", wenc, self.wT_enc, sv.hs_enc, sv.hp_enc, sv.acts_enc, sv.cs_enc, S, T, Ld,
@@ -879,12 +759,8 @@ class Engine:
                 L.call("rbvae_lstm_fwd", wenc, self.wT_enc, sv.hs_enc, sv.hp_enc, sv.acts_enc, sv.cs_enc, S, T, Ld, nl)
             hs = sv.hs_enc[nl]
             if after_hs is not None:
-                self._fork(0, self.SIDE_PAIR)
-                if self.main_first and self._side_on(self.SIDE_PAIR):
-                    pending_hs = hs
-                else:
-                    with self._on_side(0, self.SIDE_PAIR):
-                        after_hs(hs)
+                self._fork()
+                pending_hs = hs
             sv.z = sv.hs_dec[0].view(N, Ld)
             if defer_losses and kl_p is not None:
                 nkl = L.query("rbvae_binarize_kl_nparts", N, Ld)
@@ -896,8 +772,6 @@ class Engine:
                 L.call("rbvae_binarize_kl_fwd", hs, U, sv.y, sv.z, kl, N, Ld, float(tau), float(r), v.eps, int(hard),
                        float(kl_p if kl_p is not None else 0.5), 1e-8, 1, int(seed) * 8 + 5, self.seed_dev)
             if encode_only:
-                if repack:
-                    self.pack_end()
                 return {"z": sv.z.view(S, T, Ld), "hs": hs, "saved": sv}
             if self.lstm_cast:
                 sv.ds_pad = self._E(N, self.Lp)
@@ -918,8 +792,6 @@ class Engine:
         if not ((self.lstm_cast or fused_pair) and not v.simple_order):
             sv.ds_pad = self._E(N, self.Lp)
             L.call("rbvae_cast_pad", self.dt, ds, sv.ds_pad, N, Ld, self.Lp)
-        if repack:
-            self.pack_end()
         sv.f = self._E(N * h3 * w3, c3)
         self._gemm(sv.ds_pad, self.Wdfc, sv.f, self.bdfc, None, None, N, 1, 1, 1, 1, 1, 1, 1, 1, self.Lp, self.F3,
                    self.Lp, self.F3, 1, "one")
@@ -980,15 +852,14 @@ class Engine:
                 L.call("rbvae_col2im_sigmoid", self.dt, Y, self.NY, P(f"decoder_cnn.deconv.{i2}.bias"), N, h1, w1, H, W,
                        self.out_ch, k, k, 1, sv.xr, None, None, None, None, 0.0, None)
         if pending_hs is not None:
-            with self._on_side(0, self.SIDE_PAIR):
+            with self._on_side():
                 after_hs(pending_hs)
         return {"xr": sv.xr, "hs": hs, "z": sv.z.view(S, T, Ld), "e": sv.e, "kl": kl, "mse": mse, "sse": sse, "saved": sv}
 
     # ---- backward --------------------------------------------------------------
     def backward(self, flat: torch.Tensor, gflat: torch.Tensor, sv: Saved, g_xr: Optional[torch.Tensor],
                  g_hs: Optional[torch.Tensor], g_z: Optional[torch.Tensor], g_e: Optional[torch.Tensor] = None,
-                 kl_weight: float = 0.0, kl_p: float = 0.5, g_hs_inplace: bool = False, side_first=None, cut=None,
-                 updates=None):
+                 kl_weight: float = 0.0, kl_p: float = 0.5, g_hs_inplace: bool = False, side_first=None, cut=None):
         """Writes every parameter gradient into gflat (same layout as flat).
         g_xr: [S,T,C,H,W] upstream gradient of x_recon (None: use the fused dpre3 of forward()).
         g_hs / g_z: [S,T,L] upstream gradients of h_seq / z_seq (None = 0).
@@ -1000,21 +871,12 @@ class Engine:
         cut: optional callable invoked once, on the main stream with every side stream joined, at the point where the
         gradients of decoder_cnn.* and both LSTM stacks (the contiguous tail of gflat from
         layout.offsets["decoder_cnn.fc.weight"]) are final and only the encoder CNN's remain to be computed: the
-        data-parallel trainer ends one graph and starts the next there and all-reduces that tail beside the rest.
-        updates: optional {"dec", "mid", "fin"} callables (single-GPU trainer: optimiser update + weight repack of one
-        parameter group each).  "dec" (decoder CNN + both LSTM stacks) and "mid" (conv2, conv3, encoder fc) are issued on
-        the side stream as soon as that group's gradients are final -- behind the decoder's early reduction, resp.
-        behind conv2's weight gradient with the group's own reduction in front -- so they run beside the remaining
-        data-gradient / weight-gradient GEMMs of the main stream; "fin" (conv1; conv2's repack, whose transposed copy the
-        last data-gradient GEMM still reads) follows the final reduction.  Without a side stream all three run at the
-        end.  Safe because nothing of this pass reads a group's weights once its gradients are final."""
+        data-parallel trainer ends one graph and starts the next there and all-reduces that tail beside the rest."""
         self._join()                       # side-stream work of forward() (after_hs)
-        book_with_decoder = (side_first is not None and self.book_with_dec and self._side_on(self.SIDE_DEC_WGRAD)
-                             and not self._side_on(self.SIDE_BOOK))
+        # the loss bookkeeping rides the side stream's fork for the decoder's weight gradients (no edge of its own)
+        book_with_decoder = side_first is not None and self.overlap
         if side_first is not None and not book_with_decoder:
-            self._fork(0, self.SIDE_BOOK)
-            with self._on_side(0, self.SIDE_BOOK):
-                side_first()
+            side_first()
         v = self.v
         N, S, T = sv.N, sv.S, sv.T
         H, W = sv.hw
@@ -1069,7 +931,7 @@ class Engine:
 
         # ... then its weight / bias gradients, beside the LSTM chain when overlap is on
         def decoder_wgrads():
-            if self._side_on(self.SIDE_DEC_WGRAD) and self.side_wg_cap:
+            if self.overlap:
                 self._wg_cus = max(64, 256 - min(S, 128))     # the LSTM backward kernels run beside these: S workgroups
             try:
                 decoder_wgrads_()
@@ -1108,23 +970,20 @@ class Engine:
         # The gather-index tables both streams' weight-gradient GEMMs read: complete before they enter the cache
         # (_conv_idx), built here on the main stream before the fork
         self.prepare(N)
-        self._fork(0, self.SIDE_DEC_WGRAD)
-        early_upd = (updates is not None and cut is None and self.main_first and self._side_on(self.SIDE_DEC_WGRAD))
-        # with a cut (or early updates) the reductions queued so far (decoder bias sums: their producers ran before the
-        # fork) go with the decoder's early reduction, so that every decoder gradient is final at the cut
+        self._fork()
+        # with a cut the reductions queued so far (decoder bias sums: their producers ran before the fork) go with the
+        # decoder's early reduction, so that every decoder gradient is final at the cut
         fork_jobs = None
-        if cut is not None or early_upd:
+        if cut is not None:
             fork_jobs, self._jobs = self._jobs, JobList()
-        mid_jobs = None
-        ev_lstm = ev_mid = None
         side_tail = []                # (event, callable): issued on the side stream behind the decoder's weight gradients
 
         def issue_decoder_side():
-            early = (self._side_on(self.SIDE_DEC_WGRAD) and self._side_on(self.SIDE_DEC_REDUCE)) or cut is not None or early_upd
-            main_jobs, self._jobs = self._jobs, (fork_jobs if (cut is not None or early_upd) else JobList())
-            with self._on_side(0, self.SIDE_DEC_WGRAD):
+            early = self.overlap or cut is not None
+            main_jobs, self._jobs = self._jobs, (fork_jobs if cut is not None else JobList())
+            with self._on_side():
                 if book_with_decoder:
-                    side_first()        # the loss bookkeeping rides the side stream's existing fork: no edge of its own
+                    side_first()
                 decoder_wgrads()
                 if early:
                     # the decoder's slab / partial-sum reductions right behind them, not at the end of the pass
@@ -1136,20 +995,13 @@ class Engine:
                 # reduction jobs join the final reduction
                 self._jobs = main_jobs
                 for ev, fn in side_tail:
-                    self._sides[0].wait_event(ev)
+                    self._side.wait_event(ev)
                     fn()
                 main_jobs = self._jobs
-                if early_upd:
-                    side = self._sides[0]
-                    side.wait_event(ev_lstm)            # the LSTM stacks' weight gradients (main stream)
-                    updates["dec"]()
-                    side.wait_event(ev_mid)             # conv2's weight gradient: the last producer of the mid group
-                    self._jobs = mid_jobs
-                    self._run_jobs()
-                    updates["mid"]()
             self._jobs = main_jobs
 
-        defer_side = self.main_first and self._side_on(self.SIDE_DEC_WGRAD)
+        # the main stream's continuation is issued BEFORE the side work (see __init__)
+        defer_side = self.overlap
         if not defer_side:
             issue_decoder_side()
         if self.fc_split > 1:
@@ -1227,49 +1079,34 @@ class Engine:
                 de = de + g_e.reshape(N, Ld)
         # Side-stream tail (behind the decoder's weight gradients, each piece behind an event on its inputs): launches
         # of the main chain's products that nothing on the chain waits for
-        tail_ok = defer_side and cut is None and not early_upd
+        tail_ok = defer_side and cut is None
 
         def lstm_wgrads():
             L.call("rbvae_lstm_wgrad_pair", dG, sv.hs_dec, sv.hp_dec, G("decoder_rnn.lstm.weight_ih_l0"),
                    dGe, sv.hs_enc, sv.hp_enc, G("encoder_rnn.lstm.weight_ih_l0"), S, T, Ld, nl, 0)
 
-        lstm_on_tail = tail_ok and self.lstm_wgrad_tail and not self._side_on(self.SIDE_LSTM_WGRAD)
-        if lstm_on_tail:
+        if tail_ok:
             ev_bptt = torch.cuda.Event()
             ev_bptt.record(torch.cuda.current_stream())
             side_tail.append((ev_bptt, lstm_wgrads))
-        # (RBVAE_SIDE bit 16: the older form -- the side stream waits for the whole main stream at this point)
-        self._side_wait_main(0, self.SIDE_LSTM_WGRAD)
-        with self._on_side(0, self.SIDE_LSTM_WGRAD):
-            if not lstm_on_tail:
-                lstm_wgrads()
-            if de_sums is not None and g_e is None:
-                self._jobs.add(JOB_ROWS, de_sums, G("encoder_cnn.fc.bias"), (1, 1, Ld), (0, 0, 1), nslab=S, slab=Ld)
-            else:
-                self._colsum(F32, de, N, Ld, Ld, G("encoder_cnn.fc.bias"), tag=(N, "bfc"))
-            if early_upd:
-                ev_lstm = torch.cuda.Event()
-                ev_lstm.record(torch.cuda.current_stream())
+        else:
+            lstm_wgrads()
+        if de_sums is not None and g_e is None:
+            self._jobs.add(JOB_ROWS, de_sums, G("encoder_cnn.fc.bias"), (1, 1, Ld), (0, 0, 1), nslab=S, slab=Ld)
+        else:
+            self._colsum(F32, de, N, Ld, Ld, G("encoder_cnn.fc.bias"), tag=(N, "bfc"))
         # --- encoder fc
         if de_pad is None:
             de_pad = tmp("de_pad", N, self.Lp)
             L.call("rbvae_cast_pad", self.dt, de, de_pad, N, Ld, self.Lp)
         def wfc_wgrad():
-            if self.Lp <= 64 and self.wfc_swap:
-                # roles swapped: rows = the F3 flatten positions (full 128-row tiles), columns = the <= 64 padded logits
-                # (the 64-column instance) -- as [Lp rows] x [F3 columns] half of every 128 x 128 tile was padding.
-                # Slab element (f, l) -> torch (l, c, g) with f = g * c3 + c (NHWC-flat position)
-                self._wgrad(sv.a3, de_pad, None, N, self.F3, self.Lp, self.F3, self.Lp, 1, G("encoder_cnn.fc.weight"),
-                            (Ld, c3, g3), (1, self.Lp, c3 * self.Lp), tag=(N, "Wfc"))
-            else:
-                self._wgrad(de_pad, sv.a3, None, N, self.Lp, self.F3, self.Lp, self.F3, 1, G("encoder_cnn.fc.weight"),
-                            (Ld, c3, g3), (self.F3, 1, c3), tag=(N, "Wfc"))
+            self._wgrad(de_pad, sv.a3, None, N, self.Lp, self.F3, self.Lp, self.F3, 1, G("encoder_cnn.fc.weight"),
+                        (Ld, c3, g3), (self.F3, 1, c3), tag=(N, "Wfc"))
 
         # The encoder fc's weight gradient is a 32-workgroup launch nothing on the data-gradient chain waits for: with
         # the deferred side work it rides the side stream (behind an event on de_pad), so the main chain goes
         # straight on to the next data-gradient GEMM instead of queueing it behind a full chip (18 us in the step)
-        wfc_on_side = tail_ok and self.wfc_side
-        if wfc_on_side:
+        if tail_ok:
             ev_de = torch.cuda.Event()
             ev_de.record(torch.cuda.current_stream())
             side_tail.append((ev_de, wfc_wgrad))
@@ -1283,20 +1120,12 @@ class Engine:
         self._gemm(de_pad, self.WfcT, da3, None, sv.a3 if v.simple_order else None, None, N, 1, 1, 1, 1, 1, 1, 1, 1,
                    self.Lp, self.F3, self.Lp, self.F3, 1, "one", colsum_ws=ws3)
         self._jobs.add(JOB_ROWS, ws3, G(f"encoder_cnn.conv.{i2}.bias"), (1, 1, c3), (0, 0, 1), nslab=mt * g3, slab=c3)
-        def on_tail(bit, fn):
-            """Encoder weight gradient `bit` of RBVAE_TAIL_WGRADS: on the side stream's tail behind an event on its
-            inputs (the data-gradient chain then runs ahead), else here on the main stream."""
-            if tail_ok and (self.tail_wgrads & bit):
-                ev = torch.cuda.Event()
-                ev.record(torch.cuda.current_stream())
-                side_tail.append((ev, fn))
-            else:
-                fn()
-
         # --- conv3
         idx3, idx2 = self._conv_idx(N, h2, w2, h3, w3), self._conv_idx(N, h1, w1, h2, w2)
-        on_tail(1, lambda: self._wgrad(da3, sv.a2, idx3, P3, c3, c2, c3, c2, kk, G(f"encoder_cnn.conv.{i2}.weight"),
-                                       (c3, c2, kk), (kk * c2, 1, c2), tag=(N, "W3"), geom=(N, h3, w3, h2, w2)))
+        # (the encoder's full-chip weight gradients stay on the main stream: on the side stream's tail they only contend
+        # with the data-gradient GEMMs, 0.458 -> 0.476 / 0.487 ms per step in round 2)
+        self._wgrad(da3, sv.a2, idx3, P3, c3, c2, c3, c2, kk, G(f"encoder_cnn.conv.{i2}.weight"),
+                    (c3, c2, kk), (kk * c2, 1, c2), tag=(N, "W3"), geom=(N, h3, w3, h2, w2))
         da2 = tmp("da2", P2, c2)
         self._gemm(da3, self.W3d, da2, None, sv.a2, None, N, h3, w3, h3, w3, 1, h2, w2, 2, c3, c2, c3, c2, kk, "dgrad",
                    scale=gs, bias_grad=G(f"encoder_cnn.conv.{i1}.bias"), tag=(N, "da2"))
@@ -1310,54 +1139,21 @@ class Engine:
             self._join()
             cut()
         # --- conv2
-        on_tail(2, lambda: self._wgrad(da2, sv.a1, idx2, P2, c2, c1, c2, c1, kk, G(f"encoder_cnn.conv.{i1}.weight"),
-                                       (c2, c1, kk), (kk * c1, 1, c1), tag=(N, "W2"), geom=(N, h2, w2, h1, w1)))
-        if early_upd:
-            # the mid group (conv2, conv3, encoder fc) is complete: its reduction, optimiser update and repack go to the
-            # side stream (issued with the deferred side work below); only conv1's pieces remain for the end
-            ev_mid = torch.cuda.Event()
-            ev_mid.record(torch.cuda.current_stream())
-            mid_jobs, self._jobs = self._jobs, JobList()
-        elif tail_ok and self.mid_reduce:
-            # RBVAE_MID_REDUCE=1: everything reducible so far (conv3 / conv2 slabs, bias sums) is reduced on the side
-            # stream's tail, beside the last data-gradient GEMM; the final launch keeps conv1's and the fc's pieces
-            ev_m = torch.cuda.Event()
-            ev_m.record(torch.cuda.current_stream())
-            mid_only, self._jobs = self._jobs, JobList()
-
-            def run_mid():
-                saved, self._jobs = self._jobs, mid_only
-                self._run_jobs()
-                self._jobs = saved
-            side_tail.append((ev_m, run_mid))
-        elif self._side_on(self.SIDE_ENC_REDUCE):
-            # everything reducible so far (fc, conv3, conv2 slabs; the LSTM-side column sums) goes to the side stream
-            # now, beside the last data-gradient GEMM and conv1's weight gradient; only those two's reductions
-            # remain for the end of the pass
-            self._fork(0, self.SIDE_ENC_REDUCE)
-            with self._on_side(0, self.SIDE_ENC_REDUCE):
-                self._run_jobs()
-            self._jobs = JobList()
+        self._wgrad(da2, sv.a1, idx2, P2, c2, c1, c2, c1, kk, G(f"encoder_cnn.conv.{i1}.weight"),
+                    (c2, c1, kk), (kk * c1, 1, c1), tag=(N, "W2"), geom=(N, h2, w2, h1, w1))
         da1 = tmp("da1", P1, c1)
         self._gemm(da2, self.W2d, da1, None, sv.a1, None, N, h2, w2, h2, w2, 1, h1, w1, 2, c2, c1, c2, c1, kk, "dgrad",
                    scale=gs, bias_grad=G(f"encoder_cnn.conv.{i0}.bias"), tag=(N, "da1"))
         # --- conv1 (1-tap GEMM over the saved im2col columns)
         if sv.col1 is None:
             wf1 = self._wf_ksplit(N, self.in_ch, H, W, c1)
-            on_tail(4, lambda: self._wgrad_first(0, sv.x_in, sv.fm_in, da1, N, self.in_ch, H, W, c1, c1, wf1,
-                                                 G(f"encoder_cnn.conv.{i0}.weight"), (c1, self.in_ch, kk),
-                                                 (self.K1, 1, self.in_ch), tag=(N, "W1")))
+            self._wgrad_first(0, sv.x_in, sv.fm_in, da1, N, self.in_ch, H, W, c1, c1, wf1, G(f"encoder_cnn.conv.{i0}.weight"),
+                              (c1, self.in_ch, kk), (self.K1, 1, self.in_ch), tag=(N, "W1"))
         else:
-            on_tail(4, lambda: self._wgrad(da1, sv.col1, None, P1, c1, self.K1, c1, self.K1, 1,
-                                           G(f"encoder_cnn.conv.{i0}.weight"), (c1, self.in_ch, kk),
-                                           (self.K1, 1, self.in_ch), tag=(N, "W1")))
+            self._wgrad(da1, sv.col1, None, P1, c1, self.K1, c1, self.K1, 1, G(f"encoder_cnn.conv.{i0}.weight"),
+                        (c1, self.in_ch, kk), (self.K1, 1, self.in_ch), tag=(N, "W1"))
         if defer_side:
             issue_decoder_side()
         # every slab / partial-sum reduction of this pass in one launch, once the side stream has caught up
         self._join()
         self._run_jobs()
-        if updates is not None:
-            if not early_upd:
-                updates["dec"]()
-                updates["mid"]()
-            updates["fin"]()

@@ -328,10 +328,23 @@ class LDMEncoder(nn.Module):
         m = self._moments(x)
         return m.clone() if self.use_graph else m      # a replayed graph writes the same rows at the next call
 
+    def _weights_version(self) -> int:
+        """sum of the frozen buffers' in-place version counters: an in-place weight change (p.data.copy_, a foreign
+        optimiser step) moves it, and the packed copies + captured graphs (which hold their addresses) are rebuilt"""
+        return sum(self._p(n)._version for n in self._names)
+
+    def _check_weights(self):
+        ver = self._weights_version()
+        if getattr(self, "_packed_ver", None) != ver:
+            if self._packed is not None:
+                self._drop_packed()
+            self._packed_ver = ver
+
     def _moments(self, x: torch.Tensor) -> torch.Tensor:
         """moments through the captured graph of this input shape (first call of a shape: eager, which also fills the
         packed weights; second call: capture; then replays).  The rows returned belong to the graph: consume them on
         the current stream before the next call of the same shape."""
+        self._check_weights()
         if (not self.use_graph or not x.is_cuda or x.dim() != 4 or x.shape[1] != self.cfg["in_channels"]
                 or x.shape[2] % 8 or x.shape[3] % 8 or torch.cuda.is_current_stream_capturing()):
             return self._moments_eager(x)
@@ -361,6 +374,7 @@ class LDMEncoder(nn.Module):
         N, C, H, W = x.shape
         if H % 8 or W % 8:
             raise ValueError("frame sides must be divisible by 8")
+        self._check_weights()
         if self._packed is None or self._packed[0] != x.device:
             self._pack(x.device)
         dev, dt, tdt, ke, pk = self._packed

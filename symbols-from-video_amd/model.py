@@ -79,6 +79,9 @@ class _ForwardFn(torch.autograd.Function):
                           seed=model._next_seed(), need_grad=need)
         ctx.model, ctx.eng, ctx.sv = model, eng, out["saved"]
         ctx.simple = eng.v.simple_order
+        # Where the first conv's weight gradient is rebuilt from the frames themselves (rbvae_wgrad_first: no im2col rows in
+        # HBM), backward re-reads x: an in-place write to x in between must fail like it does in stock torch
+        ctx.x_ref, ctx.x_ver = (x, x._version) if (need and out["saved"].col1 is None) else (None, None)
         if ctx.simple:
             return out["xr"], out["e"].view(x.shape[0] * x.shape[1], -1)
         return out["xr"], out["hs"], out["z"]
@@ -88,6 +91,10 @@ class _ForwardFn(torch.autograd.Function):
         model, eng, sv = ctx.model, ctx.eng, ctx.sv
         if sv.acts_enc is None:
             raise RuntimeError("backward through a forward that ran without gradient tracking")
+        if ctx.x_ref is not None and ctx.x_ref._version != ctx.x_ver:
+            raise RuntimeError("one of the variables needed for gradient computation has been modified by an inplace operation: "
+                               f"the input frames are at version {ctx.x_ref._version}; expected version {ctx.x_ver} instead "
+                               "(the first convolution's weight gradient re-reads them)")
         gflat = model._gflat_ws()
         if g_xr is None:
             g_xr = torch.zeros_like(sv.xr)

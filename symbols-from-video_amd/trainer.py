@@ -92,6 +92,8 @@ class FusedTrainer:
         self.eng = None
         self.instrument = None       # optional callable(name, flops) -> context manager (bench roofline leg)
         import os
+        # single GPU: the whole step is ONE graph.  False (tools/rccl_single.py only): the multi-graph schedules of the
+        # data-parallel trainer rehearsed on one rank
         self.one_graph = True
         # world > 1: the backward pass is cut where the decoder CNN's and the LSTM stacks' gradients are final (the
         # contiguous tail of the flat buffer, 51 % of it at the headline config); that tail is all-reduced on the
@@ -106,28 +108,15 @@ class FusedTrainer:
         # are captured INTO the step's single graph on a communication stream -- no graph boundary at the cut, no
         # host-side choreography between replays
         self.ddp_ingraph = os.environ.get("RBVAE_DDP_INGRAPH", "0") == "1"
-        self.fused_pair = True
-        # RBVAE_EARLY_UPDATE=1 (single GPU, experiment, off): the optimiser update and the weight repack run per parameter
-        # group as soon as the group's gradients are final, on the side stream beside the rest of the backward pass
-        # (engine.backward(updates=...)), instead of reduce -> Adam -> (next step) repack in series at the step boundary.
-        # Measured on one GPU (tools/sweep_env.sh, same box): 0.475 vs 0.470 ms/step -- the byte-moving kernels and the
-        # GEMMs beside them share the memory system, each slows the other by what the overlap would have saved
-        # (last data-gradient GEMM 32 -> 50 us, Adam on half the buffer 15.5 us instead of 6.5): default = the plain order.
-        self.early_update = self.world == 1 and False
         self._packed_ver = None
         self._red = None
-        # RBVAE_PREFETCH_DATA=1: gather the NEXT step's batch on the side stream during the backward pass instead of at
-        # the start of the step.  Measured (same box, 2 x 2 runs): 0.4542 vs 0.4508 ms/step -- the 5.6 us gather already
-        # hides in the gap between two graph launches -- so it is off.
-        self.prefetch_data = False
-        # The optimiser step AND the weight repack as ONE batched job launch (engine.update_jobs): every parameter tensor's
-        # job applies Adam to its slice of the flat buffers and writes the packed copies from the new values while it
-        # holds them; in set_data mode the same launch gathers the next step's batch.  The step then opens directly with
-        # the first convolution: no repack launch, no gather launch, no separate Adam launch.
-        # RBVAE_FUSED_UPDATE=0: rbvae_adam_step at the end, repack (+ gather) job launch at the start of the next step.
-        self.fused_update = True and not self.early_update
+        # The step's boundary is ONE batched job launch (engine.update_jobs): every parameter tensor's job applies Adam to
+        # its slice of the flat buffers and writes the packed copies from the new values while it holds them; in set_data
+        # mode the same launch gathers the NEXT step's batch.  The step then opens directly with the first convolution: no
+        # repack launch, no gather launch, no separate Adam launch.  (Measured in round 2 and not kept: per-group updates on
+        # the side stream beside the backward GEMMs 0.475 vs 0.470 ms/step; the next batch gathered on the side stream
+        # during the backward pass 0.4542 vs 0.4508.)
         self._primed = False          # set_data mode: the input buffer holds the batch of the coming step
-        self.gather_in_pack = True
 
     # ---- the two halves of a step (plain launches; captured below) ------------------
     def _fwd_bwd(self, x, U, tau, B, T, cut=None, masks=None):
@@ -137,7 +126,7 @@ class FusedTrainer:
         g_hs = torch.empty(2 * B, T, Ld, device=self.dev)
         pair = self._pair
 
-        fused_pair = self.fused_pair and self.pair_loss != "triplet"
+        fused_pair = self.pair_loss != "triplet"    # the contrast term: value + gradient in one many-workgroup launch
         pair_parts = torch.empty(2 * L.query("rbvae_contrast_term_nparts", B, T), device=self.dev) if fused_pair else None
 
         def pair_term(hs):                   # [2B, T, L]
@@ -146,37 +135,18 @@ class FusedTrainer:
                 L.call("rbvae_triplet_term_fwd", h0, h1, B, T, Ld, float(self.margin), pair)
                 L.call("rbvae_triplet_term_bwd", h0, h1, B, T, Ld, float(self.margin), float(self.alpha), None,
                        g_hs[:B], g_hs[B:])
-            elif fused_pair:
+            else:
                 # value (as per-block sums for the bookkeeping kernel) and gradient in one many-workgroup launch
                 L.call("rbvae_contrast_term_fused", h0, h1, B, T, Ld, float(self.alpha), None, pair_parts, g_hs[:B],
                        g_hs[B:])
-            else:
-                L.call("rbvae_contrast_term_fwd", h0, h1, B, T, Ld, pair)
-                L.call("rbvae_contrast_term_bwd", h0, h1, B, T, Ld, float(self.alpha), None, g_hs[:B], g_hs[B:])
 
-        data_mode = self._data is not None and self._data_active
-
-        def gather_batch():
-            # batch (device step counter % n_batches) of the plan, gathered from the HBM-resident table
-            table, plan, _, _ = self._data
-            L.call("rbvae_gather_frames", table, table.shape[0], plan, plan.shape[1], plan.shape[0], self.step_dev,
-                   table[0].numel(), x)
-
-        eng.first_launch_jobs = None
-        if data_mode and not self._gather_ahead():
-            if self.gather_in_pack and not self.early_update and eng._pack_one_launch():
-                # the gather rides the launch of the weight repack that opens the step (one launch less on the chain)
-                table, plan, _, _ = self._data
-                from .engine import JOB_GATHER
-                eng.first_launch_jobs = [self._gather_row(x)]
-            else:
-                gather_batch()
+        # (set_data mode: this step's batch was gathered by the previous step's update launch, or by step()'s priming)
         # dropout follows the module's mode like the reference (model.train() in train_one_epoch, :501)
         # x is the item batch [B, 2, T, C, H, W] as it is; frame (v, b, t) = sequence v*B + b, state t
         chw = numel // (2 * B * T)
         out = eng.forward(model._flat, x.view(2 * B, T, *x.shape[3:]), U, tau, False, self.r, bool(model.training), masks,
                           seed=self._noise_key, need_grad=True, target=x, recon_gscale=2.0 / numel, kl_p=self.p,
-                          after_hs=pair_term, defer_losses=True, repack=not (self.early_update or self.fused_update),
+                          after_hs=pair_term, defer_losses=True,
                           frame_map=(B * T, T, T * chw, 2 * T * chw, chw), tau_dev=self.tau_dev)
         sse_ws, nparts, inv_n = out["sse"]
         kl_parts, nkl, kl_scale = out["kl"]
@@ -193,35 +163,9 @@ class FusedTrainer:
             L.call("rbvae_combine_losses", sse_ws, nparts, inv_n, None, kl_parts, nkl, kl_scale, *pargs,
                    float(self.beta_kl), float(self.alpha), self.losses, self.step_dev, float(self.lr), self.lr_dev,
                    float(b1), float(b2), self.hyper)
-            if data_mode and self.prefetch_data and not self.fused_update:
-                # the NEXT step's batch (the counter has just advanced): the forward pass is done with the input buffer,
-                # so the gather rides the side stream beside the backward pass instead of opening the next step
-                gather_batch()
 
         eng.backward(model._flat, self.gflat, out["saved"], None, g_hs, None, kl_weight=self.beta_kl, kl_p=self.p,
-                     g_hs_inplace=True, side_first=bookkeeping, cut=cut,
-                     updates=self._group_updates() if self.early_update else None)
-
-    def _group_updates(self):
-        """{"dec", "mid", "fin"}: Adam on one contiguous range of the flat buffer + the repack of that range's weights."""
-        eng, flat = self.eng, self.model._flat
-        lay = eng.layout
-        i0, i1, i2 = lay.conv_idx
-        o_c2, o_dec, n = lay.offsets[f"encoder_cnn.conv.{i1}.weight"], lay.offsets["decoder_cnn.fc.weight"], flat.numel()
-        b1, b2 = self.betas
-
-        def upd(lo, hi, group):
-            def run():
-                L.call("rbvae_adam_step", flat[lo:], self.gflat[lo:], self.m[lo:], self.vv[lo:], hi - lo, float(self.lr),
-                       float(b1), float(b2), float(self.eps), 0, 1.0 / self.world, None, self.hyper)
-                eng.pack_group(flat, group)
-            return run
-
-        return {"dec": upd(o_dec, n, "dec"), "mid": upd(o_c2, o_dec, "mid"), "fin": upd(0, o_c2, "fin")}
-
-    def _gather_ahead(self) -> bool:
-        """set_data mode: is the batch of a step gathered by its predecessor (so that the first step must be primed)?"""
-        return self.prefetch_data or self.fused_update
+                     g_hs_inplace=True, side_first=bookkeeping, cut=cut)
 
     def _gather_row(self, x):
         table, plan, _, _ = self._data
@@ -230,22 +174,15 @@ class FusedTrainer:
                 plan.data_ptr(), self.step_dev.data_ptr(), table.shape[0], 1, 0, 0, 0, 0, 0, 0]
 
     def _update(self, part=None):
-        """part: None, or "tail" / "head" (fused update only): one gradient bucket's parameters."""
-        if self.early_update:
-            return                    # done group by group inside the backward pass
-        if self.fused_update:
-            extra = None
-            if self._data is not None and self._data_active and part != "tail":
-                B, T = self._data[2], self._data[3]
-                extra = [self._gather_row(self._static[(B, T)]["x"])]      # the next step's batch (the counter has advanced)
-            tab, n = self.eng.update_jobs(self.model._flat, self.gflat, self.m, self.vv, self.hyper, self.betas, self.eps,
-                                          1.0 / self.world, extra, part)
-            L.call("rbvae_run_jobs", tab, n, self.eng._job_blocks)
-            return
-        b1, b2 = self.betas
-        L.call("rbvae_adam_step", self.model._flat, self.gflat, self.m, self.vv, self.gflat.numel(), float(self.lr),
-               float(b1), float(b2), float(self.eps), 0, 1.0 / self.world, None, self.hyper)
-        # the packed bf16 copies are refreshed at the start of the next step (beside its first kernels)
+        """Adam + weight repack (+ the next batch's gather in set_data mode) as one job launch.
+        part: None, or "tail" / "head": one gradient bucket's parameters (data-parallel split update)."""
+        extra = None
+        if self._data is not None and self._data_active and part != "tail":
+            B, T = self._data[2], self._data[3]
+            extra = [self._gather_row(self._static[(B, T)]["x"])]      # the next step's batch (the counter has advanced)
+        tab, n = self.eng.update_jobs(self.model._flat, self.gflat, self.m, self.vv, self.hyper, self.betas, self.eps,
+                                      1.0 / self.world, extra, part)
+        L.call("rbvae_run_jobs", tab, n, self.eng._job_blocks)
 
     # ---- public --------------------------------------------------------------------
     def step(self, item: Optional[torch.Tensor], temperature: float, U: Optional[torch.Tensor] = None,
@@ -275,13 +212,12 @@ class FusedTrainer:
             self.eng.seed_dev = self.step_dev
         Ld = model.latent_dim
         self._data_active = from_data
-        if self.early_update or self.fused_update:
-            # the step leaves every packed weight copy current; repack here only when the weights changed behind the
-            # trainer's back (first step, load_state_dict, a foreign optimiser)
-            ver = tuple(p._version for p in model._params())
-            if self._packed_ver != ver or model._packed_version != (id(self.eng), ver):
-                self.eng.pack(model._flat)
-                self._packed_ver = ver
+        # the step leaves every packed weight copy current; repack here only when the weights changed behind the
+        # trainer's back (first step, load_state_dict, a foreign optimiser)
+        ver = tuple(p._version for p in model._params())
+        if self._packed_ver != ver or model._packed_version != (id(self.eng), ver):
+            self.eng.pack(model._flat)
+            self._packed_ver = ver
         if U is None and not self.device_noise:
             U = torch.rand((2, B * T, Ld)).to(item.device)
         # temperature / lr travel through device scalars: they are NOT part of the graph key
@@ -310,13 +246,13 @@ class FusedTrainer:
                 graph = self._capture(st["x"], Uarg, float(temperature), B, T)
                 self._graphs[key] = graph
                 self._primed = False      # the capture's warm-up steps gathered ahead and were rolled back
-        if from_data and self._gather_ahead() and not self._primed:
+        if from_data and not self._primed:
             # first step of a plan (or after anything else used the buffer): gather this step's batch now; from here on
             # every step gathers its successor's
             table, plan, _, _ = self._data
             L.call("rbvae_gather_frames", table, table.shape[0], plan, plan.shape[1], plan.shape[0], self.step_dev,
                    table[0].numel(), st["x"])
-        self._primed = from_data and self._gather_ahead()
+        self._primed = from_data
         if graph is None:
             self._fwd_bwd(st["x"], Uarg, float(temperature), B, T, masks=masks)
             self._allreduce()
@@ -346,10 +282,7 @@ class FusedTrainer:
                 self._allreduce()
                 g[1].replay()
         self.steps += 1
-        if self.early_update or self.fused_update:
-            self.model._packed_version = (id(self.eng), self._packed_ver)      # the packed copies are current
-        else:
-            self.model._packed_version = None  # anything else that runs the model before the next step repacks first
+        self.model._packed_version = (id(self.eng), self._packed_ver)      # the packed copies are current
         return self.losses
 
     def validate(self, item: torch.Tensor, temperature: float, U: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -512,7 +445,7 @@ class FusedTrainer:
         with torch.cuda.stream(s):
             for _ in range(2):
                 self._fwd_bwd(x, U, tau, B, T, cut=(lambda: None) if (self.world > 1 and self.ddp_overlap) else None)
-                if self.world > 1 and self.ddp_overlap and self.fused_update and self.ddp_split_update:
+                if self.world > 1 and self.ddp_overlap and self.ddp_split_update:
                     self._update("tail")          # (the warm-up also builds the job tables the capture replays)
                     self._update("head")
                 else:
@@ -523,7 +456,7 @@ class FusedTrainer:
         if self._pool is None:
             self._pool = torch.cuda.graph_pool_handle()
         pool = self._pool
-        if self.world == 1 and (self.one_graph or self.early_update):
+        if self.world == 1 and self.one_graph:
             # no collective between backward and Adam: the whole step is one graph launch
             with torch.cuda.graph(g1, pool=pool):
                 self._fwd_bwd(x, U, tau, B, T)
@@ -551,7 +484,7 @@ class FusedTrainer:
                 comm.wait_stream(torch.cuda.current_stream())
                 with torch.cuda.stream(comm):
                     red.reduce_head()
-                if self.fused_update and self.ddp_split_update:
+                if self.ddp_split_update:
                     torch.cuda.current_stream().wait_event(ev_tail)
                     self._update("tail")
                     torch.cuda.current_stream().wait_stream(comm)
@@ -578,7 +511,7 @@ class FusedTrainer:
                 g2.capture_end()
                 g3.capture_begin(pool=pool)
                 g4 = None
-                if self.fused_update and self.ddp_split_update:
+                if self.ddp_split_update:
                     # the update in the two gradient buckets: the tail's runs while the head is still being all-reduced
                     self._update("tail")
                     g3.capture_end()

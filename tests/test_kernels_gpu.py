@@ -189,19 +189,6 @@ def test_conv_wgrad(sfv, dtype, k, C, Co, N, H, W, ks):
     assert rel(out.cpu().reshape(Co, C, k, k), w.grad) < tol
 
 
-def test_conv_wgrad_wide_tile_variant():
-    """The 128 x 256 weight-gradient tile (RBVAE_WG_NT4=1, read once per process: hence the child process) gives the
-    same gradients; it is off by default because its doubled K-slice slabs cost the step more than the tile saves
-    (DESIGN.md section 5)."""
-    import os, subprocess, sys
-    env = dict(os.environ, RBVAE_WG_NT4="1")
-    here = os.path.dirname(os.path.abspath(__file__))
-    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_kernels_gpu.py"), "-q", "-m", "gpu", "-k",
-                        "test_conv_wgrad and bf16 and 256", "-p", "no:cacheprovider"], env=env, capture_output=True,
-                       text=True, timeout=600)
-    assert r.returncode == 0 and "1 passed" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
-
-
 def test_conv_wgrad_bad_indices_read_the_zero_row(sfv):
     """A gather table holding out-of-range rows (stale, half-built, built for another shape) must not fault: such
     entries read the zero row, exactly like the table's own -1 padding entries."""

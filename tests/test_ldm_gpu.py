@@ -156,6 +156,32 @@ def test_captured_encode_equals_eager_and_follows_new_weights():
         assert torch.equal(g.encode(xs[3], sample=False), e.encode(xs[3], sample=False))
     with pytest.raises(ValueError):
         g.encode(torch.zeros(1, 3, 60, 64, device="cuda"))
+    # an IN-PLACE weight change (no load_state_dict, no .to()): the frozen buffers' version counters move, the packed
+    # copies and the graphs that hold their addresses are rebuilt instead of replaying against stale weights
+    for _ in range(2):
+        g.encode(xs[0], sample=False)
+    assert g._graphs
+    for m in (g, e):
+        m._p("encoder.conv_in.weight").mul_(0.5)
+    out_g = g.encode(xs[0], sample=False)
+    assert torch.equal(out_g, e.encode(xs[0], sample=False))
+    for _ in range(2):                          # ... and the re-captured graph replays the new weights
+        assert torch.equal(g.encode(xs[0], sample=False), out_g)
+
+
+def test_halo_equals_gather_on_a_four_tile_layer_and_standalone_groupnorm():
+    """512-channel layers (level 2/3 + mid block: four 128-channel column tiles per pixel tile, GroupNorm as ONE standalone
+    apply pass feeding the four tiles instead of fused into the staging) at 256 x 256 frames, where the 512-wide maps are
+    64 x 64 and 32 x 32: halo path against the gather-GEMM + GroupNorm kernels."""
+    import sfv_amd as sfv
+    torch.manual_seed(15)
+    a = sfv.LDMEncoder(compute_dtype="bf16", conv_impl="halo").cuda()
+    b = sfv.LDMEncoder(compute_dtype="bf16", conv_impl="gather").cuda()
+    b.load_state_dict(a.state_dict())
+    x = (torch.rand(1, 3, 256, 256, generator=torch.Generator().manual_seed(16)) * 2 - 1).cuda()
+    ma, mb = a.moments(x).float().cpu()[:, :8], b.moments(x).float().cpu()[:, :8]
+    assert torch.isfinite(ma).all()
+    assert float((ma - mb).norm() / mb.norm()) < 4e-2
 
 
 @pytest.mark.parametrize("N,Cin,H,W,Nout,cg", [(2, 3, 64, 64, 128, 4), (1, 3, 21, 40, 128, 4), (3, 4, 16, 48, 64, 8), (2, 3, 24, 17, 256, 16),

@@ -214,3 +214,23 @@ def test_encode_codes_and_api(sfv):
     z2 = m2.eval().encode(item[:, 0], temperature=float(g["meta/tau"]), hard=True,
                           noise_ratio=float(g["meta/noise_ratio"]), u=torch.from_numpy(g["U0"]).cuda())
     assert torch.equal(z, z2)
+
+
+def test_input_modified_between_forward_and_backward_raises():
+    """Where the first conv's weight gradient is rebuilt from the frames (rbvae_wgrad_first: bf16, large frames -- forced
+    here at a small shape), backward re-reads the input: an in-place write in between fails like stock torch's version
+    check instead of giving silently wrong conv1 gradients; without the write the same backward runs."""
+    import sfv_amd as sfv
+    torch.manual_seed(21)
+    m = sfv.Seq2SeqBinaryVAE(3, 3, 32, 32, variant="contrastive", input_hw=(64, 64), compute_dtype="bf16").cuda().train()
+    x = torch.rand(2, 3, 3, 64, 64, device="cuda")
+    eng = m._engine_for(x)
+    eng._wf_min_steps = 1
+    assert eng._wf_ksplit(6, 3, 64, 64, 64) > 0
+    xr, hs, z = m(x, 0.7)
+    x.mul_(0.5)
+    with pytest.raises(RuntimeError, match="modified by an inplace operation"):
+        (xr.sum() + hs.sum()).backward()
+    xr, hs, z = m(x, 0.7)
+    (xr.sum() + hs.sum()).backward()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in m.parameters())

@@ -560,3 +560,30 @@ def test_sixteen_fc_groups_equal_four():
     for k in lay.names:
         a, b = lay.view(ga, k).double().reshape(-1), lay.view(gb, k).double().reshape(-1)
         assert float((a - b).norm()) <= 2e-3 * max(float(b.norm()), 1e-9), k
+
+
+def test_fc_groups_fall_back_to_eight_or_four_when_sixteen_does_not_divide():
+    """F3 = 256 * (72 / 8) * (120 / 8) = 34 560 fc inputs (a 4 x 72 x 120 frame): a multiple of 128 (four K units of 32 per
+    group fit) but not of 512, so sixteen groups do not divide it -- the engine takes the largest of 16 / 8 / 4 that does
+    instead of dropping to ONE group on 32 CUs, and the step still matches the one-group step."""
+    import sfv_amd as sfv
+    from importlib import import_module
+    FusedTrainer = import_module("symbols-from-video_amd.trainer").FusedTrainer
+    g = torch.Generator().manual_seed(44)
+    item = torch.randn(1, 2, 3, 4, 72, 120, generator=g).cuda()
+    res = []
+    for force_one in (False, True):
+        torch.manual_seed(45)
+        m = sfv.Seq2SeqBinaryVAE(4, 4, 32, 32, variant="percep", input_hw=(72, 120), compute_dtype="bf16").cuda().train()
+        tr = FusedTrainer(m, lr=1e-3, device_noise=True, use_graph=False, seed=79)
+        eng = tr.eng = m._engine_for(item)
+        eng.seed_dev = tr.step_dev
+        assert eng.F3 == 34560 and eng.fc_split in (8, 4) and eng.F3 % (eng.fc_split * 32) == 0
+        if force_one:
+            eng.fc_split = 1
+        res.append((tr.step(item, 0.7).cpu(), tr.gflat.clone(), eng.layout))
+    (la, ga, lay), (lb, gb, _) = res
+    assert torch.allclose(la, lb, rtol=2e-5, atol=2e-5), (la, lb)
+    for k in lay.names:
+        a, b = lay.view(ga, k).double().reshape(-1), lay.view(gb, k).double().reshape(-1)
+        assert float((a - b).norm()) <= 3e-3 * max(float(b.norm()), 1e-9), k

@@ -26,10 +26,15 @@ if len(marks) < 12:
     marks = [i for i, n in enumerate(names) if "conv_first_fused_k<4, 0>" in n or "conv_first_fused_k<3, 0>" in n]
 if len(marks) < 12:
     marks = [i for i, n in enumerate(names) if "combine_losses_k" in n]
-if len(marks) < 17:
-    marks = [marks[0]] * (17 - len(marks)) + marks
-a, b = marks[-16], marks[-6]          # 10 graph-replayed steps (the last few before the cut are the eager warm-ups of the instrumented leg)
-steps = 10
+if len(marks) < 3:
+    sys.exit(f"prof_summary: {len(marks)} step marker kernel(s) found in {f} (PROF_MARK={_os.environ.get('PROF_MARK')!r}): "
+             "need at least 3 steps to summarise")
+# the last few marks before the cut are the eager warm-ups of the instrumented leg: skip up to 6, summarise up to 10 steps
+skip = min(6, max(0, len(marks) - 3))
+b_i = len(marks) - 1 - skip if skip else len(marks) - 1
+a_i = max(0, b_i - 10)
+a, b = marks[a_i], marks[b_i]
+steps = b_i - a_i
 agg = collections.OrderedDict()
 for r in rows[a:b]:
     n = r["Kernel_Name"].replace("void rbvae::", "").replace("rbvae::", "").split("(")[0][:48]
@@ -47,8 +52,9 @@ try:
         print(f"  {n:48s} x{c / steps:5.1f}  {t / steps:8.1f} us/step  avg {t / c:7.1f}  min {mn:7.1f} max {mx:7.1f}")
 except BrokenPipeError:
     pass
+one = (marks[b_i - 1], marks[b_i])           # the last summarised step
 if len(sys.argv) > 2:
-    a, b = marks[-7], marks[-6]
+    a, b = one
     for r in rows[a:b]:
         n = r["Kernel_Name"]
         if "gemm" in n:
@@ -56,7 +62,7 @@ if len(sys.argv) > 2:
             print(f"    {n.replace('void rbvae::', '')[:44]:44s} grid=({int(r['Grid_Size_X']) // int(r['Workgroup_Size_X'])},{r['Grid_Size_Y']},{r['Grid_Size_Z']}) {t:7.1f} us")
 if len(sys.argv) > 3:
     # timeline of one step: start offset, duration, queue/stream of every kernel (shows side-stream overlap)
-    a, b = marks[-7], marks[-6]
+    a, b = one
     t0 = int(rows[a]["Start_Timestamp"])
     for r in rows[a:b]:
         n = r["Kernel_Name"].replace("void rbvae::", "").replace("rbvae::", "").split("(")[0][:44]
