@@ -62,14 +62,25 @@ class GradReducer:
     Bucket order = reverse layer order, as SURVEY.md 8e asks; the cut sits where the side stream's work is done
     when the main chain arrives (engine.backward(cut=...)), so it costs no idle time."""
 
-    def __init__(self, gflat: torch.Tensor, cut: int, group=None, force: bool = False):
-        """force: issue the collectives even in a one-rank group (rehearsals of the multi-rank schedule on one GPU)."""
+    def __init__(self, gflat: torch.Tensor, cut: int, group=None, force: bool = False, wire_dtype=None):
+        """force: issue the collectives even in a one-rank group (rehearsals of the multi-rank schedule on one GPU).
+        wire_dtype: torch.float32 (default) or torch.bfloat16 (RBVAE_DDP_BF16=1): the buckets cross the links as bf16 --
+        half the bytes of the exchange (SURVEY.md 8e allows either); every rank rounds its gradient to bf16, the collective
+        sums in bf16, the sum is widened back into the f32 buffer (relative error of the summed gradient ~2^-9 per rank
+        added: tests/test_ddp_cpu.py bounds it against the f32 exchange)."""
         self.gflat, self.cut, self.group = gflat, int(cut), group
         self.world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
         if force and dist.is_available() and dist.is_initialized():
             self.world = max(self.world, 2)
         if not 0 < self.cut < gflat.numel() or self.cut % 4:
             raise ValueError(f"bucket cut {cut} outside the buffer or not 16-byte aligned")
+        if wire_dtype is None:
+            wire_dtype = torch.bfloat16 if os.environ.get("RBVAE_DDP_BF16", "0") == "1" else torch.float32
+        if wire_dtype not in (torch.float32, torch.bfloat16):
+            raise ValueError("wire_dtype must be torch.float32 or torch.bfloat16")
+        self.wire_dtype = wire_dtype
+        # persistent staging buffer of the bf16 exchange (same address every step: captured graphs replay the casts)
+        self._wire = torch.empty(gflat.numel(), dtype=torch.bfloat16, device=gflat.device) if wire_dtype == torch.bfloat16 else None
 
     @property
     def tail(self) -> torch.Tensor:
@@ -79,11 +90,34 @@ class GradReducer:
     def head(self) -> torch.Tensor:
         return self.gflat[:self.cut]
 
+    class _Pending:
+        """an asynchronous bucket exchange: wait() orders the current stream behind it (and widens a bf16 bucket back)"""
+
+        def __init__(self, work, part=None, wire=None):
+            self.work, self.part, self.wire = work, part, wire
+
+        def wait(self):
+            if self.work is not None:
+                self.work.wait()
+            if self.wire is not None:
+                self.part.copy_(self.wire)
+
     def _sum(self, part: torch.Tensor, async_op: bool = False):
         """all-reduce (sum) of one view of the gradient buffer; None in a one-rank job"""
         if self.world <= 1:
             return None
-        return dist.all_reduce(part, op=dist.ReduceOp.SUM, group=self.group, async_op=async_op)
+        if self._wire is None:
+            work = dist.all_reduce(part, op=dist.ReduceOp.SUM, group=self.group, async_op=async_op)
+            return self._Pending(work) if async_op else None
+        off = part.storage_offset() - self.gflat.storage_offset()
+        wire = self._wire[off:off + part.numel()]
+        wire.copy_(part)                                   # f32 -> bf16 (round to nearest even) on the current stream
+        work = dist.all_reduce(wire, op=dist.ReduceOp.SUM, group=self.group, async_op=async_op)
+        pend = self._Pending(work if async_op else None, part, wire)
+        if async_op:
+            return pend
+        pend.wait()
+        return None
 
     # synchronous forms: on return the CURRENT stream is ordered behind the collective (what the 2-graph schedule issues
     # between its graphs and what an in-graph schedule captures on its communication stream)

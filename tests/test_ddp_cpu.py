@@ -62,6 +62,24 @@ def _worker(rank, world, port, q):
     ddp.GradReducer(g_1, lay.offsets["decoder_cnn.fc.weight"]).reduce_all()
     ddp.allreduce_mean_(gflat)
     assert torch.equal(g_b / world, gflat) and torch.equal(g_1 / world, gflat)
+    # bf16 on the wire (RBVAE_DDP_BF16=1 / wire_dtype): half the bytes; the summed gradient within bf16 rounding of the f32
+    # exchange, tensor by tensor, and identical on both ranks (asynchronous buckets and the one-all-reduce form)
+    g_h, g_h1 = torch.zeros(lay.total), torch.zeros(lay.total)
+    for k in lay.names:
+        lay.view(g_h, k).copy_(p[k].grad)
+    g_h1.copy_(g_h)
+    redh = ddp.GradReducer(g_h, lay.offsets["decoder_cnn.fc.weight"], wire_dtype=torch.bfloat16)
+    wt, wh = redh.start_tail(), redh.start_head()
+    redh.wait(wt)
+    redh.wait(wh)
+    ddp.GradReducer(g_h1, lay.offsets["decoder_cnn.fc.weight"], wire_dtype=torch.bfloat16).reduce_all()
+    assert torch.equal(g_h, g_h1)
+    for k in lay.names:
+        a, b = lay.view(g_h, k).double() / world, lay.view(gflat, k).double()
+        assert float((a - b).norm()) <= 6e-3 * max(float(b.norm()), 1e-12), k
+    both = [torch.zeros_like(g_h) for _ in range(world)]
+    dist.all_gather(both, g_h)
+    assert all(torch.equal(both[0], b_) for b_ in both)
     if rank == 0:
         q.put((flat.clone(), gflat.clone()))
     dist.barrier()

@@ -140,6 +140,26 @@ def test_bench_gpus2_self_launches():
     assert all(abs(v) < 1e4 for v in line["config"]["last_losses"].values())
 
 
+@pytest.mark.timeout(900)
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs: RCCL refuses two ranks on one device")
+@pytest.mark.parametrize("bf16_wire", [0, 1])
+def test_bench_gpus2_over_rccl(bf16_wire):
+    """`python bench.py --gpus 2` on the backend of record (RCCL over xGMI, one GPU per rank; skipped on a one-GPU box,
+    where the gloo twin above is what runs): the driver's N = 2 scaling point, with the f32 and the bf16 gradient buckets."""
+    import json
+    import subprocess
+    env = dict(os.environ, RBVAE_DDP_BF16=str(bf16_wire), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "RBVAE_DIST_BACKEND"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5",
+                        "--no-cpu"], env=env, capture_output=True, text=True, timeout=840)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["config"]["backend"] == "nccl" and line["config"]["dist_world_size"] == 2
+    assert line["config"]["global_frames_per_step"] == 512 and line["value"] > 0
+    assert all(abs(v) < 1e4 for v in line["config"]["last_losses"].values())
+
+
 @pytest.mark.timeout(600)
 def test_in_graph_collectives_with_one_rank_rccl():
     """RBVAE_DDP_INGRAPH=1: the two all-reduces captured INTO the step's single HIP graph on a communication stream.

@@ -23,6 +23,8 @@ for r in csv.DictReader(open(f)):
 
 
 def inst_key(name):
+    if name.startswith("wgrad_row_k"):
+        return "wgrad_row_k<3 taps per workgroup, K-split>"
     m = re.match(r"(gather_gemm_k|wgrad_gemm_k)<([^>]*)>", name)
     if not m:
         return None

@@ -28,6 +28,10 @@ for k in sorted(fetch):
 per_inst = collections.defaultdict(lambda: [0, 0.0, 0.0])
 for name, grid, n, rd, wr in rows:
     m = re.match(r"(gather_gemm_k|wgrad_gemm_k)<([^>]*)>", name)
+    if name.startswith("wgrad_row_k"):
+        p = per_inst["wgrad_row_k<3 taps per workgroup, K-split>"]
+        p[0] += n; p[1] += rd * n; p[2] += wr * n
+        continue
     if not m:
         continue
     a = [x.strip() for x in m.group(2).split(",")]
