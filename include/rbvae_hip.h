@@ -155,6 +155,23 @@ int rbvae_gather_gemm(int dtype, const void* A, const void* W, void* Out, const 
                       unsigned long long seed, const unsigned long long* seed_dev, float* colsum_ws,
                       void* stream);
 
+/* ---- 3x3 stride-2 pad-1 convolution with the input patch resident in LDS (bf16) -----------------------------------
+ * Out[n][r][c][co] = epi( sum_{kh,kw,ci} A[n][2r + kh - 1][2c + kw - 1][ci] * W[co][kh*3 + kw][ci] ), NHWC rows, IH and IW even,
+ * OH = IH / 2, OW = IW / 2: rbvae_gather_gemm's result for the one-class descriptor of nn.Conv2d(c, c, 3, 2, 1)
+ * (percep_RBVAE_model.py:54-57; the conv-form input gradient of nn.ConvTranspose2d(c, c, 3, 2, 1, 1), :76-81, autograd as run by
+ * percep_RBVAE_train.py:552; the LDM encoder's Downsample, ldm/modules/diffusionmodules/model.py:60-79), with the same
+ * epilogue element for element (+bias, relu, *scale, dropout by key / mask with the same element indices, ReLU gate) --
+ * but a workgroup stages the 17 x 33 input patch of its 8 x 16 output pixels ONCE per 32-channel slice for all nine taps
+ * (9.7 KB through the CU's L2 -> LDS path per MFLOP at 256 output channels per workgroup instead of 15.2).
+ * rbvae_conv3x3s2_halo_ok: output channels per workgroup (256 / 128) when covered (bf16, Kc % 32 == 0, Nout % 128 == 0,
+ * even IH / IW, operands below 2 GiB), else 0.  colsum_ws (optional): [rbvae_conv3x3s2_halo_colsum_rows(..)][Nout] f32
+ * column sums of the stored values per pixel tile -- the bias gradient, finished by rbvae_reduce_rows / a row-reduce job. */
+int rbvae_conv3x3s2_halo_ok(int dtype, int Nimg, int IH, int IW, int Kc, int Nout);
+int rbvae_conv3x3s2_halo_colsum_rows(int Nimg, int IH, int IW);
+int rbvae_conv3x3s2_halo(int dtype, const void* A, const void* W, void* Out, const float* bias, const void* gate, const void* mask,
+                         int Nimg, int IH, int IW, int Kc, int Nout, int lda, int ldo, int relu, int drop_mode, float drop_p,
+                         float scale, unsigned long long seed, const unsigned long long* seed_dev, float* colsum_ws, void* stream);
+
 /* ---- the K = 64 / 128 products around the latent bottleneck (bf16) -------------------------------
  * Out[M][ldo] = A[M][lda] (K used columns) * W[N][K]^T (+ bias[N]) for a few hundred rows and thousands of columns:
  * the decoder's fc forward (Linear(latent_dim -> C3*h3*w3), percep_RBVAE_model.py:74, on the zero-padded codes) and

@@ -56,6 +56,7 @@ ISA_CHECKED = {
     "deconv_halo.hip": ("_ZN5rbvae13deconv_halo_k", ("ds_read_b128",)),
     "wgrad_halo.hip": ("_ZN5rbvae12wgrad_halo_k", ("ds_read_b64_tr_b16",)),
     "wgrad_row.hip": ("_ZN5rbvae11wgrad_row_k", ("ds_read_b64_tr_b16",)),
+    "conv_s2.hip": ("_ZN5rbvae9conv_s2_k", ("ds_read_b128",)),
     "conv_first.hip": ("_ZN5rbvae13wgrad_first_k", ("ds_read_b64_tr_b16",)),
 }
 

@@ -257,6 +257,11 @@ class Engine:
         self._dh_min_wgs = 1024
         # nine-taps-per-workgroup weight gradient of the 3x3 stride-2 layers (csrc/wgrad_halo.hip) when every workgroup
         # gets at least this many 4 x 8 pixel blocks
+        # halo-resident kernel for the 3x3 stride-2 forward-type launches (csrc/conv_s2.hip) from this many workgroups up, when
+        # its 8 x 16-pixel tiles cover at most this many times the image's pixels
+        self.conv_s2_halo = True
+        self._cs_min_wgs = 512
+        self._cs_max_waste = 1.35
         self.wgrad_halo = True
         self._wh_min_steps = 8
         self._wh_max_tiles = 2
@@ -470,6 +475,22 @@ class Engine:
                 L.call("rbvae_deconv3x3s2_halo", self.dt, A, W, out, bias, gate, mask, self.zero, nimg, th, tw, kc, nout, lda,
                        ldo, relu, drop_mode, float(drop_p), float(scale), int(seed), seed_dev, ws)
                 return
+        if (cls_key == "conv" and self.k == 3 and self.conv_s2_halo and self.dt == BF16 and sa == 2 and so == 1 and taps == 9
+                and (oh, ow) == (th, tw) and (ih, iw) == (2 * th, 2 * tw) and colsum_ws is None):
+            # 3x3 stride-2 convolution (encoder forward, decoder input gradients) with the input patch resident in LDS
+            # (csrc/conv_s2.hip): 8 x 16-pixel tiles, so small images (the bench shape's 8 x 8 / 4 x 4 maps) stay on the
+            # row-gather GEMM, as do launches of less than a few rounds of workgroups
+            bn = L.query("rbvae_conv3x3s2_halo_ok", self.dt, nimg, ih, iw, kc, nout)
+            if bn:
+                mt = L.query("rbvae_conv3x3s2_halo_colsum_rows", nimg, ih, iw)
+                if mt * (nout // bn) >= self._cs_min_wgs and mt * 128 <= self._cs_max_waste * nimg * oh * ow:
+                    ws = None
+                    if bias_grad is not None:
+                        ws = self._buf(("colsum_cs", tag), mt * nout)
+                        self._jobs.add(JOB_ROWS, ws, bias_grad, (1, 1, nout), (0, 0, 1), nslab=mt, slab=nout)
+                    L.call("rbvae_conv3x3s2_halo", self.dt, A, W, out, bias, gate, mask, nimg, ih, iw, kc, nout, lda, ldo, relu,
+                           drop_mode, float(drop_p), float(scale), int(seed), seed_dev, ws)
+                    return
         if cls_key == "one":
             desc, ncls = self._desc("one", ONE_TAP), 1
         elif cls_key == "conv":
