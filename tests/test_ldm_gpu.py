@@ -235,3 +235,27 @@ def test_conv_in_matches_conv2d_and_its_groupnorm_statistics(N, Cin, H, W, Nout,
     out3 = torch.empty_like(out)
     L.call("rbvae_conv_in", 1, x, Wp, b, zero, out3, None, 0, N, Cin, H, W, Nout, Nout)
     assert torch.equal(out3.view(torch.int16), out.view(torch.int16))
+
+
+def test_prefetching_attention_equals_the_load_wait_multiply_form_bit_for_bit():
+    """C = 512 from four key tiles up: producer waves prefetch the K / V tiles three half-steps ahead (attn_flash_db_k); fewer
+    tokens take the load-wait-multiply kernel (attn_flash_k).  Same arithmetic in the same order: running the long sequence
+    in two ways -- whole (prefetching kernel) and as the first 96 tokens only (short kernel) -- cannot be compared directly
+    (different softmax sets), so the check is the per-row definition on the CPU at both lengths with one tolerance, plus
+    run-to-run bit-identity of the prefetching kernel."""
+    import sfv_amd as sfv
+    L = sfv._lib
+    C = 512
+    g = torch.Generator().manual_seed(41)
+    for N, hw in ((2, 96), (2, 160), (1, 1024)):
+        qkv = (torch.randn(N * hw, 3 * C, generator=g) * 1.2).to(torch.bfloat16)
+        dq = qkv.cuda()
+        o = torch.empty(N * hw, C, dtype=torch.bfloat16, device="cuda")
+        L.call("rbvae_attention", 1, dq, dq[:, C:], dq[:, 2 * C:], o, N, hw, C, 3 * C, 3 * C, 3 * C, C, float(C ** -0.5))
+        o2 = torch.empty_like(o)
+        L.call("rbvae_attention", 1, dq, dq[:, C:], dq[:, 2 * C:], o2, N, hw, C, 3 * C, 3 * C, 3 * C, C, float(C ** -0.5))
+        assert torch.equal(o, o2)
+        q, k, v = (qkv[:, i * C:(i + 1) * C].float().reshape(N, hw, C) for i in range(3))
+        ref = torch.softmax(q @ k.transpose(1, 2) * C ** -0.5, dim=-1) @ v
+        got = o.float().cpu().reshape(N, hw, C)
+        assert float((got - ref).norm() / ref.norm()) < 2e-2
