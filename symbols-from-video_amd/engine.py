@@ -258,10 +258,12 @@ class Engine:
         # nine-taps-per-workgroup weight gradient of the 3x3 stride-2 layers (csrc/wgrad_halo.hip) when every workgroup
         # gets at least this many 4 x 8 pixel blocks
         # halo-resident kernel for the 3x3 stride-2 forward-type launches (csrc/conv_s2.hip) from this many workgroups up, when
-        # its 8 x 16-pixel tiles cover at most this many times the image's pixels
+        # its 8 x 16-pixel tiles cover at most this many times the image's pixels (measured, tools/time_conv_s2.py: 128 images
+        # 88 x 160 -> 44 x 80, 256 channels: 662 vs 844 us for the gather GEMM; the native 44 x 80 -> 22 x 40 layer, whose 22 x 40
+        # map the tiles cover 1.31 times: 229 vs 174 us, so it stays on the gather GEMM)
         self.conv_s2_halo = True
         self._cs_min_wgs = 512
-        self._cs_max_waste = 1.35
+        self._cs_max_waste = 1.15
         self.wgrad_halo = True
         self._wh_min_steps = 8
         self._wh_max_tiles = 2

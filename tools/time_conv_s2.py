@@ -7,7 +7,7 @@ from importlib import import_module
 E = import_module("symbols-from-video_amd.engine")
 L = sfv._lib
 dev = torch.device("cuda", 0)
-CASES = [("native conv2 (128 x 88x160 -> 44x80)", 128, 88, 160, 256, 256), ("native conv3 (44x80 -> 22x40)", 128, 44, 80, 256, 256),
+CASES = [("128 x 88x160 -> 44x80 (8 slices) ", 128, 88, 160, 256, 256), ("native conv2 (44x80 -> 22x40)", 128, 44, 80, 256, 256),
          ("cfg5 conv2 (64 x 32x32)", 64, 32, 32, 256, 256), ("LDM down 256 (4 x 256x256)", 4, 256, 256, 256, 256),
          ("LDM down 512 (4 x 128x128)", 4, 128, 128, 512, 512), ("LDM down 128 (4 x 512x512)", 4, 512, 512, 128, 128),
          ("bench conv2 (256 x 16x16)", 256, 16, 16, 256, 256)]
