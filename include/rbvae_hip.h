@@ -261,6 +261,13 @@ int rbvae_colsum(int dtype, const void* X, int P, int C, int ld, float* out, flo
  * fast: the logical index consecutive threads walk; inner != 0 (fast == 1, short d2): a thread walks d2 itself.
  * One launch (grid.y = job) replaces the per-tensor launches of a step. */
 int rbvae_run_jobs(const void* jobs_dev, int njobs, int blocks_per_job, void* stream);
+/* The same table launched with exactly the workgroups its jobs can use (a step's update launch: ~1 400 instead of 49 x 256).
+ * rbvae_job_block_map (host): for the njobs rows at rows_host (host copy of the table) write map_host[4 * b] = (job, index of
+ * workgroup b within its job, workgroups of the job <= max_blocks_per_job, 0) and return the number of workgroups (with
+ * map_host == NULL: only count them); negative = error.  rbvae_run_jobs_sized: block_map_dev = that map in device memory
+ * (16-byte aligned), total_blocks = its entries. */
+int rbvae_job_block_map(const long* rows_host, int njobs, int max_blocks_per_job, int* map_host, int map_capacity);
+int rbvae_run_jobs_sized(const void* jobs_dev, const void* block_map_dev, int total_blocks, void* stream);
 
 /* im2col of a strided f32 image (element strides sn,sc,sh,sw) into col[N*OH*OW][Kpad], column
  * (kh*KW+kw)*C + c: the 3/4-channel first Conv2d (percep_RBVAE_model.py:51) and the last

@@ -61,7 +61,7 @@ __device__ __forceinline__ float adam_at(const AdamCtx& c, long off, float step_
 constexpr int CPK_MAXROW = 2304;                       // 256 ci x 9 taps (or 144 ci x 16 taps)
 constexpr int CPK_LDS_BYTES = 16 * (CPK_MAXROW + 8);  // NCO rows of T, NCO * sizeof(T) = 16; +8 elements of pad per row
 template <typename T>
-__device__ __forceinline__ void conv_pack_rows(const Job& j, unsigned char* lds_raw) {
+__device__ __forceinline__ void conv_pack_rows(const Job& j, unsigned char* lds_raw, unsigned bidx, unsigned nblk) {
     constexpr unsigned NCO = 16 / sizeof(T), NV = 16 / sizeof(T);
     typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
     T* tile = (T*)lds_raw;
@@ -82,7 +82,7 @@ __device__ __forceinline__ void conv_pack_rows(const Job& j, unsigned char* lds_
     const AdamCtx* actx = (const AdamCtx*)j.inner;
     float step_size = 0.f, bc2_sqrt = 1.f;
     if (actx) { step_size = actx->hyper[0]; bc2_sqrt = actx->hyper[1]; }
-    for (unsigned b = blockIdx.x; b < ngr * ncb; b += gridDim.x) {
+    for (unsigned b = bidx; b < ngr * ncb; b += nblk) {
         const unsigned co0 = (b / ncb) * NCO, ci0 = (b % ncb) * cib;
         const unsigned cn = min(cib, Ci - ci0), row = cn * kk;       // this piece: cn input channels
         __syncthreads();
@@ -189,7 +189,7 @@ __device__ __forceinline__ void conv_pack_rows(const Job& j, unsigned char* lds_
 // channels): every slab's [t][ci] rows come in by 16-byte loads, all of a thread's loads in flight together, the sums
 // change order through LDS and leave as 16-byte stores of the contiguous [ci][t] row.
 constexpr int CRD_CI = 256, CRD_MAXKK = 16, CRD_ACC = CRD_CI * CRD_MAXKK / 4 / 256;      // float4 accumulators per thread
-__device__ __forceinline__ void conv_reduce_rows(const Job& j, float* tile) {
+__device__ __forceinline__ void conv_reduce_rows(const Job& j, float* tile, unsigned bidx, unsigned nblk) {
 #if defined(JOBS_ABL_ONE_SLAB) && !defined(RBVAE_ABLATION)
 #error "JOBS_ABL_ONE_SLAB gives wrong sums (timing ablation): define RBVAE_ABLATION to confirm"
 #endif
@@ -200,7 +200,7 @@ __device__ __forceinline__ void conv_reduce_rows(const Job& j, float* tile) {
 #endif
     const unsigned ncb = (Ci + CRD_CI - 1) / CRD_CI;
     float* out = (float*)j.dst;
-    for (unsigned b = blockIdx.x; b < Co * ncb; b += gridDim.x) {
+    for (unsigned b = bidx; b < Co * ncb; b += nblk) {
         const unsigned co = b / ncb, ci0 = (b % ncb) * CRD_CI;
         const unsigned cn = min((unsigned)CRD_CI, Ci - ci0);       // multiple of 4 (host-checked)
         const unsigned c4 = cn / 4, nch = kk * c4, pitch = cn + 1;
@@ -283,17 +283,25 @@ __device__ __forceinline__ void conv_reduce_rows(const Job& j, float* tile) {
     }
 }
 
-__global__ __launch_bounds__(256) void run_jobs_k(const Job* __restrict__ jobs) {
+// Launch shapes: grid (blocks per job, jobs) -- every job gets the same number of workgroups, most of which leave at once --
+// or, with a block map (rbvae_run_jobs_sized), a 1-D grid of exactly the workgroups the jobs need: map[b] = (job, index of
+// the workgroup within the job, workgroups of the job).  A step's update launch was 12 544 workgroups of which ~1 400 had work.
+__global__ __launch_bounds__(256) void run_jobs_k(const Job* __restrict__ jobs, const int4* __restrict__ map) {
     __shared__ __attribute__((aligned(16))) unsigned char lds_raw[CPK_LDS_BYTES];
     static_assert(CPK_LDS_BYTES >= (int)sizeof(float) * CRD_MAXKK * (CRD_CI + 1), "the reduce tile fits the pack tile");
     static_assert(CPK_LDS_BYTES >= 256 * 16, "the wide row reduction's tree fits");
-    const Job j = jobs[blockIdx.y];
+    unsigned bidx = blockIdx.x, nblk = gridDim.x, jidx = blockIdx.y;
+    if (map) {
+        const int4 m = map[blockIdx.x];
+        jidx = (unsigned)m.x; bidx = (unsigned)m.y; nblk = (unsigned)m.z;
+    }
+    const Job j = jobs[jidx];
     if (j.type == 3) {
-        if (j.dtype == RBVAE_F32) conv_pack_rows<float>(j, lds_raw); else conv_pack_rows<bf16_t>(j, lds_raw);
+        if (j.dtype == RBVAE_F32) conv_pack_rows<float>(j, lds_raw, bidx, nblk); else conv_pack_rows<bf16_t>(j, lds_raw, bidx, nblk);
         return;
     }
     if (j.type == 4) {
-        conv_reduce_rows(j, (float*)lds_raw);
+        conv_reduce_rows(j, (float*)lds_raw, bidx, nblk);
         return;
     }
     if (j.type == 6 || j.type == 7) {
@@ -329,7 +337,7 @@ __global__ __launch_bounds__(256) void run_jobs_k(const Job* __restrict__ jobs) 
                 const unsigned nt0 = (D0 + T0 - 1) / T0, nt1 = (d1 + T1 - 1) / T1, nt2 = (d2 + T2 - 1) / T2;
                 const unsigned pitch = T2 + 1, tel = T0 * T1 * T2;
                 float* tile = (float*)lds_raw;                                           // [T0 * T1][T2 + 1]
-                for (unsigned t = blockIdx.x; t < nt0 * nt1 * nt2; t += gridDim.x) {
+                for (unsigned t = bidx; t < nt0 * nt1 * nt2; t += nblk) {
                     const unsigned b2 = (t % nt2) * T2, b1 = ((t / nt2) % nt1) * T1, b0 = (t / (nt2 * nt1)) * T0;
                     // master order (i2 fastest), four elements per thread and round: their 16 loads are in flight together
                     // (one element per round was 32 dependent round trips per tile: the stores of one may alias the loads of
@@ -379,7 +387,7 @@ __global__ __launch_bounds__(256) void run_jobs_k(const Job* __restrict__ jobs) 
                 return;
             }
         }
-        for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        for (long i = (long)bidx * 256 + threadIdx.x; i < n; i += (long)nblk * 256) {
             const float w = adam_at(c, base + i, step_size, bc2_sqrt);
             if (j.type == 6) {
                 const unsigned i2 = (unsigned)(i % d2), r = (unsigned)(i / d2), i1 = r % d1, i0 = r / d1;
@@ -402,7 +410,7 @@ __global__ __launch_bounds__(256) void run_jobs_k(const Job* __restrict__ jobs) 
         const long b = counter ? (long)(counter[0] % (unsigned long long)nb) : 0;
         const float4* table = (const float4*)j.src;
         float4* out = (float4*)j.dst;
-        for (long r = blockIdx.x; r < rows; r += gridDim.x) {
+        for (long r = bidx; r < rows; r += nblk) {
             long src = plan[b * rows + r];
             if (src < 0 || src >= table_rows) src = 0;
             for (long i = threadIdx.x; i < vec; i += 256) out[r * vec + i] = table[src * vec + i];
@@ -412,7 +420,7 @@ __global__ __launch_bounds__(256) void run_jobs_k(const Job* __restrict__ jobs) 
     const unsigned d0 = (unsigned)j.d0, d1 = (unsigned)j.d1, d2 = (unsigned)j.d2;
     const unsigned n = d0 * d1 * d2;
     // this job may need fewer blocks than the launch provides
-    if (blockIdx.x * (j.type == 2 ? 4u : 256u) >= n) return;
+    if (bidx * (j.type == 2 ? 4u : 256u) >= n) return;
     if (j.type == 2) {
         const unsigned nsl = (unsigned)j.nslab, slb = (unsigned)j.slab;
         if (nsl >= 1024 && (n & 3) == 0 && (slb & 3) == 0 && ((size_t)j.src & 15) == 0) {
@@ -421,7 +429,7 @@ __global__ __launch_bounds__(256) void run_jobs_k(const Job* __restrict__ jobs) 
             // threads -- one wave per column walked 16 384 rows with 64-way uncoalesced dword loads (50 us for 4 MB)
             float4* red = (float4*)lds_raw;
             float* out = (float*)j.dst;
-            for (unsigned cb = blockIdx.x; cb < n / 4; cb += gridDim.x) {
+            for (unsigned cb = bidx; cb < n / 4; cb += nblk) {
                 float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
                 const float* col = j.src + 4 * cb;
                 unsigned k = threadIdx.x;
@@ -458,7 +466,7 @@ __global__ __launch_bounds__(256) void run_jobs_k(const Job* __restrict__ jobs) 
         }
         // out[c] = scale * sum_k src[k*slab + c]; one wave per output, lanes stride the slabs, shuffle-reduce
         const int lane = threadIdx.x & 63;
-        const unsigned wave = blockIdx.x * 4 + (threadIdx.x >> 6), nw = gridDim.x * 4;
+        const unsigned wave = bidx * 4 + (threadIdx.x >> 6), nw = nblk * 4;
         float* out = (float*)j.dst;
         const unsigned ns = (unsigned)j.nslab, slab = (unsigned)j.slab;
         for (unsigned c = wave; c < n; c += nw) {
@@ -484,7 +492,7 @@ __global__ __launch_bounds__(256) void run_jobs_k(const Job* __restrict__ jobs) 
         // the strided side): a thread owns (i0, i1) and walks i2 itself, so the strided side is read / written
         // as whole rows of consecutive i1 and the contiguous side as d2-element runs per thread
         const unsigned ns = (unsigned)j.nslab;
-        for (unsigned i = blockIdx.x * 256 + threadIdx.x; i < d0 * d1; i += gridDim.x * 256) {
+        for (unsigned i = bidx * 256 + threadIdx.x; i < d0 * d1; i += nblk * 256) {
             const unsigned i1 = i % d1, i0 = i / d1;
             const size_t lin0 = (size_t)i * d2;
             const size_t so0 = i0 * (size_t)j.s0 + i1 * (size_t)j.s1;
@@ -535,7 +543,7 @@ __global__ __launch_bounds__(256) void run_jobs_k(const Job* __restrict__ jobs) 
     const int f = j.fast;
     const unsigned ef = f == 0 ? d0 : (f == 1 ? d1 : d2);       // extent of the fastest index
     const unsigned em = f == 2 ? d1 : d2;                        // extent of the middle one
-    for (unsigned i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+    for (unsigned i = bidx * 256 + threadIdx.x; i < n; i += nblk * 256) {
         const unsigned fv = i % ef, r = i / ef;
         const unsigned mid = r % em, slow = r / em;
         const unsigned i0 = f == 0 ? fv : slow;
@@ -578,7 +586,72 @@ using namespace rbvae;
 extern "C" int rbvae_run_jobs(const void* jobs_dev, int njobs, int blocks_per_job, void* stream) {
     RBVAE_CHECK_ARG(jobs_dev && njobs > 0 && blocks_per_job > 0, "run_jobs: bad arguments");
     RBVAE_CHECK_ARG(njobs <= 65535, "run_jobs: too many jobs");
-    hipLaunchKernelGGL(run_jobs_k, dim3(blocks_per_job, njobs), dim3(256), 0, (hipStream_t)stream, (const Job*)jobs_dev);
+    hipLaunchKernelGGL(run_jobs_k, dim3(blocks_per_job, njobs), dim3(256), 0, (hipStream_t)stream, (const Job*)jobs_dev,
+                       (const int4*)nullptr);
     RBVAE_CHECK_LAUNCH("run_jobs");
+    return RBVAE_OK;
+}
+
+// workgroups job `r` (16 x int64, host copy of a table row) can use: the loop bounds of run_jobs_k's branches
+static long job_blocks_of(const long* r) {
+    const long type = r[0], d0 = r[3], d1 = r[4], d2 = r[5], n = d0 * d1 * d2;
+    const long dtype = r[11];
+    if (type == 3) {
+        const long es = (dtype & 255) == RBVAE_F32 ? 4 : 2, nco = 16 / es, nv = 16 / es, kk = d2;
+        long cib = (CPK_MAXROW / kk) / nv * nv;
+        if (cib > d1) cib = d1;
+        if (cib > CPK_CIB && d1 % CPK_CIB == 0) cib = CPK_CIB;
+        return ((d0 + nco - 1) / nco) * ((d1 + cib - 1) / cib);
+    }
+    if (type == 4) return d0 * ((d1 + CRD_CI - 1) / CRD_CI);
+    if (type == 5) return d0;
+    if (type == 6 || type == 7) {
+        if (type == 6 && n >= (1l << 20)) {
+            const long a0 = r[6], a1 = r[7], c0 = r[9], c1 = r[10];
+            const int fA = a0 == 1 ? 0 : (a1 == 1 ? 1 : 2);
+            const int fB = !r[15] ? fA : (c0 == 1 ? 0 : (c1 == 1 ? 1 : 2));
+            if (fA != 2 || fB != 2) {
+                long T0, T1, T2;
+                if (fA != 2 && fB != 2 && fA != fB) { T2 = 16; T0 = fB == 0 ? 32 : 16; T1 = fB == 1 ? 32 : 16; }
+                else { const int f = fA != 2 ? fA : fB; T2 = 32; T0 = f == 0 ? 32 : 8; T1 = f == 1 ? 32 : 8; }
+                if (T0 > d0) T0 = d0;
+                if (T1 > d1) T1 = d1;
+                if (T2 > d2) T2 = d2;
+                return ((d0 + T0 - 1) / T0) * ((d1 + T1 - 1) / T1) * ((d2 + T2 - 1) / T2);
+            }
+        }
+        return (n + 255) / 256;
+    }
+    if (type == 2) return (n + 3) / 4;              // four columns (wide rows) or four waves = four outputs per workgroup
+    if (r[14]) return (d0 * d1 + 255) / 256;        // a thread per (i0, i1) row
+    return (n + 255) / 256;
+}
+
+extern "C" int rbvae_job_block_map(const long* rows_host, int njobs, int max_blocks_per_job, int* map_host, int map_capacity) {
+    if (!rows_host || njobs <= 0 || max_blocks_per_job <= 0) return fail(RBVAE_E_INVALID, "job_block_map: bad arguments");
+    long total = 0;
+    for (int j = 0; j < njobs; ++j) {
+        long nb = job_blocks_of(rows_host + 16l * j);
+        if (nb < 1) nb = 1;
+        if (nb > max_blocks_per_job) nb = max_blocks_per_job;
+        if (map_host) {
+            if (total + nb > map_capacity) return fail(RBVAE_E_INVALID, "job_block_map: map of %d entries is too small", map_capacity);
+            for (long b = 0; b < nb; ++b) {
+                int* m = map_host + 4 * (total + b);
+                m[0] = j; m[1] = (int)b; m[2] = (int)nb; m[3] = 0;
+            }
+        }
+        total += nb;
+    }
+    if (total >= (1l << 31)) return fail(RBVAE_E_INVALID, "job_block_map: too many workgroups");
+    return (int)total;
+}
+
+extern "C" int rbvae_run_jobs_sized(const void* jobs_dev, const void* block_map_dev, int total_blocks, void* stream) {
+    RBVAE_CHECK_ARG(jobs_dev && block_map_dev && total_blocks > 0, "run_jobs_sized: bad arguments");
+    RBVAE_CHECK_ARG((uintptr_t)block_map_dev % 16 == 0, "run_jobs_sized: the block map must be 16-byte aligned");
+    hipLaunchKernelGGL(run_jobs_k, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream, (const Job*)jobs_dev,
+                       (const int4*)block_map_dev);
+    RBVAE_CHECK_LAUNCH("run_jobs_sized");
     return RBVAE_OK;
 }

@@ -189,6 +189,20 @@ class JobList:
         return tuple(tuple(r) for r in self.rows)
 
 
+def job_block_map(rows, device, cap):
+    """Block map of a job table for rbvae_run_jobs_sized: one workgroup entry (job, index within the job, workgroups of the
+    job) per workgroup the rows can use, at most `cap` per job.  -> (int32 device tensor [n][4], n)."""
+    import numpy as np
+    arr = np.ascontiguousarray(np.array(rows, dtype=np.int64).reshape(len(rows), 16))
+    total = L.query("rbvae_job_block_map", arr.ctypes.data, len(rows), cap, None, 0)
+    if total <= 0:
+        raise RuntimeError("rbvae_job_block_map: " + L.lib().rbvae_last_error().decode())
+    m = np.empty(4 * total, dtype=np.int32)
+    if L.query("rbvae_job_block_map", arr.ctypes.data, len(rows), cap, m.ctypes.data, total) != total:
+        raise RuntimeError("rbvae_job_block_map: " + L.lib().rbvae_last_error().decode())
+    return torch.from_numpy(m).to(device), total
+
+
 class Saved:
     """Activations one forward call keeps for its backward."""
     __slots__ = ("N", "S", "T", "hw", "train", "tau", "tau_dev", "hard", "col1", "x_in", "fm_in", "a1", "a2", "a3", "e", "hs_enc", "hp_enc",
@@ -240,7 +254,8 @@ class Engine:
         self._jobs: Optional[JobList] = None
         self._wg_cus = 256
         self.last_wgrad_kernel = None  # kernel family the last _wgrad() call launched (bench.py's roofline leg keys its timers by it)
-        self._job_blocks = 256      # workgroups per job of a batched job launch
+        self._job_blocks = 256      # workgroups per job of a batched job launch (at most)
+        self.sized_jobs = 2         # job tables launched with exactly the workgroups they can use: 0 none, 1 the update table, 2 all
         self._side: Optional[torch.cuda.Stream] = None
         # Side stream (graph capture turns the fork / join into graph edges; `overlap = False`: everything in issue order on
         # one stream -- bench.py's `isolated` leg).  What rides it was settled by same-GPU sweeps in rounds 1-2 (ms/step):
@@ -327,6 +342,21 @@ class Engine:
         self.wT_enc = torch.zeros(nl, 2, Ld, 4 * Ld, dtype=torch.float32, device=self.device)   # [k][gate row]
         self.wT_dec = torch.zeros(nl, 2, Ld, 4 * Ld, dtype=torch.float32, device=self.device)
 
+    def _register_table(self, tab: torch.Tensor, rows):
+        """Remember the block map of an uploaded job table (run_table launches it with exactly the workgroups it can use)."""
+        if not hasattr(self, "_table_maps"):
+            self._table_maps = {}
+        self._table_maps[tab.data_ptr()] = job_block_map(rows, self.device, self._job_blocks) + (tab,)
+
+    def run_table(self, tab: torch.Tensor, n: int, kind: int = 2):
+        """One batched job launch of an uploaded table: sized (rbvae_run_jobs_sized) when its block map is registered and
+        sized_jobs covers its kind (1 = the optimiser update table, 2 = the pack / reduce tables)."""
+        m = getattr(self, "_table_maps", {}).get(tab.data_ptr())
+        if m is None or self.sized_jobs < kind:
+            L.call("rbvae_run_jobs", tab, n, self._job_blocks)
+        else:
+            L.call("rbvae_run_jobs_sized", tab, m[0], m[1])
+
     def pack(self, flat: torch.Tensor):
         """f32 parameters (reference layouts) -> the packed T copies the GEMMs read (one launch)."""
         key = flat.data_ptr()
@@ -334,8 +364,9 @@ class Engine:
         if tab is None:
             jl = self._pack_jobs(flat)
             tab = (jl.upload(self.device), len(jl.rows), jl)
+            self._register_table(tab[0], jl.rows)
             self._pack_tab[key] = tab
-        L.call("rbvae_run_jobs", tab[0], tab[1], self._job_blocks)
+        self.run_table(tab[0], tab[1])
 
     def update_jobs(self, flat, gflat, m, v, hyper, betas, eps, gscale, extra_rows=None, part=None):
         """Optimiser step + weight repack of a training step as ONE batched job launch: every parameter tensor is a job
@@ -392,6 +423,7 @@ class Engine:
         if by_src:
             raise RuntimeError("pack jobs whose source is not a parameter tensor")
         t = torch.tensor(rows, dtype=torch.int64).to(self.device)
+        self._register_table(t, rows)
         self._pack_tab[key] = (t, len(rows), ctx, jl)
         return t, len(rows)
 
@@ -651,8 +683,9 @@ class Engine:
         tab = self._bwd_tab.get(sig)
         if tab is None:
             tab = (jl.upload(self.device), len(jl.rows), jl)
+            self._register_table(tab[0], jl.rows)
             self._bwd_tab[sig] = tab
-        L.call("rbvae_run_jobs", tab[0], tab[1], self._job_blocks)
+        self.run_table(tab[0], tab[1])
 
     def _E(self, *shape, dtype=None):
         return torch.empty(*shape, dtype=dtype or self.tdt, device=self.device)

@@ -182,7 +182,7 @@ class FusedTrainer:
             extra = [self._gather_row(self._static[(B, T)]["x"])]      # the next step's batch (the counter has advanced)
         tab, n = self.eng.update_jobs(self.model._flat, self.gflat, self.m, self.vv, self.hyper, self.betas, self.eps,
                                       1.0 / self.world, extra, part)
-        L.call("rbvae_run_jobs", tab, n, self.eng._job_blocks)
+        self.eng.run_table(tab, n, 1)
 
     # ---- public --------------------------------------------------------------------
     def step(self, item: Optional[torch.Tensor], temperature: float, U: Optional[torch.Tensor] = None,

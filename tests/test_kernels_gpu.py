@@ -887,7 +887,7 @@ def test_fused_update_jobs_equal_adam_plus_pack(sfv, variant, in_ch, dtype, Ld, 
     packed = ("W1p", "W2f", "W2d", "W3f", "W3d", "Wfc", "WfcT", "Wdfc", "WdfcT", "bdfc", "V1f", "V1d", "V2f", "V2d", "V3p",
               "V3f", "wT_enc", "wT_dec")
     res = []
-    for fused in (False, True):
+    for fused in (False, True, "sized"):
         eng = E.Engine(variant, in_ch, in_ch, Ld, hw, dtype, torch.device("cuda", 0))
         n = eng.layout.total
         gen = torch.Generator().manual_seed(96)
@@ -902,7 +902,12 @@ def test_fused_update_jobs_equal_adam_plus_pack(sfv, variant, in_ch, dtype, Ld, 
         # the bias-correction terms as the trainer prepares them (step 7)
         sfv._lib.call("rbvae_combine_losses", None, 0, 0.0, one, one, 0, 0.0, one, 0, 0.0, 0.0, 1.0, 1.0, out4, step, 2e-3, None,
                       0.9, 0.999, hyper)
-        if fused:
+        if fused == "sized":      # the same table launched with exactly the workgroups its jobs can use (rbvae_run_jobs_sized)
+            tab, nj = eng.update_jobs(flat, grad, m, v, hyper, (0.9, 0.999), 1e-8, 0.5)
+            bmap, nb = eng._table_maps[tab.data_ptr()][:2]
+            assert nb < nj * 256 and int(bmap.view(-1, 4)[:, 0].max()) == nj - 1
+            eng.run_table(tab, nj)
+        elif fused:
             tab, nj = eng.update_jobs(flat, grad, m, v, hyper, (0.9, 0.999), 1e-8, 0.5)
             sfv._lib.call("rbvae_run_jobs", tab, nj, 256)
         else:
@@ -915,3 +920,4 @@ def test_fused_update_jobs_equal_adam_plus_pack(sfv, variant, in_ch, dtype, Ld, 
         res.append({**pv, **{k: getattr(eng, k).clone() for k in packed}})
     for k in res[0]:
         assert torch.equal(res[0][k], res[1][k]), k
+        assert torch.equal(res[0][k], res[2][k]), k

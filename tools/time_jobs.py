@@ -41,6 +41,21 @@ def time_tab(label, tab, n, jl):
         return [a.elapsed_time(b) * 1e3 for a, b in evs]
     timed([(tab, n)])
     whole = timed([(tab, n)] * 3)
+    # the same table with exactly the workgroups its jobs can use (rbvae_run_jobs_sized)
+    from importlib import import_module as _im
+    bmap, nb = _im("symbols-from-video_amd.engine").job_block_map(jl.rows, dev, 256)
+    def timed_sized(reps):
+        torch.cuda.synchronize()
+        torch.cuda._sleep(40_000_000)
+        evs = []
+        for _ in range(reps):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record(); L.call("rbvae_run_jobs_sized", tab, bmap, nb); b.record()
+            evs.append((a, b))
+        torch.cuda.synchronize()
+        return [a.elapsed_time(b) * 1e3 for a, b in evs]
+    timed_sized(1)
+    print(f"{label}: sized launch of {nb} workgroups (instead of {n * 256}): {min(timed_sized(3)):.1f} us")
     each = timed([(tab[i:i + 1].contiguous(), 1) for i in range(n)])
     print(f"{label}: {n} jobs, all together {min(whole):.1f} us (event pair overhead ~4.8 us included)")
     for i, r in enumerate(jl.rows):
