@@ -1,5 +1,5 @@
 """Same-box A/B of engine settings on the bench workload (or native / cfg 3): ms per step for each setting, alternating.
-usage: python tools/ab_step.py [--cfg bench|native|cfg3] [--steps 300] [--rounds 2] "name:attr=val,attr=val" ...
+usage: python tools/ab_step.py [--cfg bench|native|cfg3] [--steps 300] [--rounds 2] "name:attr=val,tr.attr=val" ...   (attr: engine attribute, tr.attr: trainer attribute)
 e.g.   python tools/ab_step.py "row:wgrad_row=1" "gemm:wgrad_row=0" "row8:wgrad_row=1,_wr_min_steps=8" """
 import argparse, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -28,8 +28,11 @@ def build(spec):
     eng = m._engine_for(item)          # the engine the trainer will pick up at its first step
     for kv in filter(None, sets.split(",")):
         k, v = kv.split("=")
-        assert hasattr(eng, k), k
-        setattr(eng, k, type(getattr(eng, k))(int(v)) if not isinstance(getattr(eng, k), float) else float(v))
+        obj = eng
+        if k.startswith("tr."):                 # a trainer attribute (e.g. tr.early_tail_update=0)
+            obj, k = tr, k[3:]
+        assert hasattr(obj, k), k
+        setattr(obj, k, type(getattr(obj, k))(int(v)) if not isinstance(getattr(obj, k), float) else float(v))
     for _ in range(10):
         tr.step(item, 0.7)
     torch.cuda.synchronize()
