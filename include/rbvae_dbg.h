@@ -17,6 +17,11 @@ int rbvae_dbg_wg_stamps(unsigned long long* buf, void* stream);   /* same for rb
 /* rbvae_wgrad3x3s2_row (-DWR_STAMPS=1 builds): per workgroup start, loop start, loop end, end (100 MHz), cycles waited at
  * the stage barriers, cycles of the loop, K steps */
 int rbvae_dbg_wr_stamps(unsigned long long* buf, void* stream);
+/* librbvae_hip: which kernel rbvae_conv3x3_halo runs for bf16: 2 (default) the product dispatch -- the persistent kernel with
+ * producer / MFMA wave roles (conv_halo_ws.hip) for layers of at most 256 input channels and at least 512 tiles, else the
+ * one-tile-per-workgroup kernel (conv_halo.hip); 1 the latter always; 0 the persistent kernel wherever it covers -- for the
+ * bit-identity test and A/B timing; returns the previous value */
+int rbvae_dbg_conv_halo_variant(int v);
 int rbvae_dbg_tr16(const void* img, const int* rowsel, const int* colsel, void* out, void* stream);
 
 #ifdef __cplusplus

@@ -53,6 +53,7 @@ ISA_CHECKED = {
     "wgrad_gemm.hip": ("_ZN5rbvae12wgrad_gemm_k", ("ds_read_b64_tr_b16",)),
     "gather_gemm.hip": ("_ZN5rbvae13gather_gemm_k", ("ds_read_b128",)),
     "conv_halo.hip": ("_ZN5rbvae11conv_halo_k", ("ds_read_b128",)),
+    "conv_halo_ws.hip": ("_ZN5rbvae14conv_halo_ws_k", ("ds_read_b128",)),
     "deconv_halo.hip": ("_ZN5rbvae13deconv_halo_k", ("ds_read_b128",)),
     "wgrad_halo.hip": ("_ZN5rbvae12wgrad_halo_k", ("ds_read_b64_tr_b16",)),
     "wgrad_row.hip": ("_ZN5rbvae11wgrad_row_k", ("ds_read_b64_tr_b16",)),
@@ -62,7 +63,8 @@ ISA_CHECKED = {
 
 
 # kernels with register-destination loads issued as inline asm (counted vmcnt waits): the load opcode
-ASM_VMEM_LOADS = {"conv_halo.hip": "global_load_dwordx4", "deconv_halo.hip": "global_load_dwordx4"}
+ASM_VMEM_LOADS = {"conv_halo.hip": "global_load_dwordx4", "deconv_halo.hip": "global_load_dwordx4",
+                  "conv_halo_ws.hip": "buffer_load_dwordx4"}
 
 
 def _check_asm_reads(src):

@@ -23,61 +23,9 @@
 // as the MFMA row operand so a lane owns 4 consecutive output channels of one pixel; the tile leaves through LDS as
 // whole 16-B chunks of NHWC rows (bias, residual addend), optionally with the tile's GroupNorm partial statistics
 // (per image and group: mean and sum of squared deviations) for the NEXT GroupNorm.
-#include "common.h"
-#include <stdlib.h>
-#include <type_traits>
+#include "conv_halo.h"
 
 namespace rbvae {
-
-typedef __attribute__((ext_vector_type(8))) short bf16x8_t;
-typedef __attribute__((ext_vector_type(4))) float f32x4_t;
-typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
-
-struct ChArgs {
-    const unsigned char* A;        // [Nimg*IH*IW][lda] T
-    const unsigned char* W;        // [Nout][9][Kc] T
-    unsigned char* Out;            // [Nimg*OH*OW][ldo] T
-    const float* bias;             // [Nout] or null
-    const unsigned char* addend;   // [Nimg*OH*OW][ldo] T or null (residual)
-    const unsigned char* zero;     // >= 128 zero bytes
-    const float* gn_scale;         // [Nimg][Kc] or null: input -> swish?(x * scale + shift) while staging
-    const float* gn_shift;
-    float* stats;                  // null or [m tiles][Nout / cg] float2 (mean, M2) of the stored tile per group
-    int gn_swish, stats_cg;        // channels per group of the output statistics
-    int Nimg, IH, IW, OH, OW, dh0, dw0;
-    int Kc, Nout, lda, ldo;
-    int tiles_r, tiles_c, ntn, total;
-};
-
-__device__ __forceinline__ void ch_glds16(const void* g, void* lds) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                     (__attribute__((address_space(3))) void*)lds, 16, 0, 0);
-}
-
-template <typename T> struct ChMma;
-template <> struct ChMma<bf16_t> {
-    static __device__ __forceinline__ void run(f32x4_t& acc, const u32x4_t& rowop, const u32x4_t& colop) {
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8_t*)&rowop, *(const bf16x8_t*)&colop, acc, 0, 0, 0);
-    }
-};
-template <> struct ChMma<float> {
-    static __device__ __forceinline__ void run(f32x4_t& acc, const u32x4_t& rowop, const u32x4_t& colop) {
-        const f32x4_t r = *(const f32x4_t*)&rowop, c = *(const f32x4_t*)&colop;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(r[q], c[q], acc, 0, 0, 0);
-    }
-};
-
-constexpr int CH_BM = 256, CH_BN = 128, CH_T = 16;          // tile: 16 x 16 pixels x 128 channels
-constexpr int CH_PW = CH_T + 2, CH_NSLOT = CH_PW * CH_PW;    // 18 x 18 patch
-constexpr int CH_NSLOT_PAD = 336;                             // multiple of 16
-constexpr int CH_PLANE = CH_NSLOT_PAD * 16;                   // bytes per chunk plane
-constexpr int CH_KKOFF = 4 * CH_PLANE + 64;                   // chunk 4kk+fg = kk * KKOFF + fg part
-constexpr int CH_ABUF = 8 * CH_PLANE + 128;                   // 43136: one patch image (planes + staggers)
-constexpr int CH_BBYTES = CH_BN * 128;
-constexpr int CH_NA = 6;                                      // register-staged 16-B pieces per thread and slice
-
-__device__ __forceinline__ unsigned ch_plane_off(int chunk) { return (unsigned)(chunk * CH_PLANE + (chunk >> 1) * 32); }
 
 // bytes of the staging buffers / epilogue tile + statistics scratch (the tables follow)
 template <typename T, int RING> constexpr int ch_lds_main() {
@@ -95,17 +43,6 @@ template <typename T, int RING> constexpr int ch_lds_main() {
 #if CH_ABL && !defined(RBVAE_ABLATION)
 #error "CH_ABL builds give wrong results: define RBVAE_ABLATION to confirm"
 #endif
-
-template <int I, int N, typename F> __device__ __forceinline__ void ch_static_for(F&& f) {
-    if constexpr (I < N) {
-        f(std::integral_constant<int, I>{});
-        ch_static_for<I + 1, N>(f);
-    }
-}
-
-// workgroup barrier that orders LDS traffic only.  __syncthreads() also waits vmcnt(0): behind the epilogue's global stores
-// every barrier then costs a full store round trip (the epilogue ran at half the HBM write rate because of it).
-__device__ __forceinline__ void ch_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 template <int N> __device__ __forceinline__ void ch_wait_barrier() {
 #if CH_ABL & 2
@@ -646,6 +583,8 @@ static int launch_ch(const ChArgs& a, hipStream_t st) {
 
 using namespace rbvae;
 
+static int ch_variant = 2;
+
 extern "C" int rbvae_conv3x3_halo_ok(int dtype, int IH, int IW, int OH, int OW, int Kc, int Nout) {
     const int KE = dtype == RBVAE_F32 ? 32 : 64;
     if (dtype != RBVAE_F32 && dtype != RBVAE_BF16) return 0;
@@ -685,7 +624,19 @@ extern "C" int rbvae_conv3x3_halo(int dtype, const void* A, const void* W, void*
     a.total = (int)total;
     hipStream_t st = (hipStream_t)stream;
     if (dtype == RBVAE_F32) return gn_scale ? launch_ch<float, 3, true>(a, st) : launch_ch<float, 3, false>(a, st);
+    // bf16: the persistent kernel with producer / MFMA wave roles (conv_halo_ws.hip), bit-identical to conv_halo_k:
+    // 2 (auto): the persistent kernel where it measured ahead -- at most 256 input channels (the per-tile prologue / epilogue it
+    // overlaps is a third of such a tile) and at least two tiles per CU to walk
+    const bool ws_auto = a.Kc <= 256 && a.total >= 512;
+    if ((ch_variant == 0 || (ch_variant == 2 && ws_auto)) && ch_ws_covers(a)) return launch_ch_ws(a, st);
     return gn_scale ? launch_ch<bf16_t, 3, true>(a, st) : launch_ch<bf16_t, 3, false>(a, st);
+}
+
+/* include/rbvae_dbg.h: 2 = the product dispatch (auto), 1 = conv_halo_k always, 0 = the persistent kernel wherever it covers (bit-identity tests, A/B timing) */
+extern "C" int rbvae_dbg_conv_halo_variant(int v) {
+    const int old = ch_variant;
+    ch_variant = v;
+    return old;
 }
 
 extern "C" size_t rbvae_conv3x3_halo_stats_floats(int Nimg, int OH, int OW, int Nout, int cg) {
