@@ -625,9 +625,9 @@ extern "C" int rbvae_conv3x3_halo(int dtype, const void* A, const void* W, void*
     hipStream_t st = (hipStream_t)stream;
     if (dtype == RBVAE_F32) return gn_scale ? launch_ch<float, 3, true>(a, st) : launch_ch<float, 3, false>(a, st);
     // bf16: the persistent kernel with producer / MFMA wave roles (conv_halo_ws.hip), bit-identical to conv_halo_k:
-    // 2 (auto): the persistent kernel where it measured ahead -- at most 256 input channels (the per-tile prologue / epilogue it
-    // overlaps is a third of such a tile) and at least two tiles per CU to walk
-    const bool ws_auto = a.Kc <= 256 && a.total >= 512;
+    // 2 (auto): the persistent kernel where it measured ahead -- at least two tiles per CU to walk (the per-tile prologue and
+    // epilogue it overlaps are a third of a two-slice tile; with one tile per workgroup there is nothing to overlap)
+    const bool ws_auto = a.total >= 512;
     if ((ch_variant == 0 || (ch_variant == 2 && ws_auto)) && ch_ws_covers(a)) return launch_ch_ws(a, st);
     return gn_scale ? launch_ch<bf16_t, 3, true>(a, st) : launch_ch<bf16_t, 3, false>(a, st);
 }

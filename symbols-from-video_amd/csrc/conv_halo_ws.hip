@@ -19,10 +19,15 @@
 //     of slice g + 1 is written during slice g's taps 0-7 (buffer (g + 1) & 1, last read by slice g - 1), its loads are
 //     issued a slice ahead in two batches (tap 3: pieces 0-5 + the GroupNorm coefficients; tap 8: pieces 6-10) as the
 //     registers of the pieces before them come free.
-//   * Every producer wait is a counted s_waitcnt vmcnt(N), N = the operations issued behind the awaited one in the STEADY
-//     op stream  T0 T1 T2 T3 A T4 T5 T6 T7 T8 B  per slice (Tj = the four tile pieces of tap j's body).  Where a real
-//     operation does not exist (the prologue, the last slices of the walk) a dummy out-of-range buffer load of the same
-//     count takes its place, so one loop body serves the whole walk.
+//   * The patch pieces ROLL: a piece's register is re-loaded for the slice after next right behind the instruction that
+//     consumed it, so every patch load has a whole slice (nine units) to land.  (Loaded in two batches four to six units ahead,
+//     the loads' latency was what the patch staging cost: with out-of-range loads the kernel ran 15 % faster, with the
+//     processing alone removed not at all.)
+//   * Every producer wait is a counted s_waitcnt vmcnt(N) against the PERIODIC op stream of a slice,
+//       T0 C L0 L1 | T1 L2 L3 | T2 L4 L5 | T3 L6 | T4 L7 | T5 L8 | T6 L9 | T7 L10 | T8
+//     (Tj = the four tile pieces of tap j's body, C = the GroupNorm coefficients, Lk = the re-load of piece k): a piece is
+//     awaited with vmcnt(P - 1), P = the operations of a period.  Where a real operation does not exist (the prologue, the
+//     last slices of the walk) an out-of-range load of the same count takes its place, so one loop body serves the whole walk.
 #include "conv_halo.h"
 
 // timing ablations (wrong results on purpose; -DRBVAE_ABLATION builds only, tools/ab_variants.sh): 1 no weight LDS-DMA (dummy
@@ -39,8 +44,6 @@ namespace rbvae {
 
 constexpr int CW_RING = 4;
 constexpr int CW_NP = 11;                                    // patch pieces per producer thread and slice: slots slot0 + 32 i
-constexpr int CW_NPA = 6;                                    // pieces of load batch A (tap 3); batch B (tap 8) = the rest
-constexpr int CW_NPB = CW_NP - CW_NPA;
 constexpr int CW_MAXN = 512;                                 // output channels whose bias the workgroup keeps in LDS
 constexpr int CW_LDS = 2 * CH_ABUF + CW_RING * CH_BBYTES + CW_MAXN * 4;    // 153 856 B: patches, weight ring, the bias
 constexpr int CW_PITCH = CH_BN * 2 + 16;                     // epilogue tile row: 128 bf16 + 16 B
@@ -50,13 +53,19 @@ static_assert(CW_LDS <= 160 * 1024, "LDS carve");
 // patch pieces processed in the body of tap j (for the NEXT slice)
 __host__ __device__ constexpr int cw_pp(int j) { return j < 3 ? 2 : j < 8 ? 1 : 0; }
 __host__ __device__ constexpr int cw_pp_before(int j) { int s = 0; for (int k = 0; k < j; ++k) s += cw_pp(k); return s; }
-static_assert(cw_pp_before(9) == CW_NP && cw_pp_before(3) == CW_NPA, "piece schedule: batch A is done before tap 3 re-issues it");
+static_assert(cw_pp_before(9) == CW_NP, "piece schedule");
+// operations behind tile u's at the top of unit j: two tiles + what the three bodies before issued behind their tile pieces
+__host__ __device__ constexpr int cw_ntop(int j, int nc) {
+    int n = 8;
+    for (int d = 1; d <= 3; ++d) { const int b = (j + 9 - d) % 9; n += cw_pp(b) + (b == 0 ? nc : 0); }
+    return n;
+}
 
 template <bool GN>
 __global__ __launch_bounds__(768, 1) void conv_halo_ws_k(const ChArgs p) {
     constexpr int MT = 4, NTW = 4;
-    constexpr int NC = GN ? 4 : 0;                           // coefficient loads in batch A
-    constexpr int NA = CW_NPA + NC, NB = CW_NPB;
+    constexpr int NC = GN ? 4 : 0;                           // coefficient loads per slice
+    constexpr int PERIOD = 36 + CW_NP + NC;                  // vector-memory operations of a producer wave per slice
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -160,17 +169,9 @@ __global__ __launch_bounds__(768, 1) void conv_halo_ws_k(const ChArgs p) {
         float gsc[8], gsh[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) { gsc[e] = 1.f; gsh[e] = 0.f; }
-        // (asm operands of a GENERIC lambda cannot name captured variables: the batches are plain lambdas, the counted waits
-        // take their registers as arguments)
-        auto load_A = [&]() {
-#pragma unroll
-            for (int i = 0; i < CW_NPA; ++i)
-                asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(areg[i]) : "v"(pixoff[i]), "s"(rsA), "s"(soffA) : "memory");
-        };
-        auto load_B = [&]() {
-#pragma unroll
-            for (int i = CW_NPA; i < CW_NP; ++i)
-                asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(areg[i]) : "v"(pixoff[i]), "s"(rsA), "s"(soffA) : "memory");
+        // (asm operands of a GENERIC lambda cannot name captured variables: registers and offsets travel as arguments)
+        auto load_piece = [&](u32x4_t& dst, int off) {
+            asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(dst) : "v"(off), "s"(rsA), "s"(soffA) : "memory");
         };
         auto load_coefs = [&]() {
             if constexpr (GN) {
@@ -181,33 +182,19 @@ __global__ __launch_bounds__(768, 1) void conv_halo_ws_k(const ChArgs p) {
             }
         };
         // N vector-memory operations may still be outstanding behind the awaited ones
-        auto landed_A = [](auto n_tag, u32x4_t (&ar)[CW_NP]) {
-            asm volatile("s_waitcnt vmcnt(%6)"
-                         : "+v"(ar[0]), "+v"(ar[1]), "+v"(ar[2]), "+v"(ar[3]), "+v"(ar[4]), "+v"(ar[5])
-                         : "n"(decltype(n_tag)::value));
-        };
-        auto landed_B = [](auto n_tag, u32x4_t (&ar)[CW_NP]) {
-            asm volatile("s_waitcnt vmcnt(%5)"
-                         : "+v"(ar[6]), "+v"(ar[7]), "+v"(ar[8]), "+v"(ar[9]), "+v"(ar[10])
-                         : "n"(decltype(n_tag)::value));
-        };
+        auto piece_landed = [](auto n_tag, u32x4_t& r) { asm volatile("s_waitcnt vmcnt(%1)" : "+v"(r) : "n"(decltype(n_tag)::value)); };
         auto coefs_landed = [](auto n_tag, u32x4_t (&nc)[4]) {
             asm volatile("s_waitcnt vmcnt(%4)" : "+v"(nc[0]), "+v"(nc[1]), "+v"(nc[2]), "+v"(nc[3]) : "n"(decltype(n_tag)::value));
         };
         auto take_coefs = [&](auto n_tag) {                  // the coefficients of the slice processed next: landed, into gsc / gsh
             if constexpr (GN) {
                 coefs_landed(n_tag, ncoef);
-                // real copies, made HERE (asm): the landing registers are rewritten by the next batch A while the copies are
-                // still in use
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    asm volatile("v_mov_b32 %0, %1" : "=v"(gsc[e]) : "v"(ncoef[0][e]));
-                    asm volatile("v_mov_b32 %0, %1" : "=v"(gsc[4 + e]) : "v"(ncoef[1][e]));
-                    asm volatile("v_mov_b32 %0, %1" : "=v"(gsh[e]) : "v"(ncoef[2][e]));
-                    asm volatile("v_mov_b32 %0, %1" : "=v"(gsh[4 + e]) : "v"(ncoef[3][e]));
+                    gsc[e] = __uint_as_float(ncoef[0][e]); gsc[4 + e] = __uint_as_float(ncoef[1][e]);
+                    gsh[e] = __uint_as_float(ncoef[2][e]); gsh[4 + e] = __uint_as_float(ncoef[3][e]);
                 }
             }
-            mask_proc = mask_ld;
         };
         // four dummy operations in the place of a tile that does not exist (out of range: they return zeros).  Their
         // destination is ONE register reserved for the whole walk: a load lands whenever it lands, and a register the compiler
@@ -251,27 +238,32 @@ __global__ __launch_bounds__(768, 1) void conv_halo_ws_k(const ChArgs p) {
             if (K < CW_NP - 1 || last_ok) asm volatile("ds_write_b128 %0, %1" ::"v"(dst), "v"(t) : "memory");
         };
         using I0 = std::integral_constant<int, 0>;
+        using PieceWait = std::integral_constant<int, PERIOD - 1>;
+        using CoefWait = std::integral_constant<int, CW_NP + 32>;       // behind C: the eleven re-loads and T1..T8
 
-        // ---- prologue: slice 0's patch (whole), then the op stream of a slice body from its batch A on
+        // ---- prologue: slice 0's patch (whole), then one period of the op stream as "slice -1" would have issued it: slice 1's
+        // coefficients and pieces, out-of-range loads for the tiles that do not exist, the tiles of units 0, 1, 2
         SliceD d0 = desc(0);
         set_patch(d0);
         load_coefs();
-        load_A(); load_B();
+        ch_static_for<0, CW_NP>([&](auto k_tag) { load_piece(areg[decltype(k_tag)::value], pixoff[decltype(k_tag)::value]); });
         take_coefs(std::integral_constant<int, CW_NP>{});
-        landed_A(std::integral_constant<int, CW_NPB>{}, areg);
-        landed_B(I0{}, areg);
+        ch_static_for<0, CW_NP>([&](auto k_tag) { piece_landed(I0{}, areg[decltype(k_tag)::value]); });
+        mask_proc = mask_ld;
         ch_static_for<0, CW_NP>([&](auto k_tag) { piece(k_tag, 0); });
         {
             SliceD d1 = desc(1);
             set_patch(d1);
-            load_coefs();                                    // A
-            load_A();
-            dummy4(); dummy4();                              // T4 T5
-            tile(d0.wsoff, 0);                               // T6 T7 T8: the tiles of units 0, 1, 2
-            tile(d0.wsoff + 1 * p.Kc * 2, 1);
-            tile(d0.wsoff + 2 * p.Kc * 2, 2);
-            load_B();                         // B
-            take_coefs(std::integral_constant<int, 20 + NB>{});
+            ch_static_for<0, 9>([&](auto j_tag) {
+                constexpr int j = decltype(j_tag)::value;
+                if constexpr (j < 6) dummy4();
+                else tile(d0.wsoff + (j - 6) * p.Kc * 2, j - 6);
+                if constexpr (j == 0) load_coefs();
+                ch_static_for<cw_pp_before(j), cw_pp_before(j) + cw_pp(j)>([&](auto k_tag) {
+                    load_piece(areg[decltype(k_tag)::value], pixoff[decltype(k_tag)::value]);
+                });
+            });
+            take_coefs(CoefWait{});
         }
 
         // ---- the walk
@@ -281,9 +273,8 @@ __global__ __launch_bounds__(768, 1) void conv_halo_ws_k(const ChArgs p) {
             const int nbuf = (g + 1) & 1;
             ch_static_for<0, 9>([&](auto j_tag) {
                 constexpr int j = decltype(j_tag)::value;
-                // tile u landed (operations behind it: two tiles, batch B behind taps 0-2, batch A behind taps 4-6), this
-                // wave's patch writes done
-                constexpr int NTOP = 8 + (j >= 4 && j <= 6 ? NA : 0) + (j <= 2 ? NB : 0);
+                // tile u landed, this wave's patch writes done
+                constexpr int NTOP = cw_ntop(j, NC);
 #if CW_ABL & 32
                 asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)" ::"n"(NTOP) : "memory");
 #else
@@ -294,15 +285,20 @@ __global__ __launch_bounds__(768, 1) void conv_halo_ws_k(const ChArgs p) {
                 if constexpr (j + 3 < 9) tile(dc.wsoff + (j + 3) * p.Kc * 2, slot);
                 else if (v1) tile(dn.wsoff + (j + 3 - 9) * p.Kc * 2, slot);
                 else dummy4();
-                // the pieces of this tap's body (loaded a slice ago): batch A behind T4..T8, B and T0..Tj, batch B behind T0..T3
-                if constexpr (j == 0) landed_A(std::integral_constant<int, 20 + NB + 4>{}, areg);
-                if constexpr (j == 3) landed_B(std::integral_constant<int, 16>{}, areg);
-                if (v1) {
-                    ch_static_for<cw_pp_before(j), cw_pp_before(j) + cw_pp(j)>([&](auto k_tag) { piece(k_tag, nbuf); });
+                if constexpr (j == 0) {
+                    // the pieces in the registers are slice g + 1's (mask of a slice ago); from here on they are re-loaded for g + 2
+                    mask_proc = mask_ld;
+                    set_patch(dl);
+                    load_coefs();                            // C
                 }
-                if constexpr (j == 2) set_patch(dl);
-                if constexpr (j == 3) { load_coefs(); load_A(); }                    // A (slice g + 2)
-                if constexpr (j == 8) { load_B(); take_coefs(std::integral_constant<int, 20 + NB>{}); }   // B
+                // this body's pieces: landed (a period ago) -> GroupNorm -> the other patch buffer -> re-load for slice g + 2
+                ch_static_for<cw_pp_before(j), cw_pp_before(j) + cw_pp(j)>([&](auto k_tag) {
+                    constexpr int K = decltype(k_tag)::value;
+                    piece_landed(PieceWait{}, areg[K]);
+                    if (v1) piece(k_tag, nbuf);
+                    load_piece(areg[K], pixoff[K]);
+                });
+                if constexpr (j == 8) take_coefs(CoefWait{});
             });
             if (dc.kc == nkc - 1 && g + 1 < nslices) {
                 for (int b = 0; b < nb_epi; ++b) asm volatile("s_barrier" ::: "memory");
