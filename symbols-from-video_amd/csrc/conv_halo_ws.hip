@@ -222,13 +222,36 @@ __global__ __launch_bounds__(768, 1) void conv_halo_ws_k(const ChArgs p) {
 #endif
             u32x4_t t = areg[K];
             if constexpr (GN) {
+                // conv_halo_k's arithmetic element for element (fma; x * rcp(1 + exp2(-log2e x)); round to bf16), written on
+                // PAIRS so that it compiles to packed f32 instructions: the producers are the critical path of a GroupNorm layer
+                // (without the patch work it runs 26 % faster), and what they contend for with the MFMA waves of their SIMD is
+                // the vector issue port -- the instruction COUNT (sharing one reciprocal between four elements, fewer
+                // quarter-rate but more plain instructions, made it slower).
+                typedef float v2f __attribute__((ext_vector_type(2)));
+                typedef __bf16 v2b __attribute__((ext_vector_type(2)));
                 const u32x4_t v = t;
-                bf16_t* ev = (bf16_t*)&t;
+                v2f x[4];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    float x = fmaf(Elem<bf16_t>::load(ev + e), gsc[e], gsh[e]);
-                    if (p.gn_swish) x = x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504f * x));
-                    Elem<bf16_t>::store(ev + e, x);
+                for (int q = 0; q < 4; ++q) {
+                    const v2f in = {__uint_as_float(v[q] << 16), __uint_as_float(v[q] & 0xffff0000u)};
+                    const v2f sc = {gsc[2 * q], gsc[2 * q + 1]}, sh = {gsh[2 * q], gsh[2 * q + 1]};
+                    x[q] = __builtin_elementwise_fma(in, sc, sh);
+                }
+                if (p.gn_swish) {                                   // a branch, not eight selects (uniform)
+                    asm volatile("" ::: "memory");
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        v2f e = x[q] * -1.44269504f;
+                        e.x = __builtin_amdgcn_exp2f(e.x); e.y = __builtin_amdgcn_exp2f(e.y);
+                        v2f d = e + 1.0f;
+                        d.x = __builtin_amdgcn_rcpf(d.x); d.y = __builtin_amdgcn_rcpf(d.y);
+                        x[q] = x[q] * d;
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const v2b r = __builtin_convertvector(x[q], v2b);      // v_cvt_pk_bf16_f32: round to nearest even, both halves
+                    t[q] = __builtin_bit_cast(unsigned, r);
                 }
                 const bool real = (mask_proc >> K) & 1u;
 #pragma unroll
