@@ -610,6 +610,9 @@ static int dispatch_gg(const GgArgs& a, hipStream_t st, int max_steps) {
     constexpr int dbg = 0;
     int ns = max_steps <= 2 ? 1 : (blocks > 256 ? 2 : 3);
     if (force) ns = force;
+    // one workgroup per CU and a deep K (the 256-channel convolutions at 256 frames): a ring of FOUR, three slices in flight --
+    // a K step of the 128 x 128 tile is ~0.27 us, two of them are less lead than an L2 miss takes (bench step -0.6 %, same box)
+    if (ns == 3 && blocks > 128 && max_steps >= 8) ns = 4;
     // a deep-K product with few rows and <= 64 columns (the LDM encoder's conv_out: 16 384 rows, K = 4608, 8 columns): 64-row
     // tiles put a workgroup on every CU instead of on half of them (55 -> 30 us)
     if (a.Nout <= 64 && blocks <= 128 && max_steps >= 16 && sizeof(T) == 2 && !a.colsum_ws && !a.xcd_order)
