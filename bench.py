@@ -134,8 +134,8 @@ def roofline_leg(trainer, steps, tname, overlap):
     host's launch latency, and the cost of an empty event pair is measured the same way and subtracted.
 
       gather_gemm_k<T,2,4,3,64-row tile>  64x64 tiles, deep K, 4096 rows: conv3 forward, first deconv's input gradient
-      gather_gemm_k<T,4,8,3>  128x128 row-gather GEMM, deep K, 129..256 workgroups: conv2 forward, first deconv
-                              forward (4 parity classes) and their two input-gradient twins
+      gather_gemm_k<T,4,8,4>  128x128 row-gather GEMM, deep K, 129..256 workgroups, ring of four LDS-DMA stages: conv2
+                              forward, first deconv forward (4 parity classes) and their two input-gradient twins
       wgrad_row_k             3x3 stride-2 weight gradient, the three taps of a kernel row per workgroup (csrc/wgrad_row.hip)
       wgrad_gemm_k<T,2,3>     128x128 weight-gradient GEMM with K split over workgroups: the other 256-channel ones
     Algorithmic FLOPs: 2 * output rows * Nout * Kc * taps for the gather GEMM (the 4 parity classes of a
@@ -169,7 +169,8 @@ def roofline_leg(trainer, steps, tname, overlap):
         elif blocks <= 128:
             name = "gather_gemm_k<%s, 2, 4, 3>" % tname
         else:
-            name = "gather_gemm_k<%s, 4, 8, 3>" % tname
+            # (one workgroup per CU: a ring of four stages when the K loop has at least eight steps, else three)
+            name = "gather_gemm_k<%s, 4, 8, %d>" % (tname, 4 if max_taps * (kc // ke) >= 8 else 3)
         rows, t_eff = (nimg * th * tw * 4, taps / 4.0) if cls_key == "dgrad" else (nimg * th * tw, float(taps))
         with timers.setdefault(name, KernelTimer())(2.0 * rows * nout * kc * t_eff):
             return orig_gemm(*args, **kw)

@@ -97,7 +97,7 @@ __global__ __launch_bounds__(768, 1) void conv_halo_ws_k(const ChArgs p) {
         const int tr = trc / tcn, tc = trc - tr * tcn;
         r0 = tr * CH_T; c0 = tc * CH_T; n0 = ntile * CH_BN;
     };
-    const int nb_epi = 4 + (p.stats ? 3 : 0);                // barriers of a tile's epilogue
+    const int nb_epi = 4 + (p.stats ? 2 : 0);                // barriers of a tile's epilogue
 
     if (w >= 8) {
         // =========================== producer waves ===========================
@@ -543,8 +543,6 @@ __global__ __launch_bounds__(768, 1) void conv_halo_ws_k(const ChArgs p) {
             float* r_sum = (float*)tile;                       // [8 waves][BN]
             float* r_m2 = r_sum + 8 * CH_BN;                   // [8][BN]
             float* r_cnt = r_m2 + 8 * CH_BN;                   // [8]
-            float* c_mean = r_cnt + 8;                         // [BN] channel means, then [BN + 1] channel M2 and the count
-            float* c_m2 = c_mean + CH_BN;
             if (lane < 16) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
@@ -554,7 +552,7 @@ __global__ __launch_bounds__(768, 1) void conv_halo_ws_k(const ChArgs p) {
                 if (lane == 0) r_cnt[w] = fcnt;
             }
             ch_lds_barrier();
-            const int cg = p.stats_cg, ng = CH_BN / cg;
+            const int cg = p.stats_cg;
             if (tid < CH_BN) {
                 float S = 0.f, N = 0.f;
 #pragma unroll
@@ -567,23 +565,22 @@ __global__ __launch_bounds__(768, 1) void conv_halo_ws_k(const ChArgs p) {
                     const float d = nk > 0.f ? r_sum[kq * CH_BN + tid] / nk - mean : 0.f;
                     M2 += r_m2[kq * CH_BN + tid] + nk * d * d;
                 }
-                c_mean[tid] = mean;
-                c_m2[tid] = M2;
-                if (tid == 0) c_m2[CH_BN] = N;
-            }
-            ch_lds_barrier();
-            if (tid < ng) {
-                const float N = c_m2[CH_BN];
+                // group = cg adjacent channels = cg adjacent lanes of this wave: every lane sums its group's channels in channel
+                // order through lane reads (conv_halo_k's sums in conv_halo_k's order, without its third barrier and the
+                // latency-bound loop of 32 threads over LDS)
+                const int gl0 = (lane / cg) * cg;
                 float gm = 0.f;
-                for (int c = 0; c < cg; ++c) gm += c_mean[tid * cg + c];
+                for (int c = 0; c < cg; ++c) gm += __int_as_float(__builtin_amdgcn_ds_bpermute((gl0 + c) << 2, __float_as_int(mean)));
                 gm /= (float)cg;
                 float gM2 = 0.f;
                 for (int c = 0; c < cg; ++c) {
-                    const float d = c_mean[tid * cg + c] - gm;
-                    gM2 += c_m2[tid * cg + c] + N * d * d;
+                    const float mc = __int_as_float(__builtin_amdgcn_ds_bpermute((gl0 + c) << 2, __float_as_int(mean)));
+                    const float qc = __int_as_float(__builtin_amdgcn_ds_bpermute((gl0 + c) << 2, __float_as_int(M2)));
+                    const float d = mc - gm;
+                    gM2 += qc + N * d * d;
                 }
                 const int Gn = p.Nout / cg;
-                ((float2*)p.stats)[(size_t)mtile * Gn + n0 / cg + tid] = make_float2(gm, gM2);
+                if (lane == gl0) ((float2*)p.stats)[(size_t)mtile * Gn + n0 / cg + tid / cg] = make_float2(gm, gM2);
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the scratch is a patch buffer again behind the next barrier
         }
@@ -603,7 +600,8 @@ __global__ __launch_bounds__(768, 1) void conv_halo_ws_k(const ChArgs p) {
 bool ch_ws_covers(const ChArgs& a) {
     const long lim = 1l << 31;
     return (long)a.Nimg * a.IH * a.IW * a.lda * 2 < lim && (long)a.Nout * 9 * a.Kc * 2 < lim && (long)a.Nimg * a.Kc * 4 < lim &&
-           (long)a.Nimg * a.OH * a.OW * a.ldo * 2 < lim && a.Kc % 64 == 0 && a.Nout <= CW_MAXN;
+           (long)a.Nimg * a.OH * a.OW * a.ldo * 2 < lim && a.Kc % 64 == 0 && a.Nout <= CW_MAXN &&
+           (!a.stats || (a.stats_cg <= 64 && 64 % a.stats_cg == 0));       // a statistics group within one wave's lanes
 }
 
 int launch_ch_ws(const ChArgs& a, hipStream_t st) {
