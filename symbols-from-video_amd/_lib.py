@@ -97,6 +97,21 @@ DBG_LIB_PATH = os.path.join(HERE, "librbvae_dbg.so")
 _dbg = None
 
 
+def dbg_lib():
+    """librbvae_dbg.so itself (for the hooks that take no stream, e.g. rbvae_dbg_conv_halo_variant)."""
+    global _dbg
+    if _dbg is None:
+        lib()                                   # the probes resolve rbvae::fail (and the hooks their switches) from the main library
+        l = ctypes.CDLL(DBG_LIB_PATH)
+        for n, (restype, a) in parse_header(DBG_HEADER).items():
+            fn = getattr(l, n, None)            # the stamp hooks exist in stamped builds of the main library only
+            if fn is not None:
+                fn.restype = restype
+                fn.argtypes = [t for t, _ in a]
+        _dbg = l
+    return _dbg
+
+
 def dbg_call(name, *args):
     """Call a hardware-map probe of librbvae_dbg.so on torch's current stream."""
     global _dbg

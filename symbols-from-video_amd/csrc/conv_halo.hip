@@ -583,7 +583,9 @@ static int launch_ch(const ChArgs& a, hipStream_t st) {
 
 using namespace rbvae;
 
-static int ch_variant = 2;
+// which kernel the bf16 dispatch takes: 2 auto (product), 1 conv_halo_k always, 0 the persistent kernel wherever it covers.
+// Written only by librbvae_dbg's rbvae_dbg_conv_halo_variant (include/rbvae_dbg.h: bit-identity tests, A/B timing).
+namespace rbvae { int ch_variant = 2; }
 
 extern "C" int rbvae_conv3x3_halo_ok(int dtype, int IH, int IW, int OH, int OW, int Kc, int Nout) {
     const int KE = dtype == RBVAE_F32 ? 32 : 64;
@@ -630,13 +632,6 @@ extern "C" int rbvae_conv3x3_halo(int dtype, const void* A, const void* W, void*
     const bool ws_auto = a.total >= 512;
     if ((ch_variant == 0 || (ch_variant == 2 && ws_auto)) && ch_ws_covers(a)) return launch_ch_ws(a, st);
     return gn_scale ? launch_ch<bf16_t, 3, true>(a, st) : launch_ch<bf16_t, 3, false>(a, st);
-}
-
-/* include/rbvae_dbg.h: 2 = the product dispatch (auto), 1 = conv_halo_k always, 0 = the persistent kernel wherever it covers (bit-identity tests, A/B timing) */
-extern "C" int rbvae_dbg_conv_halo_variant(int v) {
-    const int old = ch_variant;
-    ch_variant = v;
-    return old;
 }
 
 extern "C" size_t rbvae_conv3x3_halo_stats_floats(int Nimg, int OH, int OW, int Nout, int cg) {

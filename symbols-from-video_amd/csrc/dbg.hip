@@ -75,3 +75,11 @@ int rbvae_dbg_tr16(const void* img, const int* rowsel, const int* colsel, void* 
     return RBVAE_OK;
 }
 }
+
+// which kernel rbvae_conv3x3_halo (librbvae_hip) runs for bf16: see include/rbvae_dbg.h; returns the previous value
+namespace rbvae { extern int ch_variant; }
+extern "C" int rbvae_dbg_conv_halo_variant(int v) {
+    const int old = rbvae::ch_variant;
+    rbvae::ch_variant = v;
+    return old;
+}

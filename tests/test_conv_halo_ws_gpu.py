@@ -21,7 +21,7 @@ def sfv():
 def run(sfv, variant, A, Wp, out, bias, addend, N, H, W, cin, cout, scale=None, shift=None, swish=0, stats=None, cg=0, pad=(1, 1),
         OH=None, OW=None):
     zero = torch.zeros(256, dtype=torch.uint8, device="cuda")
-    l = sfv._lib.lib()
+    l = sfv._lib.dbg_lib()
     old = l.rbvae_dbg_conv_halo_variant(variant)          # 1: one tile per workgroup, 0: persistent wherever it covers
     try:
         sfv._lib.call("rbvae_conv3x3_halo", 1, A, Wp, out, bias, addend, zero, scale, shift, swish, stats, cg, N, H, W,

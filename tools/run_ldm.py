@@ -6,7 +6,7 @@ torch.manual_seed(0)
 m = sfv.LDMEncoder(compute_dtype="bf16", use_graph=bool(int(os.environ.get("LDM_GRAPH", "0")))).cuda()
 shapes = [(int(a.split("x")[0]), int(a.split("x")[1])) for a in sys.argv[1:]] or [(8, 256), (4, 512)]     # e.g. 4x512
 if "LDM_HALO_VARIANT" in os.environ:        # A/B of rbvae_conv3x3_halo's kernels (include/rbvae_dbg.h): 1 one tile per workgroup, 0 persistent, 2 auto
-    sfv._lib.lib().rbvae_dbg_conv_halo_variant(int(os.environ["LDM_HALO_VARIANT"]))
+    sfv._lib.dbg_lib().rbvae_dbg_conv_halo_variant(int(os.environ["LDM_HALO_VARIANT"]))
 for (N, S) in shapes:
     x = torch.rand(N, 3, S, S, device="cuda") * 2 - 1
     for _ in range(2): m.encode(x, sample=False)

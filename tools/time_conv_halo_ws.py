@@ -9,7 +9,7 @@ import torch
 import sfv_amd as sfv
 
 L = sfv._lib
-lib = L.lib()
+lib = L.dbg_lib()
 zero = torch.zeros(256, dtype=torch.uint8, device="cuda")
 
 
