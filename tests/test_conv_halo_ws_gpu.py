@@ -43,6 +43,8 @@ CASES = [
     (9, 64, 128, 80, 80, 0, 0, 0, 1, 1),          # 9 x 25 = 225 tiles of ONE slice (a tile per slice: buffers alternate per tile)
     (20, 64, 128, 64, 80, 1, 1, 1, 0, 1),         # 400 one-slice tiles: walks of one and two tiles
     (4, 192, 128, 48, 48, 1, 1, 0, 0, 1),         # three slices (odd): the epilogue's buffer alternates between tiles
+    (12, 64, 128, 128, 128, 1, 1, 1, 1, 1),       # 768 one-slice tiles: three per workgroup (the product dispatch's territory)
+    (4, 128, 256, 256, 192, 1, 1, 1, 1, 1),       # 4 x 16 x 12 x 2 = 1536 items of two slices: six per workgroup, both channel tiles
 ]
 
 
