@@ -58,7 +58,7 @@ ISA_CHECKED = {
     "wgrad_halo.hip": ("_ZN5rbvae12wgrad_halo_k", ("ds_read_b64_tr_b16",)),
     "wgrad_row.hip": ("_ZN5rbvae11wgrad_row_k", ("ds_read_b64_tr_b16",)),
     "conv_s2.hip": ("_ZN5rbvae9conv_s2_k", ("ds_read_b128",)),
-    "conv_first.hip": ("_ZN5rbvae13wgrad_first_k", ("ds_read_b64_tr_b16",)),
+    "conv_first.hip": (("_ZN5rbvae13wgrad_first_k", "_ZN5rbvae18wgrad_first_wide_k"), ("ds_read_b64_tr_b16",)),
 }
 
 
@@ -79,10 +79,12 @@ def _check_asm_reads(src):
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"hipcc -S failed on {src}:\n{r.stderr}")
-    prefix, ops = ISA_CHECKED[src]
-    bad = mod.tr_asm_hazards(open(asm).read(), prefix, ops)
-    if src in ASM_VMEM_LOADS:
-        bad += mod.asm_vmem_load_hazards(open(asm).read(), prefix, ASM_VMEM_LOADS[src])
+    prefixes, ops = ISA_CHECKED[src]
+    bad = []
+    for prefix in ((prefixes,) if isinstance(prefixes, str) else prefixes):
+        bad += mod.tr_asm_hazards(open(asm).read(), prefix, ops)
+        if src in ASM_VMEM_LOADS:
+            bad += mod.asm_vmem_load_hazards(open(asm).read(), prefix, ASM_VMEM_LOADS[src])
     if bad:
         raise RuntimeError(src + " ISA check failed (fragment register touched before its wait):\n" + "\n".join(bad[:20]))
 

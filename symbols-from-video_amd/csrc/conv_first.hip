@@ -486,12 +486,217 @@ template <int CIN, int MODE> __global__ __launch_bounds__(512, 4) void wgrad_fir
     *(f32x4_t*)(slab + (nt0 + 1) * 16) = acc1;
 }
 
+// The same sums for layers of 256 (512, ...) output channels with ALL 256 channels of a pixel block in one workgroup.
+// wgrad_first_k gives every 64-channel tile its own workgroup, and each of them loads the block's patch and rebuilds its
+// im2col rows: at Nout = 256 four workgroups do that work for every block, and it -- LDS reads of the patch, conversions, the
+// swizzled row writes -- not the HBM stream is what the kernel runs at (staging its operands two blocks ahead changed nothing,
+// DESIGN.md 5).  Here the rows are built once per block and multiplied with the four [128 px][64 co] images of the dY tile
+// (each in wgrad_first_k's layout: the same fragment addressing with an image offset).  Both operands travel through
+// registers two blocks ahead (two register sets for the even / odd blocks of the walk; every load branch-free, so the
+// compiler's counted waits hold); one workgroup per CU (153 KB of LDS); rbvae_wgrad_gemm's slab layout.
+constexpr int WFW_LDS = 16384 + 2 * 4 * 16384 + 4 * CF_PA * CF_PP * 4;
+template <int CIN, int MODE> __global__ __launch_bounds__(512, 2) void wgrad_first_wide_k(const WfArgs p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char wsm[];
+    unsigned char* s_col = wsm;                                   // im2col rows [px][64 k], tr-swizzled
+    unsigned char* s_dy = wsm + 16384;                            // [2 buffers][4 channel tiles][128 px][64 co], tr-swizzled
+    float* s_patch = (float*)(wsm + 16384 + 2 * 4 * 16384);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nct = p.Nout >> 8;
+    const int cot = blockIdx.x % nct, ks = blockIdx.x / nct;
+    const int co0 = cot * 256;
+    const int tb_n = (p.OW + CF_TB - 1) / CF_TB, ta_n = (p.OH + CF_TA - 1) / CF_TA;
+    const int blk0 = ks * p.per, blk1 = min(blk0 + p.per, p.nblk);
+    static constexpr CfOff<CIN, MODE> otab{};
+    int koff[8];
+#pragma unroll
+    for (int k8 = 0; k8 < 8; ++k8) koff[k8] = otab.v[(tid & 7) * 8 + k8];
+
+    constexpr int R0 = CIN * CF_PA, PIT0 = ((R0 + 1) / 2 + 7) / 8;
+    constexpr int RUN = CF_PB * CIN, PN = CF_PA * RUN, PIT1 = (PN + 511) / 512;
+    constexpr int PIT = MODE == 0 ? PIT0 : PIT1;
+    struct Stage { float pv[PIT]; float hv; u32x4_t dy[8]; };
+    auto load_block = [&](int blk_, Stage& st) {
+        unsigned b = (unsigned)min(blk_, blk1 - 1);                       // (past the end: the last block again, never used)
+        const int tbi = b % (unsigned)tb_n; b /= (unsigned)tb_n;
+        const int tai = b % (unsigned)ta_n;
+        const int n = b / (unsigned)ta_n;
+        const int ih0 = 2 * tai * CF_TA - 1, iw0 = 2 * tbi * CF_TB - 1;
+        if constexpr (MODE == 0) {
+            const float* xf = p.x + cf_frame_off(p.fm, n);
+#pragma unroll
+            for (int it = 0; it < PIT; ++it) {
+                const int row = 2 * (w + 8 * it) + (lane >> 5);
+                const int c = row / CF_PA, r = row - c * CF_PA;
+                const int ih = ih0 + r, iw = iw0 + 1 + (lane & 31);
+                const bool ok = row < R0 && ih >= 0 && ih < p.IH && iw < p.IW;
+                const float v = xf[ok ? ((size_t)c * p.IH + ih) * p.IW + iw : 0];
+                st.pv[it] = ok ? v : 0.f;
+            }
+            {
+                const int c = tid / CF_PA, r = tid - c * CF_PA;
+                const int ih = ih0 + r;
+                const bool ok = tid < R0 && ih >= 0 && ih < p.IH && iw0 >= 0;
+                const float v = xf[ok ? ((size_t)c * p.IH + ih) * p.IW + iw0 : 0];
+                st.hv = ok ? v : 0.f;
+            }
+        } else {
+            const float* xf = p.x + (size_t)n * p.IH * p.IW * CIN;
+#pragma unroll
+            for (int it = 0; it < PIT; ++it) {
+                const int i = it * 512 + tid;
+                const int r = i / RUN, j = i - r * RUN;
+                const int ih = ih0 + r, iw = iw0 + j / CIN;
+                const bool ok = i < PN && ih >= 0 && ih < p.IH && iw >= 0 && iw < p.IW;
+                const float v = xf[ok ? ((long)ih * p.IW + iw0) * CIN + j : 0];
+                st.pv[it] = ok ? v : 0.f;
+            }
+            st.hv = 0.f;
+        }
+        // the dY tile: thread -> pixel rows (2 w + i2) * 8 + lane / 8, swizzled 16-byte chunk lane % 8 of channel tile q
+#pragma unroll
+        for (int i2 = 0; i2 < 2; ++i2) {
+            const int r = (2 * w + i2) * 8 + (lane >> 3);
+            const int oh = tai * CF_TA + (r >> 4), ow = tbi * CF_TB + (r & 15);
+            const bool v = oh < p.OH && ow < p.OW;
+            const unsigned char* src = p.dY + ((size_t)(n * p.OH + oh) * p.OW + ow) * ((size_t)p.ldy * 2) + co0 * 2 +
+                                       (((lane & 7) ^ wf_swz(r)) * 16);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) st.dy[q * 2 + i2] = *(const u32x4_t*)(v ? src + q * 128 : p.zero);
+        }
+    };
+    auto store_block = [&](const Stage& st, int buf) {
+        if constexpr (MODE == 0) {
+#pragma unroll
+            for (int it = 0; it < PIT; ++it) {
+                const int row = 2 * (w + 8 * it) + (lane >> 5);
+                if (row < R0) s_patch[row * CF_PP + 1 + (lane & 31)] = st.pv[it];
+            }
+            if (tid < R0) s_patch[tid * CF_PP] = st.hv;
+        } else {
+#pragma unroll
+            for (int it = 0; it < PIT; ++it) {
+                const int i = it * 512 + tid;
+                const int r = i / RUN, j = i - r * RUN;
+                if (i < PN) s_patch[r * (CF_PP * CIN) + j] = st.pv[it];
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int i2 = 0; i2 < 2; ++i2)
+                *(u32x4_t*)(s_dy + (buf * 4 + q) * 16384 + (2 * w + i2) * 1024 + lane * 16) = st.dy[q * 2 + i2];
+    };
+
+    // consumer: wave w = co sub-tile w & 3 of EVERY channel tile x the k sub-tiles 2 (w >> 2), 2 (w >> 2) + 1
+    const int fi = lane & 15, fg = lane >> 4;
+    const int qq = fi >> 2, pp = fi & 3;
+    const int mt = w & 3, nt0 = (w >> 2) * 2;
+    const int row0 = 8 * fg + qq;
+    const int offA = row0 * 128 + (((mt * 2 + (pp >> 1)) ^ wf_swz(row0)) * 16) + (pp & 1) * 8;
+    const int offB0 = row0 * 128 + (((nt0 * 2 + (pp >> 1)) ^ wf_swz(row0)) * 16) + (pp & 1) * 8;
+    const int offB1 = row0 * 128 + ((((nt0 + 1) * 2 + (pp >> 1)) ^ wf_swz(row0)) * 16) + (pp & 1) * 8;
+    f32x4_t acc[4][2];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { acc[q][0] = f32x4_t{0.f, 0.f, 0.f, 0.f}; acc[q][1] = acc[q][0]; }
+    const unsigned l_col = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)s_col;
+    const unsigned l_dy = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)s_dy;
+
+    auto block = [&](int blk, Stage& st, int buf) {
+        store_block(st, buf);
+        load_block(blk + 2, st);
+        wf_lds_barrier();
+        // im2col rows: 128 rows x 8 chunks of 8 columns
+#pragma unroll
+        for (int i0 = 0; i0 < 128 * 8; i0 += 512) {
+            const int i = i0 + tid;
+            const int r = i >> 3, c = i & 7;
+            const int oy = r >> 4, ox = r & 15;
+            const int corner = (2 * oy * CF_PP + 2 * ox) * (MODE == 0 ? 1 : CIN);
+            unsigned short e[8];
+#pragma unroll
+            for (int k8 = 0; k8 < 8; ++k8) {
+                const float v = koff[k8] >= 0 ? s_patch[corner + max(koff[k8], 0)] : 0.f;
+                e[k8] = f32_to_bf16(v);
+            }
+            u32x4_t pk;
+            pk[0] = (unsigned)e[0] | ((unsigned)e[1] << 16); pk[1] = (unsigned)e[2] | ((unsigned)e[3] << 16);
+            pk[2] = (unsigned)e[4] | ((unsigned)e[5] << 16); pk[3] = (unsigned)e[6] | ((unsigned)e[7] << 16);
+            *(u32x4_t*)(s_col + r * 128 + ((c ^ wf_swz(r)) * 16)) = pk;
+        }
+        wf_lds_barrier();
+        const unsigned la = l_dy + buf * (4 * 16384);
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) {
+            s16x4_t al[4], ah[4], b0l, b0h, b1l, b1h;
+            const unsigned ada = la + offA + kb * (32 * 128), adb0 = l_col + offB0 + kb * (32 * 128), adb1 = l_col + offB1 + kb * (32 * 128);
+            asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(b0l) : "v"(adb0));
+            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:512" : "=v"(b0h) : "v"(adb0));
+            asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(b1l) : "v"(adb1));
+            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:512" : "=v"(b1h) : "v"(adb1));
+            asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(al[0]) : "v"(ada));
+            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:512" : "=v"(ah[0]) : "v"(ada));
+            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:16384" : "=v"(al[1]) : "v"(ada));
+            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:16896" : "=v"(ah[1]) : "v"(ada));
+            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:32768" : "=v"(al[2]) : "v"(ada));
+            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:33280" : "=v"(ah[2]) : "v"(ada));
+            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:49152" : "=v"(al[3]) : "v"(ada));
+            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:49664" : "=v"(ah[3]) : "v"(ada));
+            asm volatile("s_waitcnt lgkmcnt(0)"
+                         : "+v"(b0l), "+v"(b0h), "+v"(b1l), "+v"(b1h), "+v"(al[0]), "+v"(ah[0]), "+v"(al[1]), "+v"(ah[1]), "+v"(al[2]),
+                           "+v"(ah[2]), "+v"(al[3]), "+v"(ah[3]));
+            const bf16x8_t fb0 = bf16x8_t{b0l[0], b0l[1], b0l[2], b0l[3], b0h[0], b0h[1], b0h[2], b0h[3]};
+            const bf16x8_t fb1 = bf16x8_t{b1l[0], b1l[1], b1l[2], b1l[3], b1h[0], b1h[1], b1h[2], b1h[3]};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const bf16x8_t fa = bf16x8_t{al[q][0], al[q][1], al[q][2], al[q][3], ah[q][0], ah[q][1], ah[q][2], ah[q][3]};
+                acc[q][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb0, fa, acc[q][0], 0, 0, 0);
+                acc[q][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb1, fa, acc[q][1], 0, 0, 0);
+            }
+        }
+        wf_lds_barrier();                                                // everyone is done with s_patch / s_col / this dY buffer
+    };
+    if (blk0 < blk1) {
+        Stage sa, sb;
+        load_block(blk0, sa);
+        load_block(blk0 + 1, sb);
+        for (int blk = blk0; blk < blk1; blk += 2) {
+            block(blk, sa, 0);
+            if (blk + 1 < blk1) block(blk + 1, sb, 1);
+        }
+    }
+    // D[row = k 4 fg + r][col = co fi]: a lane owns 4 consecutive k of one co
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        float* slab = p.dW + ((size_t)ks * p.Nout + co0 + q * 64 + mt * 16 + fi) * 64 + 4 * fg;
+        *(f32x4_t*)(slab + nt0 * 16) = acc[q][0];
+        *(f32x4_t*)(slab + (nt0 + 1) * 16) = acc[q][1];
+    }
+}
+
 static int wf_shape_ok(int dtype, int Cin, int IH, int IW, int Nout, int N) {
     const int OH = (IH + 2 - 3) / 2 + 1, OW = (IW + 2 - 3) / 2 + 1;
     return dtype == RBVAE_BF16 && Cin >= 1 && Cin <= 4 && Nout >= 64 && Nout % 64 == 0 && N >= 1 && IH >= 1 && IW >= 1 &&
            (long)N * OH * OW * 256 < (1l << 31) && (long)N * Cin * IH * IW < (1l << 40);
 }
+template <int CIN, int MODE> static void wf_launch_wide(const WfArgs& a, hipStream_t st) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)wgrad_first_wide_k<CIN, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, WFW_LDS);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((wgrad_first_wide_k<CIN, MODE>), dim3((a.Nout / 256) * a.ksplit), dim3(512), WFW_LDS, st, a);
+}
 template <int MODE> static void wf_launch(const WfArgs& a, hipStream_t st) {
+    if (a.Nout % 256 == 0) {           // all 256 channels of a block in one workgroup: the im2col rows are built once, not four times
+        switch (a.Cin) {
+            case 1: wf_launch_wide<1, MODE>(a, st); break;
+            case 2: wf_launch_wide<2, MODE>(a, st); break;
+            case 3: wf_launch_wide<3, MODE>(a, st); break;
+            default: wf_launch_wide<4, MODE>(a, st); break;
+        }
+        return;
+    }
     const int blocks = (a.Nout / 64) * a.ksplit;
     switch (a.Cin) {
         case 1: hipLaunchKernelGGL((wgrad_first_k<1, MODE>), dim3(blocks), dim3(512), 0, st, a); break;

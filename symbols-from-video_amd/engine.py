@@ -574,7 +574,10 @@ class Engine:
         nblk = L.query("rbvae_wgrad_first_blocks", self.dt, Cin, IH, IW, Nout, N)
         if nblk == 0:
             return 0
-        ks = max(1, min(512 // (Nout // 64), nblk))            # two workgroups per CU
+        if Nout % 256 == 0:
+            ks = max(1, min(256 // (Nout // 256), nblk))       # all 256 channels of a block in one workgroup, one workgroup per CU
+        else:
+            ks = max(1, min(512 // (Nout // 64), nblk))        # two workgroups per CU
         return ks if nblk // ks >= self._wf_min_steps else 0
 
     def _wgrad_first(self, mode, x, fm, Dy, N, Cin, IH, IW, Nout, ldy, ks, out, dims, strides, tag=None):

@@ -706,7 +706,10 @@ def test_deconv_last_dgrad_fused(sfv, N, Cout, OH, OW, C1):
 
 
 @pytest.mark.parametrize("N,Cin,IH,IW,Nout,ks", [(3, 4, 32, 32, 256, 2), (2, 3, 21, 40, 64, 3), (4, 3, 64, 64, 64, 7),
-                                                  (2, 4, 7, 70, 128, 1), (5, 1, 16, 16, 64, 5)])
+                                                  (2, 4, 7, 70, 128, 1), (5, 1, 16, 16, 64, 5),
+                                                  # Nout % 256 == 0: wgrad_first_wide_k (a workgroup takes every channel)
+                                                  (2, 4, 21, 40, 256, 3), (1, 3, 16, 32, 256, 1), (3, 3, 30, 34, 512, 4),
+                                                  (7, 1, 18, 18, 256, 7), (4, 4, 44, 80, 256, 6)])
 def test_wgrad_first_rebuilds_the_im2col_rows(sfv, N, Cin, IH, IW, Nout, ks):
     """rbvae_wgrad_first (csrc/conv_first.hip): the weight gradients of the first Conv2d (mode 0: frames, also through a
     frame map) and of the last ConvTranspose2d (mode 1: NHWC f32 image) from the 3/4-channel image itself, against
@@ -724,8 +727,9 @@ def test_wgrad_first_rebuilds_the_im2col_rows(sfv, N, Cin, IH, IW, Nout, ks):
     assert L.query("rbvae_wgrad_first_blocks", 1, Cin, IH, IW, Nout + 8, N) == 0
     ks = min(ks, nblk)
     dy = (torch.randn(P, Nout, generator=g) / 8).bfloat16().cuda()
-    Wp = torch.zeros(Nout, 64, dtype=torch.bfloat16, device="cuda")
-    b = torch.zeros(Nout, device="cuda")
+    Nf = min(Nout, 256)                         # the forward kernels (which write the im2col rows) stop at 256 channels
+    Wp = torch.zeros(Nf, 64, dtype=torch.bfloat16, device="cuda")
+    b = torch.zeros(Nf, device="cuda")
 
     def via_col(col):
         k2 = max(1, -(-P // 4096))
@@ -736,11 +740,11 @@ def test_wgrad_first_rebuilds_the_im2col_rows(sfv, N, Cin, IH, IW, Nout, ks):
     # mode 0: frames
     x = torch.randn(N, Cin, IH, IW, generator=g).cuda()
     col = torch.empty(P, 64, dtype=torch.bfloat16, device="cuda")
-    out_a = torch.empty(P, Nout, dtype=torch.bfloat16, device="cuda")
-    L.call("rbvae_conv_first_fused", 1, x, 0, 0, 0, 0, Cin * IH * IW, Wp, b, zero, col, out_a, N, Cin, IH, IW, Nout, Nout, 1, 0,
+    out_a = torch.empty(P, Nf, dtype=torch.bfloat16, device="cuda")
+    L.call("rbvae_conv_first_fused", 1, x, 0, 0, 0, 0, Cin * IH * IW, Wp, b, zero, col, out_a, N, Cin, IH, IW, Nf, Nf, 1, 0,
            0.0, 1.0, 0, None)
     out_b = torch.full_like(out_a, float("nan"))
-    L.call("rbvae_conv_first_fused", 1, x, 0, 0, 0, 0, Cin * IH * IW, Wp, b, zero, None, out_b, N, Cin, IH, IW, Nout, Nout, 1, 0,
+    L.call("rbvae_conv_first_fused", 1, x, 0, 0, 0, 0, Cin * IH * IW, Wp, b, zero, None, out_b, N, Cin, IH, IW, Nf, Nf, 1, 0,
            0.0, 1.0, 0, None)
     assert torch.equal(out_a.view(torch.int16), out_b.view(torch.int16))
     want = via_col(col)
@@ -765,12 +769,12 @@ def test_wgrad_first_rebuilds_the_im2col_rows(sfv, N, Cin, IH, IW, Nout, ks):
     assert torch.equal(slabs_m, slabs)
     # mode 1: NHWC f32 image (d(loss)/d(pre-sigmoid) of the last ConvTranspose2d)
     dpre = (torch.randn(N, IH, IW, Cin, generator=g) * 0.1).cuda()
-    gate = torch.ones(P, Nout, dtype=torch.bfloat16, device="cuda")
+    gate = torch.ones(P, Nf, dtype=torch.bfloat16, device="cuda")
     col3 = torch.empty(P, 64, dtype=torch.bfloat16, device="cuda")
-    o3 = torch.empty(P, Nout, dtype=torch.bfloat16, device="cuda")
-    L.call("rbvae_deconv_last_dgrad_fused", 1, dpre, Wp, zero, col3, gate, o3, N, Cin, IH, IW, Nout, Nout, 1.0, None)
+    o3 = torch.empty(P, Nf, dtype=torch.bfloat16, device="cuda")
+    L.call("rbvae_deconv_last_dgrad_fused", 1, dpre, Wp, zero, col3, gate, o3, N, Cin, IH, IW, Nf, Nf, 1.0, None)
     o4 = torch.full_like(o3, float("nan"))
-    L.call("rbvae_deconv_last_dgrad_fused", 1, dpre, Wp, zero, None, gate, o4, N, Cin, IH, IW, Nout, Nout, 1.0, None)
+    L.call("rbvae_deconv_last_dgrad_fused", 1, dpre, Wp, zero, None, gate, o4, N, Cin, IH, IW, Nf, Nf, 1.0, None)
     assert torch.equal(o3.view(torch.int16), o4.view(torch.int16))
     want3 = via_col(col3)
     slabs3 = torch.full((ks, Nout, 64), float("nan"), device="cuda")
