@@ -45,7 +45,7 @@ struct DlArgs {
                          // together, then multiplied
 #endif
 #ifndef DL_SL
-#define DL_SL 2          // 128-byte channel slices resident at a time (build switch: 1 -> three workgroups per CU)
+#define DL_SL 2          // 128-byte channel slices resident at a time (build switch: 1 with DL_PIPE 0 -> five workgroups per CU)
 #endif
 constexpr int DL_TA = 8, DL_TB = 16;                 // input block
 constexpr int DL_HA = DL_TA + 1, DL_HB = DL_TB + 1;  // with halo
@@ -59,19 +59,21 @@ __device__ __forceinline__ void dl_glds16(const void* g, void* lds) {
                                      (__attribute__((address_space(3))) void*)lds, 16, 0, 0);
 }
 
-__global__ __launch_bounds__(256, (DL_SL == 1 ? 3 : 2)) void deconv_last_fused_k(const DlArgs p) {
+__global__ __launch_bounds__(256, (DL_SL == 1 ? 5 : 3)) void deconv_last_fused_k(const DlArgs p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int KS = p.C1 >> 6;                                        // 128-byte slices per row
-    // Two slices (128 channels) are resident at a time: 40 KB of pixel rows + 12 KB of the product matrix + 24 KB of
-    // products keep a workgroup under 80 KB, so two share a CU and one's loads run under the other's MFMAs and
-    // gather phase (with all of C1 resident it was one workgroup per CU, every phase exposed, and slower than the
-    // two-kernel path).
+    // Two 128-byte channel slices are resident at a time, not all of C1, and the f32 products Y take the slice buffers'
+    // place once the last slice is multiplied: 52 KB per workgroup, so THREE share a CU and one's loads run under the
+    // others' MFMAs and gather phases.  (All of C1 resident: one workgroup per CU, every phase exposed, slower than the
+    // two-kernel path.  Y beside the slices, 76 KB, two per CU: 93 us at native 4x88x160 against 74 -- and the same 93 with
+    // a ring of three slices at two per CU: it is the number of workgroups whose phases interleave that counts, not the
+    // slices in flight; one buffer, unpipelined, five per CU: 79.)
     constexpr int SL = DL_SL;
-    // a 64-channel layer (cfg 3) has ONE slice: one buffer, 50 KB, three workgroups per CU instead of two
+    // a 64-channel layer (cfg 3) has ONE slice: one buffer, 26 KB, five workgroups per CU (94 registers)
     const int NBUF = KS > 1 ? SL : 1;
     unsigned char* s_pix = smem;                                     // [NBUF][DL_MROWS][128]
     unsigned char* s_wts = s_pix + (size_t)NBUF * DL_MROWS * 128;    // [NBUF][DL_WROWS][128]
-    float* s_y = (float*)(s_wts + (size_t)NBUF * DL_WROWS * 128);    // [DL_MROWS][DL_YP]
+    float* s_y = (float*)smem;                                       // [DL_MROWS][DL_YP], over the slice buffers once they are dead
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int OH = 2 * p.IH, OW = 2 * p.IW;
     const int tb_n = (p.IW + DL_TB - 1) / DL_TB, ta_n = (p.IH + DL_TA - 1) / DL_TA;
@@ -235,6 +237,7 @@ __global__ __launch_bounds__(256, (DL_SL == 1 ? 3 : 2)) void deconv_last_fused_k
         for (int c = 0; c < 4; ++c) asm volatile("" : "+v"(tg[it][c]));
 #pragma unroll
     for (int c = 0; c < 4; ++c) asm volatile("" : "+v"(bz[c]));
+    __syncthreads();                     // every wave has read its last fragments: the products go where the slices were
     // D[(tap,co) row 4g + r][pixel i]
 #pragma unroll
     for (int pi = 0; pi < 3; ++pi) {
@@ -323,7 +326,10 @@ __global__ __launch_bounds__(256, (DL_SL == 1 ? 3 : 2)) void deconv_last_fused_k
 }
 
 static int dl_blocks(int N, int IH, int IW) { return N * cdiv(IH, DL_TA) * cdiv(IW, DL_TB); }
-static size_t dl_lds(int C1) { return (size_t)(C1 > 64 ? DL_SL : 1) * (DL_MROWS + DL_WROWS) * 128 + (size_t)DL_MROWS * DL_YP * 4; }
+static size_t dl_lds(int C1) {
+    const size_t slices = (size_t)(C1 > 64 ? DL_SL : 1) * (DL_MROWS + DL_WROWS) * 128, y = (size_t)DL_MROWS * DL_YP * 4;
+    return slices > y ? slices : y;
+}
 
 }  // namespace rbvae
 
