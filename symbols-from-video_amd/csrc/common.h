@@ -165,14 +165,21 @@ __device__ __forceinline__ void drop_chunk_zero_f32(unsigned run, unsigned thres
         if (e + 2 < EC) { s ^= s << 13; s ^= s >> 17; s ^= s << 5; }
     }
 }
+// Two packed 16-bit elements at a time (the same decisions: element dropped iff its 16 bits < thresh16): keep = min(sat(s -
+// (thresh16 - 1)), 1) per half is 1 iff s >= thresh16, and the word is multiplied by it -- three packed instructions per
+// pair where the compare / select form takes eight (inline asm: the compiler turns the C++ form back into compares).  The
+// epilogues share their SIMD's issue port with the matrix-core waves of the next tile; their instruction count is run time.
 template <int EC>
 __device__ __forceinline__ void drop_chunk_zero_b16(unsigned run, unsigned thresh16, unsigned* w) {
+    if (thresh16 == 0) return;                       // p = 0: nothing is dropped (thresh16 - 1 would wrap)
     unsigned s = drop_bits(run, 0);
+    const unsigned tm1 = (thresh16 - 1u) * 0x00010001u, one2 = 0x00010001u;
 #pragma unroll
     for (int e = 0; e < EC; e += 2) {
-        unsigned v = w[e >> 1];
-        v = (s & 0xffffu) < thresh16 ? (v & 0xffff0000u) : v;
-        v = (s >> 16) < thresh16 ? (v & 0x0000ffffu) : v;
+        unsigned d, k, v = w[e >> 1];
+        asm("v_pk_sub_u16 %0, %1, %2 clamp" : "=v"(d) : "v"(s), "v"(tm1));
+        asm("v_pk_min_u16 %0, %1, %2" : "=v"(k) : "v"(d), "v"(one2));
+        asm("v_pk_mul_lo_u16 %0, %1, %2" : "=v"(v) : "v"(v), "v"(k));
         w[e >> 1] = v;
         if (e + 2 < EC) { s ^= s << 13; s ^= s >> 17; s ^= s << 5; }
     }

@@ -44,3 +44,13 @@ dp = torch.empty(N, oh2, ow2, Cin, device="cuda")
 def last(): L.call("rbvae_deconv_last_fused", 1, rows, Vp, NY, b4, zero, N, OH, OW, Nout, Cin, xr, tgt, 0, 0, 0, 0, Cin * oh2 * ow2, ws, dp, 0.5)
 t = timed(last); by = rows.numel() * 2 + 3 * xr.numel() * 4
 print(f"deconv_last_fused ({Nout} ch -> image + loss)  {t:7.1f} us  {by / t / 1e6:5.2f} TB/s of {by / 1e6:.0f} MB", flush=True)
+# the two weight gradients of the ends from the images themselves (rbvae_wgrad_first)
+nblk = L.query("rbvae_wgrad_first_blocks", 1, Cin, IH, IW, Nout, N)
+ks = max(1, min(256 // (Nout // 256), nblk)) if Nout % 256 == 0 else max(1, min(512 // (Nout // 64), nblk))
+slabs = torch.empty(ks, Nout, 64, device="cuda")
+dy = (torch.randn(P, Nout, device="cuda") / 8).bfloat16()
+def wg0(): L.call("rbvae_wgrad_first", 1, 0, x, 0, 0, 0, 0, Cin * IH * IW, dy, slabs, zero, N, Cin, IH, IW, Nout, Nout, ks)
+def wg1(): L.call("rbvae_wgrad_first", 1, 1, dpre, 0, 0, 0, 0, 0, dy, slabs, zero, N, Cin, IH, IW, Nout, Nout, ks)
+by = x.numel() * 4 + dy.numel() * 2
+t = timed(wg0); print(f"wgrad_first mode 0 (frames x dY, {ks} slabs)    {t:7.1f} us  {by / t / 1e6:5.2f} TB/s of {by / 1e6:.0f} MB", flush=True)
+t = timed(wg1); print(f"wgrad_first mode 1 (image grad x d2)         {t:7.1f} us  {by / t / 1e6:5.2f} TB/s of {by / 1e6:.0f} MB", flush=True)
