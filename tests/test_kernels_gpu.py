@@ -165,6 +165,38 @@ def test_hash_dropout_statistics(sfv):
     assert abs(corr(k0, k1)) < 0.01
 
 
+def test_keyed_dropout_mask_is_its_definition(sfv):
+    """The keep-mask of drop_mode 1 restated on the host (csrc/common.h: drop_key, drop_run, drop_bits, then a xorshift32
+    walk with 16 bits per element over each 16-byte store chunk; dropped iff the 16 bits < floor(p * 2^32) >> 16) against
+    the zeros the bf16 GEMM epilogue stores -- element for element, so the packed 16-bit form of the decision (v_pk_sub_u16
+    clamp / v_pk_min_u16 / v_pk_mul_lo_u16) cannot drift from the compare form the f32 path and the mask kernels use."""
+    g = torch.Generator().manual_seed(9)
+    M, K, Nout, seed, pdrop = 777, 64, 136, 11, 0.2
+    A = (torch.rand(M, K, generator=g) + 0.5).bfloat16()
+    Wt = (torch.rand(Nout, K, generator=g) + 0.5).bfloat16()         # positive products: a zero is a dropped element
+    out = torch.empty(M, Nout, dtype=torch.bfloat16, device="cuda")
+    gemm(sfv, DT["bf16"][0], A.cuda(), Wt.cuda(), out, None, None, None, (M, 1, 1, 1, 1, 1, 1, 1, 1), K, Nout, 1,
+         [1, 0, 0, 0, 0, 0], 1, drop_mode=1, drop_p=pdrop, scale=1.25, seed=seed)
+    got_keep = (out.float().cpu() != 0).numpy()
+    u64, u32 = np.uint64, np.uint32
+    with np.errstate(over="ignore"):
+        x = u64(seed) * u64(0x9E3779B97F4A7C15) + u64(0xD6E8FEB86659FD93)
+        x ^= x >> u64(32); x *= u64(0xD6E8FEB86659FD93); x ^= x >> u64(32)
+        k0, k1 = u32(x & u64(0xFFFFFFFF)), u32(x >> u64(32))
+        thresh16 = u32(int(pdrop * 4294967296.0) >> 16)
+        rows, chunks = np.arange(M, dtype=np.uint64)[:, None], np.arange(0, Nout, 8, dtype=np.uint64)[None, :]
+        idx = rows * u64(Nout) + chunks                                # first element of every 8-element chunk
+        s = (idx & u64(0xFFFFFFFF)).astype(u32) + k0 + (idx >> u64(32)).astype(u32) * k1
+        s ^= s >> u32(16); s *= u32(0x7feb352d); s ^= s >> u32(15); s *= u32(0x846ca68b); s ^= s >> u32(16)
+        want_keep = np.empty((M, Nout), dtype=bool)
+        for e in range(0, 8, 2):
+            want_keep[:, e::8] = (s & u32(0xffff)) >= thresh16
+            want_keep[:, e + 1::8] = (s >> u32(16)) >= thresh16
+            s ^= s << u32(13); s ^= s >> u32(17); s ^= s << u32(5)
+    assert np.array_equal(got_keep, want_keep)
+    assert 0.17 < 1.0 - want_keep.mean() < 0.23
+
+
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
 @pytest.mark.parametrize("k,C,Co,N,H,W,ks", [(3, 64, 64, 3, 16, 24, 1), (3, 256, 256, 2, 8, 8, 2), (4, 64, 128, 2, 16, 16, 3),
                                               (3, 128, 72, 5, 10, 6, 1)])
