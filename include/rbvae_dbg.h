@@ -22,6 +22,10 @@ int rbvae_dbg_wr_stamps(unsigned long long* buf, void* stream);
  * one-tile-per-workgroup kernel (conv_halo.hip); 1 the latter always; 0 the persistent kernel wherever it covers -- for the
  * bit-identity test and A/B timing; returns the previous value */
 int rbvae_dbg_conv_halo_variant(int v);
+/* which kernels rbvae_lstm_pair_fwd / rbvae_lstm_pair_bwd (librbvae_hip) run at L == 32: 1 (default) one thread per hidden
+ * unit (lstm_pair_fwd_unit_k: four gate rows per thread, one barrier per diagonal), 0 one thread per gate row -- for the
+ * bit-identity tests and A/B timing; returns the previous value */
+int rbvae_dbg_lstm_unit_threads(int v);
 int rbvae_dbg_tr16(const void* img, const int* rowsel, const int* colsel, void* out, void* stream);
 
 #ifdef __cplusplus

@@ -83,3 +83,12 @@ extern "C" int rbvae_dbg_conv_halo_variant(int v) {
     rbvae::ch_variant = v;
     return old;
 }
+
+// which kernels rbvae_lstm_pair_fwd / _bwd (librbvae_hip) run at L == 32: 1 one thread per hidden unit (default), 0 one per
+// gate row; returns the previous value
+namespace rbvae { extern int lstm_unit_threads; }
+extern "C" int rbvae_dbg_lstm_unit_threads(int v) {
+    const int old = rbvae::lstm_unit_threads;
+    rbvae::lstm_unit_threads = v;
+    return old;
+}

@@ -27,6 +27,7 @@
 namespace rbvae {
 
 typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+int lstm_unit_threads = 1;       // 0: the gate-row kernels also at L == 32 (rbvae_dbg_lstm_unit_threads: identity tests, A/B timing)
 
 __device__ __forceinline__ long lstm_layer_floats(int L) { return 8l * L * L + 8l * L; }
 
@@ -774,6 +775,160 @@ __global__ __launch_bounds__(1024) void lstm_pair_fwd_k(const PairArgs p) {
     }
 }
 
+// The same wavefront with one WAVE per layer (L == 32): lane (unit j, half hf) holds two gate rows of its unit -- i, f in
+// lanes 0-31, g, o in lanes 32-63 (128 weights in registers) -- forms their pre-activations with the same four accumulator
+// chains per dot product, and lanes 0-31 fetch g, o from their partner lanes (two cross-lane moves) and update the cell at
+// once: the activated gates never pass through LDS, so a diagonal needs ONE workgroup barrier of 2 * layers waves instead
+// of two barriers of 16 waves, and the x_t / h_{t-1} vectors are read by half the lanes (the gate-row form spends a third
+// of a step in those broadcast reads: bench step 0.4269 -> 0.4223 ms with three quarters of them removed).  Same
+// expressions in the same order as lstm_pair_fwd_k: identical results.  A diagonal writes h_t of (layer, t) and reads rows
+// (layer, t-1), (layer-1, t): distinct LDS rows, so the single barrier per diagonal orders everything.  (All four gate rows
+// in one thread, 256 weights: the compiler parks a quarter of them in accumulation registers and moves them back every
+// diagonal -- slower than the gate-row form.)
+__global__ __launch_bounds__(512) void lstm_pair_fwd_unit_k(const PairArgs p) {
+    RBVAE_RAISE_PRIO();
+    constexpr int L = 32, LS = 32;
+    const int T = p.T, S = p.S, layers = p.layers;
+    const float inv_tau_src = p.tau_dev ? p.tau_dev[0] : p.tau;
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* hbuf = sm;                                    // [2][layers+1][T][LS]: stack, slot, time
+    float* nbuf = hbuf + 2 * (layers + 1) * T * LS;      // [T][LS] noise term of the binarisation
+    float* red = nbuf + T * LS;                          // [16] block reduction
+    const int q = threadIdx.x >> 6, j = threadIdx.x & 31, hf = (threadIdx.x >> 5) & 1;      // global layer, unit, gate pair
+    const int stack = q >= layers, l = q - (stack ? layers : 0);
+    const int s = blockIdx.x;
+    float* hs_all = stack ? p.hs_d : p.hs_e;
+    float* hprev = stack ? p.hp_d : p.hp_e;
+    float* acts = stack ? p.acts_d : p.acts_e;
+    float* cs = stack ? p.cs_d : p.cs_e;
+    float* hb = hbuf + stack * (layers + 1) * T * LS;
+    const float* wblk = stack ? p.wblk_d : p.wblk_e;
+    const float* wT = stack ? p.wT_d : p.wT_e;
+    const float* wl = wblk + l * lstm_layer_floats(L);
+    float wih[2][L], whh[2][L], bsum[2];
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+        const int r = (2 * hf + g) * L + j;
+        bsum[g] = wl[8l * L * L + r] + wl[8l * L * L + 4 * L + r];
+        const float* pi = wT ? wT + (long)(l * 2) * L * 4 * L + r : wl + r * L;
+        const float* ph = wT ? pi + L * 4 * L : pi + 4 * L * L;
+        const int kstride = wT ? 4 * L : 1;
+#pragma unroll
+        for (int k = 0; k < L; ++k) { wih[g][k] = pi[k * kstride]; whh[g][k] = ph[k * kstride]; }
+    }
+    for (int i = threadIdx.x; i < T * L; i += blockDim.x) {
+        const long o = ((long)s * T) * L + i;
+        const bool parts = p.in_parts != nullptr;
+        const float* ip = parts ? p.in_parts + o : p.hs_e + o;
+        const long st = parts ? p.part_stride : 0;
+        const int np = parts ? p.nparts : 1;
+        const float a0 = ip[0];
+        const float a1 = ip[(np > 1 ? 1 : 0) * st];
+        const float a2 = ip[(np > 2 ? 2 : 0) * st];
+        const float a3 = ip[(np > 3 ? 3 : 0) * st];
+        const float uin = *(p.U ? p.U + o : ip);
+        const unsigned long long sdev = *(p.seed_dev ? p.seed_dev : (const unsigned long long*)p.wblk_e);
+        float v = a0;
+        v += np > 1 ? a1 : 0.f;
+        v += np > 2 ? a2 : 0.f;
+        v += np > 3 ? a3 : 0.f;
+        for (int k = 4; k < np; ++k) v += ip[k * st];
+        if (parts) p.hs_e[o] = v;
+        hbuf[i] = v;
+        const unsigned long long seed = p.seed + (p.seed_dev ? sdev * 0x9E3779B97F4A7C15ull : 0ull);
+        const float u = p.U ? uin : (float)(hash_u32(seed, (unsigned long long)o) >> 8) * (1.0f / 16777216.0f);
+        nbuf[i] = p.ratio * (logf(u + p.neps) - logf(1.0f - u + p.neps));
+    }
+    if (p.cast_out) {
+        const int pw = p.cast_ld - L;
+        for (int i = threadIdx.x; i < T * pw; i += blockDim.x) {
+            const long o = ((long)s * T + i / pw) * p.cast_ld + L + i % pw;
+            if (p.cast_bf16) ((bf16_t*)p.cast_out)[o] = 0; else ((float*)p.cast_out)[o] = 0.f;
+        }
+    }
+    float c = 0.f;
+    for (int i = threadIdx.x; i < 2 * (layers + 1) * T * LS; i += blockDim.x)
+        if (i >= T * LS) hbuf[i] = 0.f;
+    __syncthreads();
+    const int ndiag = T + 2 * layers - 1;
+    for (int d = 0; d < ndiag; ++d) {
+        const int t = d - q;                              // wave-uniform
+        if (t >= 0 && t < T) {
+            const float* xt = hb + (l * T + t) * LS;
+            const float* hp = hb + ((l + 1) * T + (t > 0 ? t - 1 : 0)) * LS;
+            const float hscale = t > 0 ? 1.f : 0.f;
+            f32x2_t a01[2], a23[2], b01[2], b23[2];
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                a01[g] = f32x2_t{bsum[g], 0.f}; a23[g] = f32x2_t{0.f, 0.f}; b01[g] = f32x2_t{0.f, 0.f}; b23[g] = f32x2_t{0.f, 0.f};
+            }
+            // every read of the two vectors is issued before the first multiply (one LDS latency per diagonal: left to itself
+            // the compiler issues each 16-byte read just ahead of its use and the wave waits eight times)
+            float4 xs[L / 4], hv4[L / 4];
+#pragma unroll
+            for (int k = 0; k < L; k += 4) { xs[k / 4] = *(const float4*)(xt + k); hv4[k / 4] = *(const float4*)(hp + k); }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int k = 0; k < L; k += 4) {
+                const float4 xv = xs[k / 4], hv = hv4[k / 4];
+#pragma unroll
+                for (int g = 0; g < 2; ++g) {
+                    a01[g] = __builtin_elementwise_fma(f32x2_t{wih[g][k], wih[g][k + 1]}, f32x2_t{xv.x, xv.y}, a01[g]);
+                    a23[g] = __builtin_elementwise_fma(f32x2_t{wih[g][k + 2], wih[g][k + 3]}, f32x2_t{xv.z, xv.w}, a23[g]);
+                    b01[g] = __builtin_elementwise_fma(f32x2_t{whh[g][k], whh[g][k + 1]}, f32x2_t{hv.x, hv.y}, b01[g]);
+                    b23[g] = __builtin_elementwise_fma(f32x2_t{whh[g][k + 2], whh[g][k + 3]}, f32x2_t{hv.z, hv.w}, b23[g]);
+                }
+            }
+            float av[2];
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                const float pre = ((a01[g][0] + a01[g][1]) + (a23[g][0] + a23[g][1])) +
+                                  hscale * ((b01[g][0] + b01[g][1]) + (b23[g][0] + b23[g][1]));
+                av[g] = (hf == 1 && g == 0) ? fast_tanh(pre) : fast_sigmoid(pre);      // gate g of the cell is the tanh one
+            }
+            const long o = (((long)l * S + s) * T + t);
+            if (acts) {
+#pragma unroll
+                for (int g = 0; g < 2; ++g) acts[o * 4 * L + (2 * hf + g) * L + j] = av[g];
+            }
+            // lanes 0-31 (i, f) take g, o from lanes 32-63
+            const float gg = __shfl_xor(av[0], 32, 64), og = __shfl_xor(av[1], 32, 64);
+            if (hf == 0) {
+                const float ig = av[0], fg = av[1];
+                const float hpv = t > 0 ? hp[j] : 0.f;
+                c = fmaf(fg, c, ig * gg);        // explicit: the same rounding in every kernel that runs this cell
+                const float h = og * fast_tanh(c);
+                hb[((l + 1) * T + t) * LS + j] = h;
+                if (acts) {
+                    cs[o * L + j] = c;
+                    hprev[o * L + j] = hpv;
+                }
+                hs_all[(((long)(l + 1) * S + s) * T + t) * L + j] = h;
+                if (q == layers - 1) {
+                    const long e = ((long)s * T + t) * L + j;
+                    const float y = sigmoidf_((h + nbuf[t * LS + j]) / inv_tau_src);
+                    const float zz = p.hard ? (y > 0.5f ? 1.0f : 0.0f) : y;
+                    p.y_soft[e] = y;
+                    p.hs_d[e] = zz;
+                    hbuf[(layers + 1) * T * LS + t * LS + j] = zz;        // decoder stack, slot 0
+                }
+                if (p.cast_out && q == 2 * layers - 1) {
+                    const long oc = ((long)s * T + t) * p.cast_ld + j;
+                    if (p.cast_bf16) ((bf16_t*)p.cast_out)[oc] = f32_to_bf16(h); else ((float*)p.cast_out)[oc] = h;
+                }
+            }
+        }
+        lds_barrier();
+    }
+    if (p.kl_parts) {
+        float a = 0.f;
+        for (int i = threadIdx.x; i < T * L; i += blockDim.x)
+            a += kl_elem(hbuf[(layers + 1) * T * LS + i], p.lp, p.l1p, p.keps, p.clamp);
+        const float tot = block_sum(a, red);
+        if (threadIdx.x == 0) p.kl_parts[s] = tot;
+    }
+}
+
 // Optional binarise backward in the prologue of the ENCODER stack's BPTT launch (rbvae_binarize_kl_bwd fused):
 //   g_top = g_hs + (gz + klw * dKL/dz(z)) * y (1 - y) / tau      (straight-through: the same with hard codes)
 struct BinBwd {
@@ -1424,7 +1579,9 @@ int rbvae_lstm_pair_fwd(const float* wblk_enc, const float* wT_enc, const float*
     a.S = S; a.T = T; a.L = L; a.layers = layers; a.G = threads;
     const int LS = (L + 3) & ~3;
     const size_t lds = (size_t)(2 * (layers + 1) * T * LS + 2 * layers * 4 * L + T * LS + 16) * sizeof(float);
-    if (L == 32)
+    if (L == 32 && 2 * layers * 64 <= 512 && lstm_unit_threads)
+        hipLaunchKernelGGL(lstm_pair_fwd_unit_k, dim3(S), dim3(2 * layers * 64), lds, (hipStream_t)stream, a);
+    else if (L == 32)
         hipLaunchKernelGGL((lstm_pair_fwd_k<32, true>), dim3(S), dim3(2 * layers * threads), lds, (hipStream_t)stream, a);
     else if (LS == 28)      // latent_dim 25 (the reference's most common) .. 28
         hipLaunchKernelGGL((lstm_pair_fwd_k<32, false, 28>), dim3(S), dim3(2 * layers * threads), lds, (hipStream_t)stream, a);

@@ -19,4 +19,4 @@ def test_library_exports_every_declared_symbol():
     assert not [n for n in dir(raw) if n.startswith("rbvae_dbg_")] and not hasattr(raw, "rbvae_dbg_mfma_bf16")
     dbg = ctypes.CDLL(L.DBG_LIB_PATH)
     probes = [n for n in L.parse_header(L.DBG_HEADER) if "stamps" not in n]
-    assert len(probes) == 5 and all(hasattr(dbg, n) for n in probes)
+    assert len(probes) == 6 and all(hasattr(dbg, n) for n in probes)

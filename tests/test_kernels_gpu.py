@@ -550,6 +550,52 @@ def test_lstm_pair_forward_equals_three_launches(sfv, L, layers, S, T, hard):
     assert not sfv._lib.query("rbvae_lstm_pair_fwd_ok", 8, 64, 2)
 
 
+@pytest.mark.parametrize("layers,S,T,hard,use_wT,nparts", [(4, 5, 8, 0, True, 3), (2, 3, 5, 1, False, 1), (4, 2, 1, 0, True, 1), (3, 4, 11, 0, False, 5)])
+def test_lstm_pair_forward_unit_threads_bit_identical(sfv, layers, S, T, hard, use_wT, nparts):
+    """lstm_pair_fwd_unit_k (L == 32: one thread per hidden unit holds its four gate rows, one barrier per diagonal)
+    against lstm_pair_fwd_k (one thread per gate row), selected through rbvae_dbg_lstm_unit_threads: the same
+    accumulator chains and expressions, so EVERY output is bit for bit the same -- saved activations, cell states, codes,
+    the bf16 cast of the decoder's top layer, the per-sequence KL sums -- also from K-split input slabs, with device noise."""
+    L = 32
+    g = torch.Generator().manual_seed(90 + layers + T)
+    N = S * T
+    per = layers * (8 * L * L + 8 * L)
+    we, wd = (torch.randn(per, generator=g) * 0.3).cuda(), (torch.randn(per, generator=g) * 0.3).cuda()
+
+    def wT_of(w):
+        out = torch.empty(layers, 2, L, 4 * L, device="cuda")
+        for l in range(layers):
+            blk = w[l * (8 * L * L + 8 * L):]
+            out[l, 0] = blk[:4 * L * L].view(4 * L, L).t()
+            out[l, 1] = blk[4 * L * L:8 * L * L].view(4 * L, L).t()
+        return out.contiguous()
+    wTe, wTd = (wT_of(we), wT_of(wd)) if use_wT else (None, None)
+    slabs = torch.randn(nparts, S, T, L, generator=g).cuda()
+    U = torch.rand(N, L, generator=g).cuda() if hard else None           # None: counter-hash noise from (seed, step)
+    seed_dev = torch.tensor([7], dtype=torch.int64, device="cuda")
+    dbg = sfv._lib.dbg_lib()
+    outs = []
+    for unit in (1, 0):
+        old = dbg.rbvae_dbg_lstm_unit_threads(unit)
+        try:
+            bufs = [torch.zeros(layers + 1, S, T, L, device="cuda"), torch.empty(layers, S, T, L, device="cuda"),
+                    torch.empty(layers, S, T, 4 * L, device="cuda"), torch.empty(layers, S, T, L, device="cuda")]
+            bufs += [torch.zeros(layers + 1, S, T, L, device="cuda"), torch.empty(layers, S, T, L, device="cuda"),
+                     torch.empty(layers, S, T, 4 * L, device="cuda"), torch.empty(layers, S, T, L, device="cuda")]
+            y = torch.empty(N, L, device="cuda")
+            parts = torch.empty(S, device="cuda")
+            pad = torch.full((N, 64), 3.0, dtype=torch.bfloat16, device="cuda")
+            sfv._lib.call("rbvae_lstm_pair_fwd", we, wTe, wd, wTd, *bufs, slabs, nparts, S * T * L, U, y, parts, 0.6, None, 0.3,
+                          1e-8, hard, 0.1, 1e-8, 1, 1234, seed_dev, pad, 1, 64, S, T, L, layers)
+            outs.append(bufs + [y, parts, pad])
+        finally:
+            dbg.rbvae_dbg_lstm_unit_threads(old)
+    for a, b in zip(*outs):
+        assert torch.equal(a.view(torch.int16) if a.dtype == torch.bfloat16 else a.view(torch.int32),
+                           b.view(torch.int16) if b.dtype == torch.bfloat16 else b.view(torch.int32))
+    assert torch.isfinite(outs[0][8]).all() and float(outs[0][4][layers].abs().max()) > 0
+
+
 @pytest.mark.parametrize("L,layers,S,T,nparts,klw,ghs,extra", [(32, 4, 5, 8, 4, 1.0, True, False), (32, 2, 3, 5, 1, 0.0, False, True),
                                                               (25, 4, 3, 8, 3, 0.5, True, True), (7, 2, 2, 3, 1, 1.0, False, False),
                                                               (30, 3, 2, 9, 2, 0.0, True, False)])

@@ -28,6 +28,9 @@ def build(spec):
     eng = m._engine_for(item)          # the engine the trainer will pick up at its first step
     for kv in filter(None, sets.split(",")):
         k, v = kv.split("=")
+        if k.startswith("hook."):               # a library switch of include/rbvae_dbg.h, e.g. hook.lstm_unit_threads=0 (set before the capture)
+            getattr(sfv._lib.dbg_lib(), "rbvae_dbg_" + k[5:])(int(v))
+            continue
         obj = eng
         if k.startswith("tr."):                 # a trainer attribute (e.g. tr.early_tail_update=0)
             obj, k = tr, k[3:]
