@@ -1325,6 +1325,192 @@ __global__ __launch_bounds__(1024) void lstm_pair_bwd_k(const PairBwdArgs p) {
     }
 }
 
+// The same BPTT wavefront with one WAVE per virtual layer (L == 32), the backward partner of lstm_pair_fwd_unit_k: lanes
+// 0-31 (hidden unit j) do the pointwise gate gradients and write them to LDS; then lane (column kcol, half hf) multiplies
+// the two gate blocks 2*hf, 2*hf+1 of both transposed weight matrices with them (128 weights in registers, the same two
+// fused-multiply-add chains per block as lstm_pair_bwd_k), lanes 0-31 fetch the other half's block sums (four cross-lane
+// moves) and add the four blocks in the gate-row kernel's order.  The recurrent part dh_{t-1} never leaves its lane; only
+// the input gradient goes through LDS to the wave of the layer below (double-buffered by diagonal parity), and the gate
+// gradients are read back by the wave that wrote them (LDS operations of one wave complete in issue order): ONE workgroup
+// barrier of 2 * layers waves per diagonal instead of two of 16 waves.  Identical results.
+__global__ __launch_bounds__(512) void lstm_pair_bwd_unit_k(const PairBwdArgs p) {
+    RBVAE_RAISE_PRIO();
+    constexpr int L = 32;
+    const int T = p.T, S = p.S, layers = p.layers, VL = 2 * layers;
+    const BinBwd& bb = p.bb;
+    const float bin_tau = bb.tau_dev ? bb.tau_dev[0] : bb.tau;
+    extern __shared__ float sm[];
+    float* gtop = sm;                              // [T][L]            decoder top
+    float* sy = gtop + T * L;                      // [T][L]            seam: y, dKL/dz, g_hs, extra code gradient
+    float* sk = sy + T * L;
+    float* sh = sk + T * L;
+    float* sx = sh + T * L;
+    float* sacts = sx + T * L;                     // [VL][T][4L]
+    float* scs = sacts + VL * T * 4 * L;           // [VL][T][L]
+    float* dg = scs + VL * T * L;                  // [VL][4L]
+    float* partx = dg + VL * 4 * L;                // [2][VL][L]: input gradients on their way down, by diagonal parity
+    const int vl = threadIdx.x >> 6, j = threadIdx.x & 31, hf = (threadIdx.x >> 5) & 1;
+    const bool dec = vl >= layers;
+    const int l = dec ? vl - layers : vl;
+    const int s = blockIdx.x;
+    {
+        // every global load of the prologue in flight before the first use (see lstm_bwd_wave_k)
+        constexpr int U = 12;
+        const int n0 = T * L, na = T * 4 * L, n1 = VL * na, ntot = n1 + VL * n0;
+        const int nth = blockDim.x;
+        float v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            int i = (int)threadIdx.x + u * nth;
+            i = i < ntot ? i : ntot - 1;
+            const bool in_acts = i < n1;
+            const int rel = in_acts ? i : i - n1;
+            const int per = in_acts ? na : n0;
+            const int vll = rel / per, r = rel - vll * per;
+            const bool d = vll >= layers;
+            const int ll = d ? vll - layers : vll;
+            const float* base = in_acts ? (d ? p.acts_d : p.acts_e) : (d ? p.cs_d : p.cs_e);
+            v[u] = base[(((long)ll * S + s) * T) * (in_acts ? 4 * L : L) + r];
+        }
+        for (int i0 = 0; i0 < n0; i0 += nth) {
+            const int i = i0 + (int)threadIdx.x;
+            const long e = ((long)s * T) * L + (i < n0 ? i : n0 - 1);
+            const float* gp = p.g_top + e;
+            float gt = gp[0];
+            int q = 1;
+            for (; q + 3 <= p.nparts; q += 3) {
+                const float a = gp[q * p.part_stride], b = gp[(q + 1) * p.part_stride], c = gp[(q + 2) * p.part_stride];
+                gt = ((gt + a) + b) + c;
+            }
+            for (; q < p.nparts; ++q) gt += gp[q * p.part_stride];
+            const float yv = bb.y[e], zv = bb.z[e];
+            const float hsv = bb.g_hs ? bb.g_hs[e] : 0.f;
+            const float xv = p.gz_extra ? p.gz_extra[e] : 0.f;
+            if (i < n0) {
+                gtop[i] = gt;
+                sy[i] = yv;
+                sk[i] = bb.klw != 0.f ? kl_elem_grad(zv, bb.lp, bb.l1p, bb.keps, bb.clamp) : 0.f;
+                sh[i] = hsv;
+                sx[i] = xv;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int i = (int)threadIdx.x + u * nth;
+            if (i < ntot) sacts[i] = v[u];
+        }
+        for (int i = (int)threadIdx.x + U * nth; i < ntot; i += nth) {
+            const bool in_acts = i < n1;
+            const int rel = in_acts ? i : i - n1;
+            const int per = in_acts ? na : n0;
+            const int vll = rel / per, r = rel - vll * per;
+            const bool d = vll >= layers;
+            const int ll = d ? vll - layers : vll;
+            const float* base = in_acts ? (d ? p.acts_d : p.acts_e) : (d ? p.cs_d : p.cs_e);
+            sacts[i] = base[(((long)ll * S + s) * T) * (in_acts ? 4 * L : L) + r];
+        }
+    }
+    if (p.cast_out) {
+        const int pw = p.cast_ld - L;
+        for (int i = threadIdx.x; i < T * pw; i += blockDim.x) {
+            const long o = ((long)s * T + i / pw) * p.cast_ld + L + i % pw;
+            if (p.cast_bf16) ((bf16_t*)p.cast_out)[o] = 0; else ((float*)p.cast_out)[o] = 0.f;
+        }
+    }
+    const float* wl = (dec ? p.wblk_d : p.wblk_e) + l * lstm_layer_floats(L);
+    float wic[2][L], whc[2][L];
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+        const float* pi = wl + (2 * hf + g) * L * L + j;
+        const float* ph = pi + 4 * L * L;
+#pragma unroll
+        for (int jj = 0; jj < L; ++jj) { wic[g][jj] = pi[jj * L]; whc[g][jj] = ph[jj * L]; }
+    }
+    float dc_next = 0.f, dx_sum = 0.f, dh_rec = 0.f;
+    float* dG = dec ? p.dG_d : p.dG_e;
+    __syncthreads();
+    const int top = VL - 1;
+    const int ndiag = T + VL - 1;
+    for (int e = 0; e < ndiag; ++e) {
+        const int q = e - (top - vl);
+        const int t = T - 1 - q;
+        if (q >= 0 && q < T) {                             // wave-uniform
+            float* dl = dg + vl * 4 * L;
+            if (hf == 0) {
+                float dh;
+                if (vl == top) dh = gtop[t * L + j];
+                else {
+                    dh = partx[(((e - 1) & 1) * VL + vl + 1) * L + j];
+                    if (vl == layers - 1) {
+                        // the seam: dh so far is the decoder stack's input gradient = the gradient of the codes
+                        if (p.dz) p.dz[((long)s * T + t) * L + j] = dh;
+                        float gg = p.gz_extra ? dh + sx[t * L + j] : dh;
+                        if (bb.klw != 0.f) gg += bb.klw * sk[t * L + j];
+                        const float yv = sy[t * L + j];
+                        dh = sh[t * L + j] + gg * yv * (1.0f - yv) / bin_tau;
+                    }
+                }
+                if (q > 0) dh += dh_rec;
+                const float* ap = sacts + (vl * T + t) * 4 * L;
+                const float ig = ap[j], fg = ap[L + j], gg = ap[2 * L + j], og = ap[3 * L + j];
+                const float c = scs[(vl * T + t) * L + j];
+                const float cprev = t > 0 ? scs[(vl * T + t - 1) * L + j] : 0.f;
+                const float tc = fast_tanh(c);
+                const float dc = dc_next + dh * og * (1.f - tc * tc);
+                const float d_o = dh * tc * og * (1.f - og);
+                const float d_i = dc * gg * ig * (1.f - ig);
+                const float d_f = dc * cprev * fg * (1.f - fg);
+                const float d_g = dc * ig * (1.f - gg * gg);
+                dc_next = dc * fg;
+                dl[j] = d_i; dl[L + j] = d_f; dl[2 * L + j] = d_g; dl[3 * L + j] = d_o;
+                float* gp = dG + (((long)l * S + s) * T + t) * 4 * L;
+                gp[j] = d_i; gp[L + j] = d_f; gp[2 * L + j] = d_g; gp[3 * L + j] = d_o;
+            }
+            // the wave's own gate gradients back from LDS (same wave: in issue order behind the writes above)
+            const float* dgp = dl + 2 * hf * L;
+            float4 dv[2 * L / 4];
+#pragma unroll
+            for (int i = 0; i < 2 * L / 4; ++i) dv[i] = *(const float4*)(dgp + 4 * i);
+            __builtin_amdgcn_sched_barrier(0);
+            f32x2_t axp[2], ahp[2];
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                axp[g] = f32x2_t{0.f, 0.f}; ahp[g] = f32x2_t{0.f, 0.f};
+#pragma unroll
+                for (int jj = 0; jj < L; jj += 4) {
+                    const float4 d4 = dv[(g * L + jj) / 4];
+                    axp[g] = __builtin_elementwise_fma(f32x2_t{wic[g][jj], wic[g][jj + 1]}, f32x2_t{d4.x, d4.y}, axp[g]);
+                    ahp[g] = __builtin_elementwise_fma(f32x2_t{whc[g][jj], whc[g][jj + 1]}, f32x2_t{d4.x, d4.y}, ahp[g]);
+                    axp[g] = __builtin_elementwise_fma(f32x2_t{wic[g][jj + 2], wic[g][jj + 3]}, f32x2_t{d4.z, d4.w}, axp[g]);
+                    ahp[g] = __builtin_elementwise_fma(f32x2_t{whc[g][jj + 2], whc[g][jj + 3]}, f32x2_t{d4.z, d4.w}, ahp[g]);
+                }
+            }
+            const float px0 = axp[0][0] + axp[0][1], px1 = axp[1][0] + axp[1][1];
+            const float ph0 = ahp[0][0] + ahp[0][1], ph1 = ahp[1][0] + ahp[1][1];
+            // lanes 0-31 (gate blocks 0, 1) take the sums of blocks 2, 3 from lanes 32-63 and add in block order
+            const float px2 = __shfl_xor(px0, 32, 64), px3 = __shfl_xor(px1, 32, 64);
+            const float ph2 = __shfl_xor(ph0, 32, 64), ph3 = __shfl_xor(ph1, 32, 64);
+            if (hf == 0) {
+                const float dxv = px0 + px1 + px2 + px3;
+                dh_rec = ph0 + ph1 + ph2 + ph3;
+                if (vl > 0) partx[((e & 1) * VL + vl) * L + j] = dxv;
+                else {
+                    // encoder layer 0: the stack's input gradient at time t
+                    p.dx[((long)s * T + t) * L + j] = dxv;
+                    dx_sum += dxv;
+                    if (p.cast_out) {
+                        const long o = ((long)s * T + t) * p.cast_ld + j;
+                        if (p.cast_bf16) ((bf16_t*)p.cast_out)[o] = f32_to_bf16(dxv); else ((float*)p.cast_out)[o] = dxv;
+                    }
+                }
+            }
+        }
+        lds_barrier();
+    }
+    // per-sequence column sums of dx: the bias gradient of the Linear that feeds the encoder stack
+    if (vl == 0 && hf == 0 && p.dx_colsum) p.dx_colsum[(long)s * L + j] = dx_sum;
+}
+
 // Weight gradients, LDS-tiled: block = (8 gate rows, ih|hh, layer); thread (jj, kq) owns gate row jj and
 // the columns kq, kq+32, ... (column L = the bias).  Rows of dG / X stream through LDS 128 at a time.
 constexpr int LW_ROWS = 128;
@@ -1706,7 +1892,9 @@ int rbvae_lstm_pair_bwd(const float* wblk_enc, const float* wblk_dec, const floa
     const int threads = ((4 * L + 63) / 64) * 64;
     a.S = S; a.T = T; a.L = L; a.layers = layers; a.G = threads;
     const size_t lds = pair_bwd_lds(T, L, layers);
-    if (L == 32)
+    if (L == 32 && 2 * layers * 64 <= 512 && lstm_unit_threads)
+        hipLaunchKernelGGL(lstm_pair_bwd_unit_k, dim3(S), dim3(2 * layers * 64), lds, (hipStream_t)stream, a);
+    else if (L == 32)
         hipLaunchKernelGGL((lstm_pair_bwd_k<32, true>), dim3(S), dim3(2 * layers * threads), lds, (hipStream_t)stream, a);
     else
         hipLaunchKernelGGL((lstm_pair_bwd_k<32, false>), dim3(S), dim3(2 * layers * threads), lds, (hipStream_t)stream, a);

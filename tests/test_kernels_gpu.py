@@ -598,7 +598,10 @@ def test_lstm_pair_forward_unit_threads_bit_identical(sfv, layers, S, T, hard, u
 
 @pytest.mark.parametrize("L,layers,S,T,nparts,klw,ghs,extra", [(32, 4, 5, 8, 4, 1.0, True, False), (32, 2, 3, 5, 1, 0.0, False, True),
                                                               (25, 4, 3, 8, 3, 0.5, True, True), (7, 2, 2, 3, 1, 1.0, False, False),
-                                                              (30, 3, 2, 9, 2, 0.0, True, False)])
+                                                              (30, 3, 2, 9, 2, 0.0, True, False),
+                                                              # L == 32: lstm_pair_bwd_unit_k (one wave per layer)
+                                                              (32, 3, 4, 11, 5, 0.5, True, True), (32, 4, 2, 1, 1, 1.0, False, False),
+                                                              (32, 1, 3, 4, 2, 0.0, False, True)])
 def test_lstm_pair_backward_equals_two_launches(sfv, L, layers, S, T, nparts, klw, ghs, extra):
     """rbvae_lstm_pair_bwd (decoder stack -> binarise backward -> encoder stack, one wavefront) against
     rbvae_lstm_bwd_ex(decoder) + rbvae_lstm_bwd_bin(encoder): gate gradients of both stacks, the input gradient, its cast
