@@ -107,6 +107,96 @@ __global__ __launch_bounds__(256) void fc_gemm_k(const FcArgs p) {
     }
 }
 
+// The same product for wide layers (N a multiple of 128 with at least 256 column groups: the 56 320 / 65 536 features of the
+// native and 256 x 256 frame sizes).  With 16 columns per workgroup a row of the output receives 32 bytes per workgroup --
+// 14 MB written as 450 000 quarter lines, 30 us where the bytes take 4.  Here a wave owns 64 rows x 64 columns: four
+// column tiles whose W rows are dealt so that a lane's accumulators of the four tiles are 16 CONSECUTIVE columns (tile nt,
+// MFMA row 4 g + r = column 16 g + 4 nt + r), i.e. two 16-byte stores per row and lane and one whole 128-byte line per row
+// and wave.  Workgroup = 128 rows x 128 columns (wave w: rows 64 (w & 1), columns 64 (w >> 1)).  Same MFMAs in the same k
+// order per output, same rounding; the column sums pair the two row waves of a 128-row tile as fc_gemm_k does.
+template <int KH>
+__global__ __launch_bounds__(256) void fc_gemm_wide_k(const FcArgs p) {
+    constexpr int K = 32 * KH;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int fi = lane & 15, fg = lane >> 4;
+    const int n0 = blockIdx.x * 128 + 64 * (w >> 1);
+    const int r0 = blockIdx.y * 128 + 64 * (w & 1);
+    u32x4_t wf[4][KH], af[4][KH];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+        const int col = n0 + 16 * (fi >> 2) + 4 * nt + (fi & 3);       // the column MFMA row fi of tile nt computes
+        const unsigned char* wp = p.W + ((size_t)col * K + 8 * fg) * 2;
+#pragma unroll
+        for (int h = 0; h < KH; ++h) wf[nt][h] = *(const u32x4_t*)(wp + 64 * h);
+    }
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+        const int row = min(r0 + 16 * mt + fi, p.M - 1);               // clamped: rows past M are computed, not stored
+        const unsigned char* ap = p.A + ((size_t)row * p.lda + 8 * fg) * 2;
+#pragma unroll
+        for (int h = 0; h < KH; ++h) af[mt][h] = *(const u32x4_t*)(ap + 64 * h);
+    }
+    // lane's columns: n0 + 16 fg + 4 nt + r
+    f32x4_t bz[4];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+        bz[nt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        if (p.bias) bz[nt] = *(const f32x4_t*)(p.bias + n0 + 16 * fg + 4 * nt);
+    }
+    f32x4_t acc[4][4];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int h = 0; h < KH; ++h)
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt)
+                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8_t*)&wf[nt][h], *(const bf16x8_t*)&af[mt][h],
+                                                                      acc[mt][nt], 0, 0, 0);
+    float cs[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) cs[c] = 0.f;
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+        const int row = r0 + 16 * mt + fi;
+        unsigned short e[16];
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) e[4 * nt + r] = f32_to_bf16(acc[mt][nt][r] + bz[nt][r]);
+        if (row < p.M) {
+            u32x4_t lo, hi;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                lo[q] = (unsigned)e[2 * q] | ((unsigned)e[2 * q + 1] << 16);
+                hi[q] = (unsigned)e[8 + 2 * q] | ((unsigned)e[8 + 2 * q + 1] << 16);
+            }
+            unsigned char* op = p.Out + ((size_t)row * p.ldo + n0 + 16 * fg) * 2;
+            *(u32x4_t*)op = lo;
+            *(u32x4_t*)(op + 16) = hi;
+#pragma unroll
+            for (int c = 0; c < 16; ++c) cs[c] += __uint_as_float((unsigned)e[c] << 16);
+        }
+    }
+    if (p.colsum_ws) {
+        __shared__ float red[4][64];
+#pragma unroll
+        for (int c = 0; c < 16; ++c) cs[c] = fc_row_sum(cs[c]);
+        if (fi == 0) {
+#pragma unroll
+            for (int c = 0; c < 16; ++c) red[w][16 * fg + c] = cs[c];
+        }
+        __syncthreads();
+        if (tid < 128 && blockIdx.y * 128 < p.M) {
+            const int half = tid >> 6, c = tid & 63;                    // columns 64 half + c: waves 2 half (rows 0-63), 2 half + 1
+            p.colsum_ws[(size_t)blockIdx.y * p.N + blockIdx.x * 128 + 64 * half + c] = red[2 * half][c] + red[2 * half + 1][c];
+        }
+    }
+}
+
 }  // namespace rbvae
 
 using namespace rbvae;
@@ -129,7 +219,9 @@ int rbvae_fc_gemm(int dtype, const void* A, const void* W, void* Out, const floa
     FcArgs a;
     a.A = (const unsigned char*)A; a.W = (const unsigned char*)W; a.Out = (unsigned char*)Out; a.bias = bias;
     a.colsum_ws = colsum_ws; a.M = M; a.N = N; a.lda = lda; a.ldo = ldo;
-    if (K == 64) hipLaunchKernelGGL(fc_gemm_k<2>, dim3(N / 16, cdiv(M, 256)), dim3(256), 0, (hipStream_t)stream, a);
+    const bool wide = K == 64 && N % 128 == 0 && (long)(N / 128) * cdiv(M, 128) >= 256 && ldo % 8 == 0 && (uintptr_t)Out % 16 == 0;
+    if (wide) hipLaunchKernelGGL(fc_gemm_wide_k<2>, dim3(N / 128, cdiv(M, 128)), dim3(256), 0, (hipStream_t)stream, a);
+    else if (K == 64) hipLaunchKernelGGL(fc_gemm_k<2>, dim3(N / 16, cdiv(M, 256)), dim3(256), 0, (hipStream_t)stream, a);
     else hipLaunchKernelGGL(fc_gemm_k<4>, dim3(N / 16, cdiv(M, 256)), dim3(256), 0, (hipStream_t)stream, a);
     RBVAE_CHECK_LAUNCH("fc_gemm");
     return RBVAE_OK;

@@ -43,7 +43,10 @@ def gemm(sfv, dt, A, Wp, out, bias, gate, mask, geom, kc, nout, taps, desc, ncls
 
 @pytest.mark.parametrize("M,N,lda,with_bias,K", [(256, 4096, 64, True, 64), (256, 4096, 64, False, 64), (37, 1024, 72, True, 64),
                                                   (300, 2064, 64, False, 64), (1, 16, 64, True, 64), (256, 4096, 128, True, 128),
-                                                  (70, 1040, 136, False, 128)])
+                                                  (70, 1040, 136, False, 128),
+                                                  # N % 128 == 0 and at least 256 workgroups: fc_gemm_wide_k (64 x 64 per wave)
+                                                  (128, 56320, 64, True, 64), (200, 32768, 72, False, 64), (1, 32768, 64, True, 64),
+                                                  (513, 8192, 64, True, 64)])
 def test_fc_gemm_equals_one_tap_gather_gemm(sfv, M, N, lda, with_bias, K):
     """rbvae_fc_gemm (the K = 64 fc products, operands straight into the MFMA layout) against rbvae_gather_gemm with one
     tap: outputs bit for bit (same MFMAs in the same k order, same rounding), the per-128-row column sums to f32
