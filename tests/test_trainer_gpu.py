@@ -587,3 +587,31 @@ def test_fc_groups_fall_back_to_eight_or_four_when_sixteen_does_not_divide():
     for k in lay.names:
         a, b = lay.view(ga, k).double().reshape(-1), lay.view(gb, k).double().reshape(-1)
         assert float((a - b).norm()) <= 3e-3 * max(float(b.norm()), 1e-9), k
+
+
+def test_step_is_bit_identical_with_either_lstm_wavefront_kernel():
+    """The two LSTM launches of a step with one wave per layer (lstm_pair_fwd_unit_k / lstm_pair_bwd_unit_k, the default at
+    latent_dim 32) and with one thread per gate row (rbvae_dbg_lstm_unit_threads(0)): three captured-graph steps from the same
+    weights, batch, noise and dropout keys leave bit-identical losses, gradients and parameters."""
+    import sfv_amd as sfv
+    from importlib import import_module
+    FusedTrainer = import_module("symbols-from-video_amd.trainer").FusedTrainer
+    g = torch.Generator().manual_seed(43)
+    item = torch.randn(4, 2, 8, 4, 32, 32, generator=g).cuda()
+    dbg = sfv._lib.dbg_lib()
+    res = []
+    for unit in (1, 0):
+        old = dbg.rbvae_dbg_lstm_unit_threads(unit)
+        try:
+            torch.manual_seed(44)
+            m = sfv.Seq2SeqBinaryVAE(4, 4, 32, 32, variant="percep", input_hw=(32, 32), compute_dtype="bf16").cuda().train()
+            tr = FusedTrainer(m, lr=1e-3, alpha=1.0, beta_kl=1.0, bernoulli_p=0.1, noise_ratio=0.1, device_noise=True,
+                              use_graph=True, seed=78)
+            hist = [tr.step(item, 0.7).clone() for _ in range(3)]
+            torch.cuda.synchronize()
+            res.append((torch.stack(hist).cpu(), tr.gflat.clone(), m._flat.clone()))
+        finally:
+            dbg.rbvae_dbg_lstm_unit_threads(old)
+    (la, ga, wa), (lb, gb, wb) = res
+    assert torch.isfinite(la).all()
+    assert torch.equal(la, lb) and torch.equal(ga, gb) and torch.equal(wa, wb)
