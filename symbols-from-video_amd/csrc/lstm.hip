@@ -775,9 +775,17 @@ __global__ __launch_bounds__(1024) void lstm_pair_fwd_k(const PairArgs p) {
     }
 }
 
+// lanes 0-31 receive the value of lane + 32 (v_permlane32_swap_b32 with both operands the same register: the second result
+// holds [upper half, upper half]); one vector instruction where __shfl_xor(v, 32) is an LDS-crossbar round trip
+__device__ __forceinline__ float from_upper_half(float v) {
+    const unsigned a = __float_as_uint(v);
+    const auto r = __builtin_amdgcn_permlane32_swap(a, a, false, false);
+    return __uint_as_float(r[1]);
+}
+
 // The same wavefront with one WAVE per layer (L == 32): lane (unit j, half hf) holds two gate rows of its unit -- i, f in
 // lanes 0-31, g, o in lanes 32-63 (128 weights in registers) -- forms their pre-activations with the same four accumulator
-// chains per dot product, and lanes 0-31 fetch g, o from their partner lanes (two cross-lane moves) and update the cell at
+// chains per dot product, and lanes 0-31 fetch g, o from their partner lanes (two v_permlane32_swap) and update the cell at
 // once: the activated gates never pass through LDS, so a diagonal needs ONE workgroup barrier of 2 * layers waves instead
 // of two barriers of 16 waves, and the x_t / h_{t-1} vectors are read by half the lanes (the gate-row form spends a third
 // of a step in those broadcast reads: bench step 0.4269 -> 0.4223 ms with three quarters of them removed).  Same
@@ -892,7 +900,7 @@ __global__ __launch_bounds__(512) void lstm_pair_fwd_unit_k(const PairArgs p) {
                 for (int g = 0; g < 2; ++g) acts[o * 4 * L + (2 * hf + g) * L + j] = av[g];
             }
             // lanes 0-31 (i, f) take g, o from lanes 32-63
-            const float gg = __shfl_xor(av[0], 32, 64), og = __shfl_xor(av[1], 32, 64);
+            const float gg = from_upper_half(av[0]), og = from_upper_half(av[1]);
             if (hf == 0) {
                 const float ig = av[0], fg = av[1];
                 const float hpv = t > 0 ? hp[j] : 0.f;
@@ -1488,8 +1496,8 @@ __global__ __launch_bounds__(512) void lstm_pair_bwd_unit_k(const PairBwdArgs p)
             const float px0 = axp[0][0] + axp[0][1], px1 = axp[1][0] + axp[1][1];
             const float ph0 = ahp[0][0] + ahp[0][1], ph1 = ahp[1][0] + ahp[1][1];
             // lanes 0-31 (gate blocks 0, 1) take the sums of blocks 2, 3 from lanes 32-63 and add in block order
-            const float px2 = __shfl_xor(px0, 32, 64), px3 = __shfl_xor(px1, 32, 64);
-            const float ph2 = __shfl_xor(ph0, 32, 64), ph3 = __shfl_xor(ph1, 32, 64);
+            const float px2 = from_upper_half(px0), px3 = from_upper_half(px1);
+            const float ph2 = from_upper_half(ph0), ph3 = from_upper_half(ph1);
             if (hf == 0) {
                 const float dxv = px0 + px1 + px2 + px3;
                 dh_rec = ph0 + ph1 + ph2 + ph3;
