@@ -59,6 +59,7 @@ __device__ __forceinline__ void dl_glds16(const void* g, void* lds) {
                                      (__attribute__((address_space(3))) void*)lds, 16, 0, 0);
 }
 
+template <bool ONE>
 __global__ __launch_bounds__(256, (DL_SL == 1 ? 5 : 3)) void deconv_last_fused_k(const DlArgs p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int KS = p.C1 >> 6;                                        // 128-byte slices per row
@@ -113,7 +114,35 @@ __global__ __launch_bounds__(256, (DL_SL == 1 ? 5 : 3)) void deconv_last_fused_k
     // while slice s is multiplied, so the memory system is never idle between the staging rounds.
     static_assert(SL == 2, "the two slice buffers of the pipelined form");
     constexpr int PIX_I = DL_MROWS / 8, WTS_I = DL_WROWS / 8;         // LDS-DMA instructions of one slice
-    auto stage = [&](int s, int buf) __attribute__((always_inline)) {
+    // The pieces a wave stages are the same for every slice but for the slice's 128-byte offset: source (with its chunk
+    // swizzle; the zero page for padding rows and pixels outside the image) and LDS destination are worked out ONCE per
+    // block -- per slice a piece is then two adds and the LDS-DMA (the row / 17 division, bounds tests and 64-bit address
+    // arithmetic per piece and slice were a third of this kernel's vector instructions; it is half VALU-busy).
+    // (a one-slice layer -- 64 channels, cfg 3 -- has nothing to reuse them for and needs its 94 registers for five workgroups
+    // per CU: ONE compiles the inline form)
+    constexpr int NPIECE = ONE ? 1 : (PIX_I + WTS_I + 3) / 4;
+    const unsigned char* psrc[NPIECE];
+    unsigned pinc[NPIECE], pdst[NPIECE], pbuf[NPIECE];
+#pragma unroll
+    for (int i = 0; i < (ONE ? 0 : NPIECE); ++i) {
+        const int q = w + 4 * i;
+        const bool is_w = q >= PIX_I;
+        const int r = (is_w ? q - PIX_I : q) * 8 + srow;
+        const int sw = (schunk ^ ((r >> 1) & 7)) * 16;
+        const unsigned char* src = p.zero;
+        unsigned inc = 0;
+        if (is_w) {
+            if (r < p.NYP) { src = p.V + ((size_t)r * p.C1) * 2 + sw; inc = 128; }
+        } else if (r < DL_PIX) {
+            const int la = r / DL_HB, lb = r - la * DL_HB;
+            const int a = a0 + la, b = b0 + lb;
+            if (a < p.IH && b < p.IW) { src = p.D2 + ((size_t)((n * p.IH + a) * p.IW + b) * p.C1) * 2 + sw; inc = 128; }
+        }
+        psrc[i] = src; pinc[i] = inc;
+        pdst[i] = (unsigned)((is_w ? (size_t)NBUF * DL_MROWS * 128 : 0) + (size_t)(r - srow) * 128);
+        pbuf[i] = is_w ? DL_WROWS * 128 : DL_MROWS * 128;
+    }
+    auto stage_inline = [&](int s, int buf) __attribute__((always_inline)) {
         for (int q = w; q < PIX_I + WTS_I; q += 4) {
             const bool is_w = q >= PIX_I;
             const int r = (is_w ? q - PIX_I : q) * 8 + srow;
@@ -129,6 +158,14 @@ __global__ __launch_bounds__(256, (DL_SL == 1 ? 5 : 3)) void deconv_last_fused_k
             unsigned char* dst = (is_w ? s_wts + (size_t)buf * DL_WROWS * 128 : s_pix + (size_t)buf * DL_MROWS * 128) +
                                  (size_t)(r - srow) * 128;
             dl_glds16(src, dst);
+        }
+    };
+    auto stage = [&](int s, int buf) __attribute__((always_inline)) {
+        if constexpr (ONE) stage_inline(s, buf);
+        else {
+#pragma unroll
+            for (int i = 0; i < NPIECE; ++i)
+                if (w + 4 * i < PIX_I + WTS_I) dl_glds16(psrc[i] + (size_t)(pinc[i] * (unsigned)s), smem + pdst[i] + pbuf[i] * (unsigned)buf);
         }
     };
     // this wave's LDS-DMA count per slice: q = w, w + 4, ... < 26
@@ -359,14 +396,16 @@ extern "C" int rbvae_deconv_last_fused(int dtype, const void* D2, const void* V,
     a.xr = xr; a.target = target; a.tfm = DlFrameMap{fd1, fd2, fs0, fs1, fs2}; a.ws = target ? ws : nullptr; a.dpre = dpre;
     a.gscale = gscale; a.N = N; a.IH = IH; a.IW = IW; a.C1 = C1; a.NYP = NYP; a.Cout = Cout;
     const size_t lds = dl_lds(C1);
-    static size_t attr_lds = 0;
-    if (lds > attr_lds) {               // dynamic + the kernel's 80 static bytes must stay within the 160 KB of a CU
-        hipError_t e = hipFuncSetAttribute((const void*)deconv_last_fused_k, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           (int)lds);
+    static size_t attr_lds[2] = {0, 0};
+    const int one = C1 == 64;
+    const void* kern = one ? (const void*)deconv_last_fused_k<true> : (const void*)deconv_last_fused_k<false>;
+    if (lds > attr_lds[one]) {               // dynamic + the kernel's 80 static bytes must stay within the 160 KB of a CU
+        hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return fail(RBVAE_E_LAUNCH, "deconv_last_fused: %s (dynamic LDS %zu)", hipGetErrorString(e), lds);
-        attr_lds = lds;
+        attr_lds[one] = lds;
     }
-    hipLaunchKernelGGL(deconv_last_fused_k, dim3(dl_blocks(N, IH, IW)), dim3(256), lds, (hipStream_t)stream, a);
+    if (one) hipLaunchKernelGGL(deconv_last_fused_k<true>, dim3(dl_blocks(N, IH, IW)), dim3(256), lds, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(deconv_last_fused_k<false>, dim3(dl_blocks(N, IH, IW)), dim3(256), lds, (hipStream_t)stream, a);
     RBVAE_CHECK_LAUNCH("deconv_last_fused");
     return RBVAE_OK;
 }
